@@ -1,0 +1,136 @@
+/*
+ * oard.h — C ABI of liboard_hip.so: the MI355X (gfx950) implementation of OA-ReactDiff's
+ * per-timestep denoising call,
+ *
+ *     EGNNDynamics.forward   oa_reactdiff/dynamics/egnn_dynamics.py:63-168
+ *       -> LEFTNet.forward   oa_reactdiff/model/leftnet.py:724-891
+ *
+ * The reference has no FFI of its own (it is pure Python on torch ops); the interface each
+ * entry point replaces is therefore the Python call it stands in for, cited per function.
+ * Conventions: every function returns 0 on success or a negative OARD_E* code; nothing here
+ * synchronises the stream or the device except oard_topology_create (host work + uploads);
+ * all `*_dev` pointers are device pointers on the current HIP device; float tensors are
+ * contiguous row-major fp32; the library never touches torch.
+ */
+#ifndef OARD_H
+#define OARD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OARD_MAX_OBJECTS 8
+
+#define OARD_OK 0
+#define OARD_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define OARD_ENOTCOMPLETE (-2)/* topology is not "complete graph per sample" */
+#define OARD_EHIP (-3)        /* a HIP runtime call failed */
+#define OARD_ENOMEM (-4)      /* workspace too small */
+
+typedef void* oard_stream_t;  /* hipStream_t */
+
+/* Mirrors the constructor arguments of EGNNDynamics / BaseDynamics
+ * (oa_reactdiff/dynamics/_base.py:10-80) and the LEFTNet model_config
+ * (oa_reactdiff/trainer/train_ts1x.py:43-56) that shape the forward pass. */
+typedef struct oard_config {
+    int32_t hidden;          /* hidden_channels H                                   */
+    int32_t num_radial;      /* num_radial R                                        */
+    int32_t num_layers;      /* num_layers L                                        */
+    int32_t in_hidden;       /* in_hidden_channels (= embed_dim + time + conditions) */
+    int32_t n_obj;           /* len(fragment_names)                                 */
+    int32_t node_nf[OARD_MAX_OBJECTS];   /* node_nfs[k] (pos_dim + feature width)   */
+    int32_t enc_alias[OARD_MAX_OBJECTS]; /* encoder/decoder index object k uses
+                                            (enforce_same_encoding, _base.py:110-113) */
+    int32_t condition_nf;
+    int32_t condition_time;  /* bool                                                */
+    int32_t pos_dim;         /* must be 3                                           */
+    float   cutoff;
+    int32_t reflect_equiv;   /* must be 1 (production setting)                      */
+} oard_config;
+
+/* Library / ABI version (major*1000 + minor). */
+int oard_version(void);
+
+/* 0 if this build has kernels for (hidden, num_radial) and the switches in cfg, else OARD_EINVAL. */
+int oard_supported(const oard_config* cfg);
+
+/* ---- weights --------------------------------------------------------------------------------
+ * Replaces: nn.Module parameter storage of EGNNDynamics (state-dict layout in
+ * oareactdiff_amd/spec.py:state_spec == reference state_dict()).  `params_dev[i]` is the device
+ * pointer of the i-th tensor in that canonical order (buffers included; unused tensors may be
+ * NULL).  Packs every Linear into MFMA-fragment order (16x16 chunks) plus the
+ * padded bias / LayerNorm vectors and the constant inter-object edge row.  Call again after
+ * any weight update. */
+size_t oard_param_count(const oard_config* cfg);
+size_t oard_packed_bytes(const oard_config* cfg);
+int oard_pack_weights(const oard_config* cfg, const float* const* params_dev, size_t n_params,
+                      void* packed_dev, size_t packed_bytes, oard_stream_t stream);
+
+/* ---- topology -------------------------------------------------------------------------------
+ * Replaces: what get_edges_index / get_subgraph_mask / compute_frag_index derive from
+ * (combined_mask, n_frag_switch) (oa_reactdiff/utils/_graph_tools.py:9-59,
+ * egnn_dynamics.py:177-182).  Built once per sample() / batch; host arrays in, device index
+ * tables out.  Nodes are given in the reference's order (object-major). */
+typedef struct oard_topology oard_topology;
+
+int oard_topology_create(const oard_config* cfg, const int64_t* combined_mask_host,
+                         const int64_t* n_frag_switch_host, int64_t n_nodes, oard_topology** out);
+void oard_topology_destroy(oard_topology* topo);
+int64_t oard_topology_num_nodes(const oard_topology* topo);
+int64_t oard_topology_num_edges(const oard_topology* topo);        /* sum n_s (n_s - 1)         */
+int64_t oard_topology_num_inner_edges(const oard_topology* topo);  /* same-object ordered pairs */
+int64_t oard_topology_num_samples(const oard_topology* topo);
+/* Writes 1 to *ok_dev iff edge_index_dev ([2,E] int64, row-major) is exactly the edge list
+ * get_edges_index(combined_mask, remove_self_edge=True) would produce for this topology. */
+int oard_topology_check_edge_index(const oard_topology* topo, const int64_t* edge_index_dev,
+                                   int64_t n_edges, int32_t* ok_dev, oard_stream_t stream);
+
+/* ---- forward --------------------------------------------------------------------------------
+ * Replaces: EGNNDynamics.forward(xh, edge_index, t, conditions, n_frag_switch, combined_mask)
+ * (egnn_dynamics.py:63-168) including LEFTNet.forward, for update_pocket_coords=True,
+ * edge_attr=None.  xh_dev[k] / out_dev[k]: [n_k, node_nf[k]].  t_dev: [B] (one per sample) or,
+ * if t_is_scalar, [1].  conditions_dev: [B, condition_nf] (may be NULL when condition_nf==0).
+ * status_dev[0] is set to 1 if the predicted displacement contains a NaN
+ * (egnn_dynamics.py:138-143 — the caller applies the randn replacement). */
+size_t oard_workspace_bytes(const oard_config* cfg, const oard_topology* topo);
+int oard_forward(const oard_config* cfg, const oard_topology* topo, const void* packed_dev,
+                 const float* const* xh_dev, const float* t_dev, int t_is_scalar,
+                 const float* conditions_dev, float* const* out_dev,
+                 void* workspace_dev, size_t workspace_bytes, int32_t* status_dev,
+                 oard_stream_t stream);
+
+/* ---- introspection (tests / profiling) --------------------------------------------------------
+ * Copies an intermediate tensor of the LAST oard_forward on this workspace into dst_dev, in the
+ * reference's node / edge order, dense [rows, cols] fp32.  `which`: see OARD_TAP_*.  `layer`
+ * selects nothing yet (taps hold the state after the final layer) and must be 0. */
+#define OARD_TAP_S 1          /* [N, H]      node scalars s after the last layer            */
+#define OARD_TAP_VEC 2        /* [N, 3*H]    node vectors after the last layer              */
+#define OARD_TAP_EDGE 3       /* [E, 3H+R]   edge state after the last layer                */
+#define OARD_TAP_POS_FRAME 4  /* [N, 3]                                                     */
+#define OARD_TAP_DPOS 5       /* [N, 3]      LEFTNet displacement before CoM removal        */
+#define OARD_TAP_HOUT 6       /* [N, in_hidden]                                             */
+#define OARD_TAP_LABELS 7     /* [N, 1]      frame-group label (as float, reference-order id of the group's first node) */
+#define OARD_TAP_NE1 8         /* [N, 3*H]    CFConvS2V output (leftnet.py:791)              */
+int oard_tap(const oard_config* cfg, const oard_topology* topo, const void* workspace_dev,
+             int which, int layer, float* dst_dev, oard_stream_t stream);
+
+/* Debug: make oard_forward return right after a stage so the taps expose intermediate state.
+ * 0 = run everything (default); 1 = after the init stages (s = NeighborEmb output, edge state =
+ * initial edgeweight); 100 + 10*l + 1 = after layer l's GCL node update; 100 + 10*l + 2 = after
+ * layer l's EquiUpdate. */
+int oard_debug_stop_after(int code);
+
+/* Average duration (ms) and launch count per kernel family since the last reset, measured with
+ * HIP events on the launch stream when timing is enabled (bench.py's roofline leg).
+ * names: "gcl_edge", "equi_edge", "node", "init", "other". */
+int oard_timing_enable(int on);
+int oard_timing_reset(void);
+int oard_timing_get(const char* family, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OARD_H */

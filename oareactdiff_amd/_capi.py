@@ -1,0 +1,83 @@
+"""ctypes binding of liboard_hip.so (include/oard.h).  No CPU fallback: if the library is
+missing or fails to load, importing the HIP backend raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB
+
+OARD_MAX_OBJECTS = 8
+OARD_OK, OARD_EINVAL, OARD_ENOTCOMPLETE, OARD_EHIP, OARD_ENOMEM = 0, -1, -2, -3, -4
+ERRORS = {OARD_EINVAL: "invalid argument / unsupported configuration", OARD_ENOTCOMPLETE: "topology is not complete-per-sample",
+          OARD_EHIP: "HIP runtime error", OARD_ENOMEM: "workspace too small"}
+
+TAP_S, TAP_VEC, TAP_EDGE, TAP_POS_FRAME, TAP_DPOS, TAP_HOUT, TAP_LABELS, TAP_NE1 = 1, 2, 3, 4, 5, 6, 7, 8
+
+EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_bytes", "oard_pack_weights",
+           "oard_topology_create", "oard_topology_destroy", "oard_topology_num_nodes", "oard_topology_num_edges",
+           "oard_topology_num_inner_edges", "oard_topology_num_samples", "oard_topology_check_edge_index",
+           "oard_workspace_bytes", "oard_forward", "oard_tap", "oard_debug_stop_after", "oard_timing_enable", "oard_timing_reset",
+           "oard_timing_get"]
+
+
+class OardConfig(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int32), ("num_radial", C.c_int32), ("num_layers", C.c_int32), ("in_hidden", C.c_int32),
+        ("n_obj", C.c_int32), ("node_nf", C.c_int32 * OARD_MAX_OBJECTS), ("enc_alias", C.c_int32 * OARD_MAX_OBJECTS),
+        ("condition_nf", C.c_int32), ("condition_time", C.c_int32), ("pos_dim", C.c_int32), ("cutoff", C.c_float),
+        ("reflect_equiv", C.c_int32),
+    ]
+
+
+class OardError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != OARD_OK:
+        raise OardError(f"{what} failed: {ERRORS.get(rc, rc)}")
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads the in-tree library (built by `python -m oareactdiff_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise OardError(f"{LIB} not found: build it with `python -m oareactdiff_amd.build` "
+                        "(there is no CPU fallback for the HIP backend)")
+    L = C.CDLL(LIB)
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    cfgp = C.POINTER(OardConfig)
+    L.oard_version.restype = C.c_int
+    L.oard_supported.argtypes = [cfgp]; L.oard_supported.restype = C.c_int
+    L.oard_param_count.argtypes = [cfgp]; L.oard_param_count.restype = sz
+    L.oard_packed_bytes.argtypes = [cfgp]; L.oard_packed_bytes.restype = sz
+    L.oard_pack_weights.argtypes = [cfgp, C.POINTER(vp), sz, vp, sz, vp]; L.oard_pack_weights.restype = C.c_int
+    L.oard_topology_create.argtypes = [cfgp, C.POINTER(i64), C.POINTER(i64), i64, C.POINTER(vp)]
+    L.oard_topology_create.restype = C.c_int
+    L.oard_topology_destroy.argtypes = [vp]; L.oard_topology_destroy.restype = None
+    for f in ("oard_topology_num_nodes", "oard_topology_num_edges", "oard_topology_num_inner_edges",
+              "oard_topology_num_samples"):
+        getattr(L, f).argtypes = [vp]; getattr(L, f).restype = i64
+    L.oard_topology_check_edge_index.argtypes = [vp, vp, i64, vp, vp]; L.oard_topology_check_edge_index.restype = C.c_int
+    L.oard_workspace_bytes.argtypes = [cfgp, vp]; L.oard_workspace_bytes.restype = sz
+    L.oard_forward.argtypes = [cfgp, vp, vp, C.POINTER(vp), vp, C.c_int, vp, C.POINTER(vp), vp, sz, vp, vp]
+    L.oard_forward.restype = C.c_int
+    L.oard_tap.argtypes = [cfgp, vp, vp, C.c_int, C.c_int, vp, vp]; L.oard_tap.restype = C.c_int
+    L.oard_debug_stop_after.argtypes = [C.c_int]; L.oard_debug_stop_after.restype = C.c_int
+    L.oard_timing_enable.argtypes = [C.c_int]; L.oard_timing_enable.restype = C.c_int
+    L.oard_timing_reset.argtypes = []; L.oard_timing_reset.restype = C.c_int
+    L.oard_timing_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]; L.oard_timing_get.restype = C.c_int
+    _lib = L
+    return L
+
+
+def timing_get(family: str):
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    check(lib().oard_timing_get(family.encode(), C.byref(ms), C.byref(n)), "oard_timing_get")
+    return ms.value, n.value

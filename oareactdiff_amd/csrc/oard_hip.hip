@@ -1,0 +1,591 @@
+// oard_hip.hip — host side of liboard_hip.so: the C ABI declared in include/oard.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC oard_hip.hip -o liboard_hip.so
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "oard_kernels.h"
+
+#define OARD_VERSION 1001
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "liboard_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    return OARD_EHIP; } } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// per-family kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+// ------------------------------------------------------------------------------------------------
+namespace {
+enum Family { F_GCL_EDGE = 0, F_EQUI_EDGE, F_NODE, F_INIT, F_OTHER, F_COUNT };
+const char* kFamilyNames[F_COUNT] = {"gcl_edge", "equi_edge", "node", "init", "other"};
+struct TimingRec { hipEvent_t a, b; int fam; };
+struct Timing {
+    bool on = false;
+    std::vector<TimingRec> recs;
+    std::vector<hipEvent_t> pool;
+    double total_ms[F_COUNT] = {0};
+    long long launches[F_COUNT] = {0};
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    void flush() {
+        for (auto& r : recs) {
+            (void)hipEventSynchronize(r.b);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, r.a, r.b);
+            total_ms[r.fam] += ms; launches[r.fam] += 1;
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+} g_timing;
+int g_stop_after = 0;
+
+struct ScopedLaunch {
+    hipStream_t st; hipEvent_t a; int fam; bool on;
+    ScopedLaunch(int f, hipStream_t s) : st(s), fam(f), on(g_timing.on) {
+        if (on) { a = g_timing.get(); (void)hipEventRecord(a, st); }
+    }
+    ~ScopedLaunch() {
+        if (on) { hipEvent_t b = g_timing.get(); (void)hipEventRecord(b, st); g_timing.recs.push_back({a, b, fam}); }
+    }
+};
+#define LAUNCH(fam, kern, grid, block, stream, ...) do { ScopedLaunch sl_(fam, stream); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), 0, stream, __VA_ARGS__); } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+bool config_ok(const oard_config* c) {
+    if (!c) return false;
+    const bool dims = (c->hidden == 196 && c->num_radial == 96) || (c->hidden == 32 && c->num_radial == 8) ||
+                      (c->hidden == 32 && c->num_radial == 32);
+    if (!dims) return false;
+    if (c->num_layers < 1 || c->num_layers > OARD_MAX_LAYERS) return false;
+    if (c->in_hidden < 1 || c->in_hidden > 16) return false;
+    if (c->n_obj < 1 || c->n_obj > OARD_MAX_OBJECTS) return false;
+    if (c->pos_dim != 3 || c->reflect_equiv != 1) return false;
+    const int emb = c->in_hidden - (c->condition_time ? 1 : 0) - (c->condition_nf > 0 ? c->condition_nf : 0);
+    if (emb < 1) return false;
+    for (int k = 0; k < c->n_obj; ++k) {
+        const int d = c->node_nf[k] - 3;
+        if (d < 1 || d > 16) return false;
+        const int a = c->enc_alias[k];
+        if (a < 0 || a >= c->n_obj || c->node_nf[a] != c->node_nf[k]) return false;
+    }
+    return true;
+}
+int embed_dim(const oard_config* c) {
+    return c->in_hidden - (c->condition_time ? 1 : 0) - (c->condition_nf > 0 ? c->condition_nf : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed blob layout
+// ------------------------------------------------------------------------------------------------
+PackOff make_layout(const oard_config* c) {
+    const RDims d(c->hidden, c->num_radial);
+    PackOff po;
+    memset(&po, 0, sizeof(po));
+    size_t cur = 0;
+    auto take = [&](size_t n) { size_t o = cur; cur = align_up(cur + n, 64); return o; };
+    auto mat = [&](int MT, int KB) { return take((size_t)MT * KB * 256); };
+    const int emb = embed_dim(c);
+    po.emb = mat(d.HT, 1); po.emb_b = take(d.HP);
+    po.nbemb = mat(d.HT, 1); po.nbemb_b = take(d.HP);
+    po.s2v = mat(d.HT, d.HT); po.s2v_b = take(d.HP);
+    po.rl0 = mat(d.HT, d.RB); po.rl0_b = take(d.HP);
+    po.rl2 = mat(d.HT, d.HT); po.rl2_b = take(d.HP);
+    po.lin3 = take((size_t)d.H4 * 5 + 1);
+    po.pe0 = take((size_t)d.H2 * 3);
+    po.pe1 = mat(d.HT, d.PB);
+    po.embout = mat(1, d.HT); po.embout_b = take(16);
+    po.v1p = mat(d.HT, d.HT); po.v2p = take(d.HP);
+    po.un0 = mat(d.HT, 2 * d.HT); po.un0_b = take(d.HP);
+    po.un2 = mat(1, d.HT); po.un2_b = take(16);
+    po.c0row = take(d.WP);
+    po.rbf_means = take(d.RP); po.rbf_betas = take(d.RP);
+    for (int k = 0; k < c->n_obj; ++k) {
+        const int dd = c->node_nf[k] - 3;
+        po.enc[k] = take((size_t)2 * dd * dd + 2 * dd + (size_t)emb * 2 * dd + emb);
+        po.dec[k] = take((size_t)2 * dd * emb + 2 * dd + (size_t)dd * 2 * dd + dd);
+    }
+    for (int l = 0; l < c->num_layers; ++l) {
+        LayerOff& lo = po.layer[l];
+        lo.ln_g_w = take(d.HP); lo.ln_g_b = take(d.HP);
+        lo.W1a = mat(d.HT, d.HT); lo.b1 = take(d.HP);
+        lo.W1b = mat(d.HT, d.HT);
+        lo.W1c = mat(d.HT, d.WB);
+        lo.W2 = mat(d.HT, d.HT); lo.b2 = take(d.HP);
+        lo.watt = take(d.HP); lo.batt = take(1);
+        lo.W3 = mat(d.WB, d.HT); lo.b3 = take(d.WP);
+        lo.nm0 = mat(d.HT, 2 * d.HT); lo.nm0b = take(d.HP);
+        lo.nm1 = mat(d.HT, d.HT); lo.nm1b = take(d.HP);
+        lo.ln_q_w = take(d.HP); lo.ln_q_b = take(d.HP);
+        lo.xp0 = mat(d.HT, d.HT);
+        lo.xp2 = mat(3 * d.HT, d.HT);
+        lo.dp0 = mat(d.D1T, d.WB); lo.dp0b = take(d.D1P);
+        lo.dp2 = mat(3 * d.HT, d.D1T); lo.dp2b = take(3 * d.HP);
+        lo.rbfp = mat(3 * d.HT, d.RB);
+        lo.vp = mat(2 * d.HT, d.HT);
+        lo.xv0 = mat(d.HT, 2 * d.HT);
+        lo.xv2 = mat(3 * d.HT, d.HT);
+        lo.l3u = take(593);
+    }
+    po.total = cur;
+    return po;
+}
+
+// canonical parameter order == oareactdiff_amd/spec.py:state_spec == reference state_dict()
+struct ParamIdx {
+    int emb_w, emb_b, embout_w, embout_b, means, betas, nbemb_w, nbemb_b, s2v_w, s2v_b, rl0_w, rl0_b, rl2_w, rl2_b,
+        lin30_w, lin30_b, lin32_w, lin32_b, pe0_w, pe1_w;
+    int gcl0, msg0, upd0, out0, enc0, dec0, count;
+    explicit ParamIdx(const oard_config* c) {
+        int i = 0;
+        emb_w = i++; emb_b = i++; embout_w = i++; embout_b = i++; means = i++; betas = i++;
+        nbemb_w = i++; nbemb_b = i++; s2v_w = i++; s2v_b = i++; rl0_w = i++; rl0_b = i++; rl2_w = i++; rl2_b = i++;
+        lin30_w = i++; lin30_b = i++; lin32_w = i++; lin32_b = i++; pe0_w = i++; pe1_w = i++;
+        i += 2;                                   // distance_embedding (unused in forward)
+        gcl0 = i; i += 14 * c->num_layers;
+        msg0 = i; i += 9 * c->num_layers;
+        upd0 = i; i += 9 * c->num_layers;
+        i += 2;                                   // last_layer (unused in forward)
+        out0 = i; i += 6;
+        enc0 = i; i += 4 * c->n_obj;
+        dec0 = i; i += 4 * c->n_obj;
+        count = i;
+    }
+};
+
+struct Packer {
+    const float* const* p; float* blob; hipStream_t st;
+    void matrix(int src, int src_ld, int col_off, int msl, int msp, int ms, int ksl, int ksp, int ks, int MT, int KB,
+                size_t dst) {
+        PackJob j{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst};
+        const size_t total = (size_t)MT * KB * 256;
+        hipLaunchKernelGGL(k_pack_matrix, dim3((unsigned)std::min<size_t>(cdiv(total, 256), 4096)), dim3(256), 0, st, j, blob);
+    }
+    // natural (unsectioned) matrix [M][K] taken from columns [col_off, col_off+K) of a [M][src_ld] tensor
+    void nat(int src, int src_ld, int col_off, int M, int K, int MT, int KB, size_t dst) {
+        matrix(src, src_ld, col_off, M, MT * 16, 1, K, KB * 16, 1, MT, KB, dst);
+    }
+    void vec(int src, int sect_len, int sect_pad, int sects, int n_dst, size_t dst) {
+        hipLaunchKernelGGL(k_pack_vector, dim3((unsigned)cdiv(n_dst, 256)), dim3(256), 0, st,
+                           src >= 0 ? p[src] : nullptr, blob + dst, sect_len, sect_pad, sects, n_dst);
+    }
+    void raw(int src, int n, size_t dst) {
+        hipLaunchKernelGGL(k_copy_raw, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, p[src], blob + dst, n);
+    }
+};
+static WsOff make_ws(const oard_config* c, const oard_topology* tp) {
+    const RDims d(c->hidden, c->num_radial);
+    const size_t N = tp->d.N, E = std::max<long long>(tp->d.E, 1), A = std::max<long long>(tp->d.A, 1);
+    WsOff w;
+    size_t cur = 0;
+    auto take = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
+    w.pos = take(N * 3 * 4); w.pf64 = take(N * 3 * 8); w.pf32 = take(N * 3 * 4); w.x1 = take(N * 3 * 4);
+    w.pp0 = take(N * 4); w.labels = take(N * 4); w.hin = take(N * 16 * 4);
+    w.zemb = take(N * d.HP * 4); w.nb = take(N * d.HP * 4); w.s = take(N * d.HP * 4); w.s1 = take(N * d.HP * 4);
+    w.ne1 = take(N * 3 * d.HP * 4); w.xh = take(N * d.HP * 4); w.P = take(N * d.HP * 4); w.Q = take(N * d.HP * 4);
+    w.xq = take(N * 3 * d.HP * 4); w.vec = take(N * 3 * d.HP * 4); w.v2buf = take(N * 3 * d.HP * 4);
+    w.sc0 = take(N * d.HP * 4); w.vdot = take(N * d.HP * 4);
+    w.geo = take(A * GEO_STRIDE * 4); w.d64 = take(A * 8); w.rbuf = take(A * d.RP * 4);
+    w.ew = take(E * d.WP * 4); w.mbuf = take(E * d.HP * 4);
+    w.xmsg = take(A * d.HP * 4); w.vmsg = take(A * 3 * d.HP * 4);
+    w.dpos = take(N * 3 * 4); w.hout = take(N * 16 * 4);
+    w.total = cur;
+    return w;
+}
+
+
+template <class D>
+static int forward_impl(const oard_config* c, const oard_topology* topo, const float* wb, const float* const* xh,
+                        const float* t, int t_scalar, const float* cond, float* const* out, char* ws, int* status,
+                        hipStream_t st) {
+    const TopoDev& tp = topo->d;
+    const PackOff po = make_layout(c);
+    const WsOff w = make_ws(c, topo);
+    const int emb = embed_dim(c);
+    float* pos = (float*)(ws + w.pos); double* pf64 = (double*)(ws + w.pf64); float* pf32 = (float*)(ws + w.pf32);
+    float* x1 = (float*)(ws + w.x1); float* pp0 = (float*)(ws + w.pp0); int* labels = (int*)(ws + w.labels);
+    float* hin = (float*)(ws + w.hin); float* zemb = (float*)(ws + w.zemb); float* nb = (float*)(ws + w.nb);
+    float* s = (float*)(ws + w.s); float* s1 = (float*)(ws + w.s1); float* ne1 = (float*)(ws + w.ne1);
+    float* xhb = (float*)(ws + w.xh); float* P = (float*)(ws + w.P); float* Q = (float*)(ws + w.Q);
+    float* xq = (float*)(ws + w.xq); float* vec = (float*)(ws + w.vec); float* v2buf = (float*)(ws + w.v2buf);
+    float* scal = (float*)(ws + w.sc0); float* vdot = (float*)(ws + w.vdot);
+    float* geo = (float*)(ws + w.geo); double* d64 = (double*)(ws + w.d64); float* rbuf = (float*)(ws + w.rbuf);
+    float* ew = (float*)(ws + w.ew); float* mbuf = (float*)(ws + w.mbuf); float* xmsg = (float*)(ws + w.xmsg);
+    float* vmsg = (float*)(ws + w.vmsg); float* dpos = (float*)(ws + w.dpos); float* hout = (float*)(ws + w.hout);
+
+    ObjPtrs op;
+    memset(&op, 0, sizeof(op));
+    for (int k = 0; k < c->n_obj; ++k) {
+        op.xh[k] = xh[k]; op.out[k] = out[k]; op.node_nf[k] = c->node_nf[k]; op.enc[k] = po.enc[k]; op.dec[k] = po.dec[k];
+    }
+    const long long N = tp.N, E = tp.E, A = tp.A;
+    const unsigned gN = (unsigned)cdiv(N, 64), gE = (unsigned)cdiv(E, 64), gA = (unsigned)cdiv(A, 64);
+    const double cutoff = (double)c->cutoff;
+
+    HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), st));
+    LAUNCH(F_OTHER, k_prep, cdiv(N, 128), 128, st, tp, op, wb, pos, hin, t, t_scalar, cond,
+           c->condition_nf > 0 ? c->condition_nf : 0, c->condition_time, emb);
+    LAUNCH(F_INIT, k_geom, tp.n_groups, 64, st, tp, (const float*)pos, cutoff, pf64, pf32, x1, pp0, labels);
+    if (E > 0) LAUNCH(F_INIT, k_fill_edges, std::min<long long>(cdiv(E * (D::WP / 4), 256), 8192), 256, st,
+                      wb + po.c0row, ew, E, D::WP);
+    if (A > 0) {
+        LAUNCH(F_INIT, k_edge_geo, cdiv(A, 256), 256, st, tp, (const float*)pos, (const double*)pf64, cutoff, geo, d64);
+        LAUNCH(F_INIT, k_rbf, cdiv(A * D::RP, 256), 256, st, tp, (const double*)d64, (const float*)geo,
+               wb + po.rbf_means, wb + po.rbf_betas, cutoff, rbuf, ew, D::R, D::RP, D::H, D::WP);
+    }
+    LAUNCH(F_INIT, (k_node_embed<D>), gN, 256, st, tp, wb, po, (const float*)hin, zemb, nb);
+    if (A > 0) LAUNCH(F_INIT, (k_radial_lin<D>), gA, 256, st, tp, wb, po, (const float*)rbuf, (const float*)geo, ew);
+    LAUNCH(F_INIT, (k_neighbor<D>), gN, 256, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s, s1);
+    LAUNCH(F_INIT, (k_s2v_agg<D>), gN, 256, st, tp, (const float*)s1, (const float*)ew, (const float*)geo, ne1);
+    if (A > 0) LAUNCH(F_INIT, (k_scalarize<D>), gA, 256, st, tp, wb, po, (const float*)ne1, (const float*)geo, ew);
+    HIP_TRY(hipMemsetAsync(vec, 0, (size_t)N * 3 * D::HP * sizeof(float), st));
+    if (g_stop_after == 1) return OARD_OK;
+
+    for (int l = 0; l < c->num_layers; ++l) {
+        const LayerOff lo = po.layer[l];
+        LAUNCH(F_NODE, (k_node_pre<D>), gN, 256, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
+        if (E > 0) LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew, mbuf);
+        LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
+        if (g_stop_after == 100 + 10 * l + 1) return OARD_OK;
+        if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew, (const float*)rbuf,
+                          (const float*)geo, (const float*)xq, (const float*)vec, xmsg, vmsg);
+        LAUNCH(F_NODE, (k_equi_agg<D>), gN, 256, st, tp, wb, lo, (const float*)xmsg, (const float*)vmsg, (const float*)x1,
+               s, vec, v2buf, scal, vdot);
+        LAUNCH(F_NODE, (k_equi_upd<D>), gN, 256, st, tp, wb, lo, (const float*)scal, (const float*)vdot,
+               (const float*)v2buf, s, vec);
+        if (g_stop_after == 100 + 10 * l + 2) return OARD_OK;
+    }
+    LAUNCH(F_NODE, (k_out<D>), gN, 256, st, tp, wb, po, (const float*)s, (const float*)vec, dpos, hout, status);
+    LAUNCH(F_OTHER, k_post, cdiv(N, 128), 128, st, tp, op, wb, (const float*)dpos, (const float*)hout, emb);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+#define DISPATCH_DIMS(c, CALL)                                                             \
+    do {                                                                                   \
+        if ((c)->hidden == 196 && (c)->num_radial == 96) { using D = Dims<196, 96>; CALL; } \
+        else if ((c)->hidden == 32 && (c)->num_radial == 8) { using D = Dims<32, 8>; CALL; } \
+        else if ((c)->hidden == 32 && (c)->num_radial == 32) { using D = Dims<32, 32>; CALL; } \
+        else return OARD_EINVAL;                                                           \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int oard_version(void) { return OARD_VERSION; }
+int oard_supported(const oard_config* cfg) { return config_ok(cfg) ? OARD_OK : OARD_EINVAL; }
+size_t oard_param_count(const oard_config* cfg) { return config_ok(cfg) ? (size_t)ParamIdx(cfg).count : 0; }
+size_t oard_packed_bytes(const oard_config* cfg) { return config_ok(cfg) ? make_layout(cfg).total * sizeof(float) : 0; }
+
+int oard_pack_weights(const oard_config* c, const float* const* params, size_t n_params, void* packed,
+                      size_t packed_bytes, oard_stream_t stream) {
+    if (!config_ok(c) || !params || !packed) return OARD_EINVAL;
+    const ParamIdx pi(c);
+    if (n_params != (size_t)pi.count) return OARD_EINVAL;
+    const PackOff po = make_layout(c);
+    if (packed_bytes < po.total * sizeof(float)) return OARD_ENOMEM;
+    const RDims d(c->hidden, c->num_radial);
+    const int H = d.H, R = d.R, W = d.W, C = c->in_hidden, emb = embed_dim(c);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(packed, 0, po.total * sizeof(float), st));
+    Packer pk{params, (float*)packed, st};
+
+    pk.nat(pi.emb_w, C, 0, H, C, d.HT, 1, po.emb);          pk.vec(pi.emb_b, H, d.HP, 1, d.HP, po.emb_b);
+    pk.nat(pi.nbemb_w, C, 0, H, C, d.HT, 1, po.nbemb);      pk.vec(pi.nbemb_b, H, d.HP, 1, d.HP, po.nbemb_b);
+    pk.nat(pi.s2v_w, H, 0, H, H, d.HT, d.HT, po.s2v);       pk.vec(pi.s2v_b, H, d.HP, 1, d.HP, po.s2v_b);
+    pk.nat(pi.rl0_w, R, 0, H, R, d.HT, d.RB, po.rl0);       pk.vec(pi.rl0_b, H, d.HP, 1, d.HP, po.rl0_b);
+    pk.nat(pi.rl2_w, H, 0, H, H, d.HT, d.HT, po.rl2);       pk.vec(pi.rl2_b, H, d.HP, 1, d.HP, po.rl2_b);
+    pk.raw(pi.lin30_w, d.H4 * 3, po.lin3);
+    pk.raw(pi.lin30_b, d.H4, po.lin3 + d.H4 * 3);
+    pk.raw(pi.lin32_w, d.H4, po.lin3 + d.H4 * 4);
+    pk.raw(pi.lin32_b, 1, po.lin3 + d.H4 * 5);
+    pk.raw(pi.pe0_w, d.H2 * 3, po.pe0);
+    pk.nat(pi.pe1_w, d.H2, 0, H, d.H2, d.HT, d.PB, po.pe1);
+    pk.nat(pi.embout_w, H, 0, C, H, 1, d.HT, po.embout);    pk.vec(pi.embout_b, C, 16, 1, 16, po.embout_b);
+    pk.raw(pi.means, R, po.rbf_means);                      pk.raw(pi.betas, R, po.rbf_betas);
+    const int o = pi.out0;                                   // vec1_proj, vec2_proj, update_net.0 (w,b), update_net.2 (w,b)
+    pk.nat(o + 0, H, 0, H, H, d.HT, d.HT, po.v1p);
+    pk.vec(o + 1, H, d.HP, 1, d.HP, po.v2p);
+    pk.matrix(o + 2, 2 * H, 0, H, d.HP, 1, H, d.HP, 2, d.HT, 2 * d.HT, po.un0);   pk.vec(o + 3, H, d.HP, 1, d.HP, po.un0_b);
+    pk.nat(o + 4, H, 0, 2, H, 1, d.HT, po.un2);                                  pk.vec(o + 5, 2, 16, 1, 16, po.un2_b);
+    for (int k = 0; k < c->n_obj; ++k) {
+        const int a = c->enc_alias[k], dd = c->node_nf[k] - 3;
+        const int e = pi.enc0 + 4 * a, q = pi.dec0 + 4 * a;
+        size_t off = po.enc[k];
+        pk.raw(e + 0, 2 * dd * dd, off); off += 2 * dd * dd;
+        pk.raw(e + 1, 2 * dd, off); off += 2 * dd;
+        pk.raw(e + 2, emb * 2 * dd, off); off += emb * 2 * dd;
+        pk.raw(e + 3, emb, off);
+        off = po.dec[k];
+        pk.raw(q + 0, 2 * dd * emb, off); off += 2 * dd * emb;
+        pk.raw(q + 1, 2 * dd, off); off += 2 * dd;
+        pk.raw(q + 2, dd * 2 * dd, off); off += dd * 2 * dd;
+        pk.raw(q + 3, dd, off);
+    }
+    for (int l = 0; l < c->num_layers; ++l) {
+        const LayerOff& lo = po.layer[l];
+        const int g = pi.gcl0 + 14 * l;   // edge_mlp.0 w,b | edge_mlp.1 w,b | node_mlp.0 w,b | node_mlp.1 w,b | edge_out w,b | att w,b | ln w,b
+        const int ld0 = 2 * H + W;
+        pk.nat(g + 0, ld0, 0, H, H, d.HT, d.HT, lo.W1a);     pk.vec(g + 1, H, d.HP, 1, d.HP, lo.b1);
+        pk.nat(g + 0, ld0, H, H, H, d.HT, d.HT, lo.W1b);
+        pk.nat(g + 0, ld0, 2 * H, H, W, d.HT, d.WB, lo.W1c);
+        pk.nat(g + 2, H, 0, H, H, d.HT, d.HT, lo.W2);        pk.vec(g + 3, H, d.HP, 1, d.HP, lo.b2);
+        pk.matrix(g + 4, 2 * H, 0, H, d.HP, 1, H, d.HP, 2, d.HT, 2 * d.HT, lo.nm0);   pk.vec(g + 5, H, d.HP, 1, d.HP, lo.nm0b);
+        pk.nat(g + 6, H, 0, H, H, d.HT, d.HT, lo.nm1);       pk.vec(g + 7, H, d.HP, 1, d.HP, lo.nm1b);
+        pk.nat(g + 8, H, 0, W, H, d.WB, d.HT, lo.W3);        pk.vec(g + 9, W, d.WP, 1, d.WP, lo.b3);
+        pk.vec(g + 10, H, d.HP, 1, d.HP, lo.watt);           pk.raw(g + 11, 1, lo.batt);
+        pk.vec(g + 12, H, d.HP, 1, d.HP, lo.ln_g_w);         pk.vec(g + 13, H, d.HP, 1, d.HP, lo.ln_g_b);
+        const int m = pi.msg0 + 9 * l;    // dir_proj.0 w,b | dir_proj.2 w,b | x_proj.0 w | x_proj.2 w | rbf_proj w | ln w,b
+        pk.nat(m + 0, W, 0, 3 * H, W, d.D1T, d.WB, lo.dp0);   pk.vec(m + 1, 3 * H, d.D1P, 1, d.D1P, lo.dp0b);
+        pk.matrix(m + 2, 3 * H, 0, H, d.HP, 3, 3 * H, d.D1P, 1, 3 * d.HT, d.D1T, lo.dp2);
+        pk.vec(m + 3, H, d.HP, 3, 3 * d.HP, lo.dp2b);
+        pk.nat(m + 4, H, 0, H, H, d.HT, d.HT, lo.xp0);
+        pk.matrix(m + 5, H, 0, H, d.HP, 3, H, d.HP, 1, 3 * d.HT, d.HT, lo.xp2);
+        pk.matrix(m + 6, R, 0, H, d.HP, 3, R, d.RP, 1, 3 * d.HT, d.RB, lo.rbfp);
+        pk.vec(m + 7, H, d.HP, 1, d.HP, lo.ln_q_w);          pk.vec(m + 8, H, d.HP, 1, d.HP, lo.ln_q_b);
+        const int u = pi.upd0 + 9 * l;    // vec_proj w | xvec_proj.0 w | xvec_proj.2 w | lin3.0 w,b | lin3.2 w,b | lin3.4 w,b
+        pk.matrix(u + 0, H, 0, H, d.HP, 2, H, d.HP, 1, 2 * d.HT, d.HT, lo.vp);
+        pk.matrix(u + 1, 2 * H, 0, H, d.HP, 1, H, d.HP, 2, d.HT, 2 * d.HT, lo.xv0);
+        pk.matrix(u + 2, H, 0, H, d.HP, 3, H, d.HP, 1, 3 * d.HT, d.HT, lo.xv2);
+        pk.raw(u + 3, 144, lo.l3u); pk.raw(u + 4, 48, lo.l3u + 144); pk.raw(u + 5, 384, lo.l3u + 192);
+        pk.raw(u + 6, 8, lo.l3u + 576); pk.raw(u + 7, 8, lo.l3u + 584); pk.raw(u + 8, 1, lo.l3u + 592);
+    }
+    hipLaunchKernelGGL(k_c0row, dim3((unsigned)cdiv(d.WP, 256)), dim3(256), 0, st, params[pi.lin30_b], params[pi.lin32_w],
+                       params[pi.lin32_b], params[pi.rl0_b], params[pi.rl2_w], params[pi.rl2_b],
+                       (float*)packed + po.c0row, H, d.H4, d.WP);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// topology
+// ------------------------------------------------------------------------------------------------
+int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t* nfs, int64_t n_nodes,
+                         oard_topology** out) {
+    if (!config_ok(c) || !cm || !nfs || !out || n_nodes < 1 || n_nodes > (1 << 24)) return OARD_EINVAL;
+    const int N = (int)n_nodes, n_obj = c->n_obj;
+    std::vector<int> obj_start(n_obj + 1, 0);
+    for (int i = 0; i < N; ++i) {
+        if (nfs[i] < 0 || nfs[i] >= n_obj) return OARD_EINVAL;
+        if (i > 0 && nfs[i] < nfs[i - 1]) return OARD_EINVAL;           // objects must be contiguous, ascending
+        obj_start[nfs[i] + 1]++;
+    }
+    for (int k = 0; k < n_obj; ++k) obj_start[k + 1] += obj_start[k];
+    std::vector<int64_t> samples(cm, cm + N);
+    std::sort(samples.begin(), samples.end());
+    samples.erase(std::unique(samples.begin(), samples.end()), samples.end());
+    const int B = (int)samples.size();
+    if (samples.front() < 0 || samples.back() > (1 << 30)) return OARD_EINVAL;
+    std::vector<int> dense(N);
+    for (int i = 0; i < N; ++i) dense[i] = (int)(std::lower_bound(samples.begin(), samples.end(), cm[i]) - samples.begin());
+    std::vector<int> order(N);
+    for (int i = 0; i < N; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (dense[a] != dense[b]) return dense[a] < dense[b];
+        return nfs[a] < nfs[b];
+    });
+    std::vector<int> node_obj(N), node_row(N), node_ref(N), node_tidx(N), node_sample(N), sample_ptr(B + 1, 0),
+        grp_ptr((size_t)B * n_obj + 1, 0), edge_ptr(N), act_ptr(N + 1, 0);
+    for (int n = 0; n < N; ++n) {
+        const int r = order[n];
+        node_ref[n] = r; node_obj[n] = (int)nfs[r]; node_row[n] = r - obj_start[nfs[r]];
+        node_tidx[n] = (int)cm[r]; node_sample[n] = dense[r];
+        sample_ptr[dense[r] + 1]++;
+        grp_ptr[(size_t)dense[r] * n_obj + nfs[r] + 1]++;
+    }
+    for (int b = 0; b < B; ++b) sample_ptr[b + 1] += sample_ptr[b];
+    for (size_t q = 0; q < (size_t)B * n_obj; ++q) grp_ptr[q + 1] += grp_ptr[q];
+    long long E = 0, A = 0;
+    int max_group = 0, max_ns = 0;
+    for (int b = 0; b < B; ++b) {
+        const long long ns = sample_ptr[b + 1] - sample_ptr[b];
+        max_ns = std::max(max_ns, (int)ns);
+        for (int n = sample_ptr[b]; n < sample_ptr[b + 1]; ++n) { edge_ptr[n] = (int)E; E += ns - 1; }
+        if (E > 0x7fffffffLL) return OARD_EINVAL;
+    }
+    for (size_t q = 0; q < (size_t)B * n_obj; ++q) {
+        const long long ng = grp_ptr[q + 1] - grp_ptr[q];
+        max_group = std::max(max_group, (int)ng);
+        A += ng * (ng - 1);
+    }
+    if (max_group > OARD_MAX_GROUP || A > 0x7fffffffLL) return OARD_EINVAL;
+    std::vector<int> edge_src((size_t)std::max<long long>(E, 1)), edge_tgt((size_t)std::max<long long>(E, 1));
+    for (int b = 0; b < B; ++b) {
+        const int s0 = sample_ptr[b], s1 = sample_ptr[b + 1];
+        for (int n = s0; n < s1; ++n) {
+            size_t e = (size_t)edge_ptr[n];
+            for (int m = s0; m < s1; ++m) if (m != n) { edge_src[e] = n; edge_tgt[e] = m; ++e; }
+        }
+    }
+    std::vector<int> act_src((size_t)std::max<long long>(A, 1)), act_tgt((size_t)std::max<long long>(A, 1)),
+        act_edge((size_t)std::max<long long>(A, 1));
+    {
+        size_t a = 0;
+        for (int n = 0; n < N; ++n) {
+            const int q = node_sample[n] * n_obj + node_obj[n];
+            const int g0 = grp_ptr[q], g1 = grp_ptr[q + 1], s0 = sample_ptr[node_sample[n]];
+            act_ptr[n] = (int)a;
+            for (int m = g0; m < g1; ++m) if (m != n) {
+                act_src[a] = m; act_tgt[a] = n;
+                act_edge[a] = edge_ptr[m] + (n - s0) - (n > m ? 1 : 0);
+                ++a;
+            }
+        }
+        act_ptr[N] = (int)a;
+    }
+    // reference-order edge offsets: prefix of (n_s - 1) over reference node order
+    std::vector<long long> ref_ptr_ref(N), ref_edge_ptr(N);
+    {
+        long long acc = 0;
+        std::vector<int> ref_to_int(N);
+        for (int n = 0; n < N; ++n) ref_to_int[node_ref[n]] = n;
+        for (int r = 0; r < N; ++r) {
+            ref_ptr_ref[r] = acc;
+            const int b = node_sample[ref_to_int[r]];
+            acc += sample_ptr[b + 1] - sample_ptr[b] - 1;
+        }
+        for (int n = 0; n < N; ++n) ref_edge_ptr[n] = ref_ptr_ref[node_ref[n]];
+    }
+
+    // one device block
+    struct Item { const void* src; size_t bytes; size_t off; };
+    std::vector<Item> items;
+    size_t cur = 0;
+    auto add = [&](const void* p, size_t bytes) { Item it{p, bytes, cur}; cur = align_up(cur + bytes, 256); items.push_back(it); return it.off; };
+    const size_t o_obj = add(node_obj.data(), N * 4), o_row = add(node_row.data(), N * 4), o_ref = add(node_ref.data(), N * 4),
+                 o_tidx = add(node_tidx.data(), N * 4), o_smp = add(node_sample.data(), N * 4),
+                 o_sptr = add(sample_ptr.data(), (B + 1) * 4), o_eptr = add(edge_ptr.data(), N * 4),
+                 o_esrc = add(edge_src.data(), edge_src.size() * 4), o_etgt = add(edge_tgt.data(), edge_tgt.size() * 4),
+                 o_gptr = add(grp_ptr.data(), grp_ptr.size() * 4), o_aptr = add(act_ptr.data(), (N + 1) * 4),
+                 o_asrc = add(act_src.data(), act_src.size() * 4), o_atgt = add(act_tgt.data(), act_tgt.size() * 4),
+                 o_aedge = add(act_edge.data(), act_edge.size() * 4), o_rptr = add(ref_edge_ptr.data(), N * 8);
+    char* dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev, cur));
+    for (auto& it : items) {
+        hipError_t e = hipMemcpy(dev + it.off, it.src, it.bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(dev); return OARD_EHIP; }
+    }
+    oard_topology* tp = new oard_topology();
+    tp->dev_block = dev; tp->max_group = max_group; tp->max_ns = max_ns;
+    TopoDev& d = tp->d;
+    d.N = N; d.B = B; d.n_obj = n_obj; d.n_groups = B * n_obj; d.E = E; d.A = A;
+    d.node_obj = (const int*)(dev + o_obj); d.node_row = (const int*)(dev + o_row); d.node_ref = (const int*)(dev + o_ref);
+    d.node_tidx = (const int*)(dev + o_tidx); d.node_sample = (const int*)(dev + o_smp); d.sample_ptr = (const int*)(dev + o_sptr);
+    d.edge_ptr = (const int*)(dev + o_eptr); d.edge_src = (const int*)(dev + o_esrc); d.edge_tgt = (const int*)(dev + o_etgt);
+    d.grp_ptr = (const int*)(dev + o_gptr); d.act_ptr = (const int*)(dev + o_aptr); d.act_src = (const int*)(dev + o_asrc);
+    d.act_tgt = (const int*)(dev + o_atgt); d.act_edge = (const int*)(dev + o_aedge);
+    d.ref_edge_ptr = (const long long*)(dev + o_rptr);
+    *out = tp;
+    return OARD_OK;
+}
+
+void oard_topology_destroy(oard_topology* tp) {
+    if (!tp) return;
+    if (tp->dev_block) (void)hipFree(tp->dev_block);
+    delete tp;
+}
+int64_t oard_topology_num_nodes(const oard_topology* tp) { return tp ? tp->d.N : 0; }
+int64_t oard_topology_num_edges(const oard_topology* tp) { return tp ? tp->d.E : 0; }
+int64_t oard_topology_num_inner_edges(const oard_topology* tp) { return tp ? tp->d.A : 0; }
+int64_t oard_topology_num_samples(const oard_topology* tp) { return tp ? tp->d.B : 0; }
+
+int oard_topology_check_edge_index(const oard_topology* tp, const int64_t* ei, int64_t n_edges, int32_t* ok,
+                                   oard_stream_t stream) {
+    if (!tp || !ok) return OARD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int one = (n_edges == tp->d.E) ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(ok, &one, sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));      // `one` lives on this stack frame
+    if (one && tp->d.E > 0) {
+        if (!ei) return OARD_EINVAL;
+        hipLaunchKernelGGL(k_check_edges, dim3((unsigned)cdiv(tp->d.E, 256)), dim3(256), 0, st, tp->d,
+                           (const long long*)ei, (long long)n_edges, (int*)ok);
+        HIP_TRY(hipGetLastError());
+    }
+    return OARD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+size_t oard_workspace_bytes(const oard_config* c, const oard_topology* tp) {
+    if (!config_ok(c) || !tp) return 0;
+    return make_ws(c, tp).total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+int oard_forward(const oard_config* c, const oard_topology* topo, const void* packed, const float* const* xh,
+                 const float* t, int t_is_scalar, const float* cond, float* const* out, void* ws, size_t ws_bytes,
+                 int32_t* status, oard_stream_t stream) {
+    if (!config_ok(c) || !topo || !packed || !xh || !out || !ws || !status) return OARD_EINVAL;
+    if (c->condition_time && !t) return OARD_EINVAL;
+    if (c->condition_nf > 0 && !cond) return OARD_EINVAL;
+    if (c->n_obj != topo->d.n_obj) return OARD_EINVAL;
+    if (ws_bytes < make_ws(c, topo).total) return OARD_ENOMEM;
+    int rc = OARD_EINVAL;
+    DISPATCH_DIMS(c, rc = forward_impl<D>(c, topo, (const float*)packed, xh, t, t_is_scalar, cond, out, (char*)ws,
+                                          (int*)status, (hipStream_t)stream));
+    return rc;
+}
+
+int oard_tap(const oard_config* c, const oard_topology* topo, const void* ws_, int which, int layer, float* dst,
+             oard_stream_t stream) {
+    if (!config_ok(c) || !topo || !ws_ || !dst || layer != 0) return OARD_EINVAL;
+    const RDims d(c->hidden, c->num_radial);
+    const WsOff w = make_ws(c, topo);
+    const char* ws = (const char*)ws_;
+    const TopoDev& tp = topo->d;
+    hipStream_t st = (hipStream_t)stream;
+    auto nodes = [&](const float* src, int ld, int sections, int sect_pad, int sect_len) {
+        const long long tot = (long long)tp.N * sections * sect_len;
+        hipLaunchKernelGGL(k_tap_nodes, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, tp, src, ld, sections, sect_pad, sect_len, dst);
+    };
+    switch (which) {
+        case OARD_TAP_S: nodes((const float*)(ws + w.s), d.HP, 1, d.HP, d.H); break;
+        case OARD_TAP_VEC: nodes((const float*)(ws + w.vec), 3 * d.HP, 3, d.HP, d.H); break;
+        case OARD_TAP_NE1: nodes((const float*)(ws + w.ne1), 3 * d.HP, 3, d.HP, d.H); break;
+        case OARD_TAP_POS_FRAME: nodes((const float*)(ws + w.pf32), 3, 1, 3, 3); break;
+        case OARD_TAP_DPOS: nodes((const float*)(ws + w.dpos), 3, 1, 3, 3); break;
+        case OARD_TAP_HOUT: nodes((const float*)(ws + w.hout), 16, 1, 16, c->in_hidden); break;
+        case OARD_TAP_LABELS:
+            hipLaunchKernelGGL(k_tap_labels, dim3((unsigned)cdiv(tp.N, 256)), dim3(256), 0, st, tp, (const int*)(ws + w.labels), dst);
+            break;
+        case OARD_TAP_EDGE:
+            if (tp.E > 0)
+                hipLaunchKernelGGL(k_tap_edges, dim3((unsigned)cdiv(tp.E * d.W, 256)), dim3(256), 0, st, tp,
+                                   (const float*)(ws + w.ew), d.WP, d.W, dst);
+            break;
+        default: return OARD_EINVAL;
+    }
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+int oard_debug_stop_after(int code) { g_stop_after = code; return OARD_OK; }
+int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }
+int oard_timing_reset(void) {
+    g_timing.flush();
+    for (int f = 0; f < F_COUNT; ++f) { g_timing.total_ms[f] = 0; g_timing.launches[f] = 0; }
+    return OARD_OK;
+}
+int oard_timing_get(const char* family, double* total_ms, int64_t* launches) {
+    if (!family || !total_ms || !launches) return OARD_EINVAL;
+    g_timing.flush();
+    for (int f = 0; f < F_COUNT; ++f)
+        if (strcmp(family, kFamilyNames[f]) == 0) { *total_ms = g_timing.total_ms[f]; *launches = g_timing.launches[f]; return OARD_OK; }
+    return OARD_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// oard_layout.h — host-side descriptions shared by the packer and the launcher:
+// compile-time dimension helper, packed-weight offsets, canonical parameter order,
+// topology tables and workspace carving.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/oard.h"
+
+#define OARD_MAX_LAYERS 16
+#define OARD_MAX_GROUP 1024   // atoms per (object, sample) group handled by k_geom
+
+template <int H_, int R_>
+struct Dims {
+    static constexpr int H = H_, R = R_;
+    static constexpr int HT = (H + 15) / 16, HP = HT * 16;          // hidden tiles / padded
+    static constexpr int W = 3 * H + R, WB = (W + 15) / 16, WP = WB * 16;  // edge-state width
+    static constexpr int RB = (R + 15) / 16, RP = RB * 16;
+    static constexpr int H2 = H / 2, PB = (H2 + 15) / 16, PP = PB * 16;    // pos_expansion hidden
+    static constexpr int D1T = (3 * H + 15) / 16, D1P = D1T * 16;          // dir_proj hidden (natural order)
+    static constexpr int H4 = H / 4;                                        // lin3 hidden
+    static_assert(H % 4 == 0 && R % 4 == 0, "feature widths must be multiples of 4");
+};
+
+struct RDims {  // the same numbers at run time
+    int H, R, HT, HP, W, WB, WP, RB, RP, H2, PB, PP, D1T, D1P, H4;
+    explicit RDims(int h, int r) {
+        H = h; R = r; HT = (H + 15) / 16; HP = HT * 16; W = 3 * H + R; WB = (W + 15) / 16; WP = WB * 16;
+        RB = (R + 15) / 16; RP = RB * 16; H2 = H / 2; PB = (H2 + 15) / 16; PP = PB * 16;
+        D1T = (3 * H + 15) / 16; D1P = D1T * 16; H4 = H / 4;
+    }
+};
+
+// ---- packed weight blob: offsets in floats -----------------------------------------------------
+struct LayerOff {
+    // GCLMessage (leftnet.py:128-183)
+    size_t ln_g_w, ln_g_b, W1a, b1, W1b, W1c, W2, b2, watt, batt, W3, b3, nm0, nm0b, nm1, nm1b;
+    // EquiMessage (leftnet.py:186-289)
+    size_t ln_q_w, ln_q_b, xp0, xp2, dp0, dp0b, dp2, dp2b, rbfp;
+    // EquiUpdate (leftnet.py:292-346)
+    size_t vp, xv0, xv2, l3u;   // l3u raw: w0[48*3] b0[48] w2[8*48] b2[8] w4[8] b4[1]
+};
+struct PackOff {
+    size_t emb, emb_b, nbemb, nbemb_b, s2v, s2v_b, rl0, rl0_b, rl2, rl2_b;
+    size_t lin3;      // raw: w0[H4*3] b0[H4] w2[H4] b2[1]
+    size_t pe0;       // raw [H2*3]
+    size_t pe1, embout, embout_b, v1p, v2p, un0, un0_b, un2, un2_b;
+    size_t c0row;     // [WP] constant state of a masked edge
+    size_t rbf_means, rbf_betas;  // [RP]
+    size_t enc[OARD_MAX_OBJECTS], dec[OARD_MAX_OBJECTS];  // raw MLP blocks
+    LayerOff layer[OARD_MAX_LAYERS];
+    size_t total;
+};
+
+// ---- topology tables (device pointers) -----------------------------------------------------------
+struct TopoDev {
+    int N, B, n_obj, n_groups;
+    long long E, A;
+    const int *node_obj, *node_row, *node_ref, *node_tidx, *node_sample, *sample_ptr;
+    const int *edge_ptr, *edge_src, *edge_tgt;
+    const int *grp_ptr;                       // [n_groups+1], group q = sample*n_obj + obj
+    const int *act_ptr, *act_src, *act_tgt, *act_edge;
+    const long long *ref_edge_ptr;            // [N] first reference-order edge of internal node n
+};
+
+struct oard_topology {
+    TopoDev d;
+    void* dev_block;       // one allocation holding every table
+    int max_group;
+    int max_ns;
+};
+
+// ---- workspace carving (byte offsets) --------------------------------------------------------------
+struct WsOff {
+    size_t pos, pf64, pf32, x1, pp0, labels, hin, zemb, nb, s, s1, ne1, xh, P, Q, xq, vec, v2buf, sc0, vdot,
+        geo, d64, rbuf, ew, mbuf, xmsg, vmsg, dpos, hout, total;
+};

@@ -1,0 +1,366 @@
+"""`EGNNDynamics` — drop-in for `oa_reactdiff.dynamics.EGNNDynamics(model=LEFTNet)` whose forward
+pass runs on liboard_hip.so (hand-written gfx950 kernels) through the C ABI in include/oard.h.
+
+Mirrors the reference interface (oa_reactdiff/dynamics/egnn_dynamics.py:14-168,
+oa_reactdiff/dynamics/_base.py:10-132): same constructor arguments, same `forward` signature and
+return convention `(List[Tensor], None)`, same attributes (`encoders`, `decoders`, `model`,
+`pos_dim`, `node_nfs`, `fragment_names`, ...) and the same state-dict names and shapes, so a
+checkpoint's `ddpm.dynamics.*` tensors load with `load_state_dict(strict=True)`.
+
+There is no CPU / eager fallback: `forward` needs tensors on a ROCm device and the built library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _capi
+from .spec import model_dims, rbf_buffers, state_spec
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's module tree (names only)."""
+
+
+def _xavier_names(name: str) -> bool:
+    # layers the reference re-initialises with xavier_uniform_ (leftnet.py:235-242, 318-323, 558-564)
+    keys = ("x_proj.0.weight", "x_proj.2.weight", "rbf_proj.weight", "vec_proj.weight", "xvec_proj.0.weight",
+            "xvec_proj.2.weight", "vec1_proj.weight", "vec2_proj.weight", "update_net.0.weight", "update_net.2.weight")
+    return name.endswith(keys)
+
+
+class EGNNDynamics(nn.Module):
+    def __init__(
+        self,
+        model_config: Dict,
+        fragment_names: List[str],
+        node_nfs: List[int],
+        edge_nf: int,
+        condition_nf: int = 0,
+        pos_dim: int = 3,
+        update_pocket_coords: bool = True,
+        condition_time: bool = True,
+        edge_cutoff: Optional[float] = None,
+        model=None,
+        device: torch.device = torch.device("cuda"),
+        enforce_same_encoding: Optional[List] = None,
+        source: Optional[Dict] = None,
+    ) -> None:
+        super().__init__()
+        assert len(node_nfs) == len(fragment_names)                       # _base.py:44-46
+        for nf in node_nfs:
+            assert nf > pos_dim
+        if "act_fn" not in model_config:                                  # _base.py:47-50 (mutates the dict)
+            model_config["act_fn"] = "swish"
+        if "in_node_nf" not in model_config:
+            model_config["in_node_nf"] = model_config["in_hidden_channels"]
+        if model is not None and getattr(model, "__name__", "LEFTNet") != "LEFTNet":
+            raise NotImplementedError("the MI355X backend implements the LEFTNet denoiser only")
+        if model_config["act_fn"] not in ("swish", "silu"):
+            raise NotImplementedError("only the swish/silu activation is implemented")
+        for key, want in (("legacy", True), ("update", True), ("pos_grad", False), ("single_layer_output", True),
+                          ("object_aware", True), ("reflect_equiv", True), ("for_conf", False), ("ff", False)):
+            if model_config.get(key, want) != want:
+                raise NotImplementedError(f"model_config[{key!r}] must be {want} for the MI355X backend")
+        if "in_edge_nf" in model_config:
+            raise NotImplementedError("edge attributes are not part of the LEFTNet denoising path")
+        model_config.setdefault("in_hidden_channels", 8)
+        self.model_config = model_config
+        self.node_nfs = node_nfs
+        self.edge_nf = edge_nf
+        self.condition_nf = condition_nf
+        self.fragment_names = fragment_names
+        self.pos_dim = pos_dim
+        self.update_pocket_coords = update_pocket_coords
+        self.condition_time = condition_time
+        self.edge_cutoff = edge_cutoff
+        self.device = device
+        self.dist_dim = 0
+        self.embed_dim = model_config["in_node_nf"]                       # _base.py:69-77
+        self.edge_embed_dim = 0
+        if condition_time:
+            self.embed_dim -= 1
+        if condition_nf > 0:
+            self.embed_dim -= condition_nf
+        assert self.embed_dim > 0
+        self.edge_encoder, self.edge_decoder = None, None
+
+        H, R, L, Cc = model_dims(model_config)
+        self._dims = (H, R, L, Cc)
+        self._spec = state_spec(model_config, node_nfs, condition_nf, pos_dim, condition_time)
+        self.model = _Node()
+        self.encoders = nn.ModuleList([_Node() for _ in node_nfs])
+        self.decoders = nn.ModuleList([_Node() for _ in node_nfs])
+        means, betas = rbf_buffers(R, float(model_config.get("cutoff", 10.0)))
+        for name, (shape, kind, fan_in) in self._spec.items():
+            parts = name.split(".")
+            mod: nn.Module = self
+            for p in parts[:-1]:
+                if p.isdigit() and isinstance(mod, nn.ModuleList):
+                    mod = mod[int(p)]
+                else:
+                    if not hasattr(mod, p):
+                        mod.add_module(p, _Node())
+                    mod = getattr(mod, p)
+            leaf = parts[-1]
+            if kind == "buf_means":
+                mod.register_buffer(leaf, means.clone().to(device))
+            elif kind == "buf_betas":
+                mod.register_buffer(leaf, betas.clone().to(device))
+            else:
+                t = torch.empty(shape, dtype=torch.float32, device=device)
+                if kind == "ln_w":
+                    nn.init.ones_(t)
+                elif kind == "ln_b":
+                    nn.init.zeros_(t)
+                elif kind == "w" and _xavier_names(name):
+                    nn.init.xavier_uniform_(t)
+                elif kind == "b" and ".update_net." in name:
+                    nn.init.zeros_(t)
+                else:
+                    bound = 1.0 / math.sqrt(fan_in)                      # nn.Linear default scale
+                    nn.init.uniform_(t, -bound, bound)
+                mod.register_parameter(leaf, nn.Parameter(t))
+        if enforce_same_encoding is not None:                             # _base.py:110-113
+            for ii in enforce_same_encoding:
+                self.encoders[ii] = self.encoders[0]
+                self.decoders[ii] = self.decoders[0]
+        if source is not None:                                            # _base.py:65-66, 114-116
+            self.model.load_state_dict(source["model"])
+            self.encoders.load_state_dict(source["encoders"])
+            self.decoders.load_state_dict(source["decoders"])
+
+        #: "sync": reference behaviour (egnn_dynamics.py:138-143) — one host sync per call, NaN -> randn.
+        #: "async": no host sync; the device-side flag is kept in `self.last_status`.
+        self.nan_check = "sync"
+        self.last_status: Optional[Tensor] = None
+        self._packed: Optional[Tensor] = None
+        self._packed_key = None
+        self._topo_cache: "OrderedDict[tuple, _Topology]" = OrderedDict()
+        self._ws: Optional[Tensor] = None
+        self._last_topo: Optional["_Topology"] = None
+
+    # ------------------------------------------------------------------------------------------
+    def _config(self) -> _capi.OardConfig:
+        H, R, L, Cc = self._dims
+        cfg = _capi.OardConfig()
+        cfg.hidden, cfg.num_radial, cfg.num_layers, cfg.in_hidden = H, R, L, Cc
+        cfg.n_obj = len(self.node_nfs)
+        for k, nf in enumerate(self.node_nfs):
+            cfg.node_nf[k] = nf
+            cfg.enc_alias[k] = k      # aliasing is resolved through the parameter pointers we pass
+        cfg.condition_nf = self.condition_nf
+        cfg.condition_time = 1 if self.condition_time else 0
+        cfg.pos_dim = self.pos_dim
+        cfg.cutoff = float(self.model_config.get("cutoff", 10.0))
+        cfg.reflect_equiv = 1
+        return cfg
+
+    def _ordered_tensors(self) -> List[Tensor]:
+        """Tensors in the canonical order of include/oard.h (== state_spec order); encoder/decoder
+        slots follow whatever module currently sits in `self.encoders[k]` / `self.decoders[k]`."""
+        out: List[Tensor] = []
+        for name in self._spec:
+            parts = name.split(".")
+            mod: nn.Module = self
+            for p in parts[:-1]:
+                mod = mod[int(p)] if (p.isdigit() and isinstance(mod, nn.ModuleList)) else getattr(mod, p)
+            out.append(getattr(mod, parts[-1]))
+        return out
+
+    def _get_packed(self, cfg: _capi.OardConfig, stream: int) -> Tensor:
+        tensors = self._ordered_tensors()
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        L = _capi.lib()
+        dev = tensors[0].device
+        for t in tensors:
+            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _capi.OardError("parameters must be contiguous float32 tensors on one ROCm device")
+        n = L.oard_param_count(C.byref(cfg))
+        if n != len(tensors):
+            raise _capi.OardError(f"parameter count mismatch: library expects {n}, module has {len(tensors)}")
+        nbytes = L.oard_packed_bytes(C.byref(cfg))
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        _capi.check(L.oard_pack_weights(C.byref(cfg), ptrs, n, packed.data_ptr(), nbytes, stream), "oard_pack_weights")
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    def _get_topology(self, cfg, edge_index: Tensor, n_frag_switch: Tensor, combined_mask: Tensor,
+                      stream: int) -> "_Topology":
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
+               n_frag_switch.data_ptr(), n_frag_switch._version, combined_mask.data_ptr(), combined_mask._version,
+               combined_mask.numel())
+        topo = self._topo_cache.get(key)
+        if topo is not None:
+            self._topo_cache.move_to_end(key)
+            return topo
+        topo = _Topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+        self._topo_cache[key] = topo
+        while len(self._topo_cache) > 8:
+            self._topo_cache.popitem(last=False)
+        return topo
+
+    # ------------------------------------------------------------------------------------------
+    def forward(
+        self,
+        xh: List[Tensor],
+        edge_index: Tensor,
+        t: Tensor,
+        conditions: Tensor,
+        n_frag_switch: Tensor,
+        combined_mask: Tensor,
+        edge_attr: Optional[Tensor] = None,
+    ) -> Tuple[List[Tensor], Optional[Tensor]]:
+        if not self.update_pocket_coords:
+            raise NotImplementedError                                     # egnn_dynamics.py:125
+        if edge_attr is not None:
+            raise NotImplementedError("edge attributes are not part of the LEFTNet denoising path")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the MI355X backend is forward-only in this release: call it under "
+                                      "torch.no_grad() (sampling / inpainting)")
+        dev = xh[0].device
+        if dev.type != "cuda":
+            raise _capi.OardError("EGNNDynamics.forward needs tensors on a ROCm device (no CPU fallback)")
+        L = _capi.lib()
+        cfg = self._config()
+        _capi.check(L.oard_supported(C.byref(cfg)), "oard_supported (hidden_channels/num_radial not built)")
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            packed = self._get_packed(cfg, stream)
+            topo = self._get_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+            n_obj = len(self.node_nfs)
+            xs = []
+            for k in range(n_obj):
+                x = xh[k]
+                if x.dtype != torch.float32 or not x.is_contiguous():
+                    x = x.contiguous().float()
+                if x.shape != (topo.obj_counts[k], self.node_nfs[k]):
+                    raise _capi.OardError(f"xh[{k}] has shape {tuple(x.shape)}, expected "
+                                          f"{(topo.obj_counts[k], self.node_nfs[k])}")
+                xs.append(x)
+            outs = [torch.empty_like(x) for x in xs]
+            t_scalar = 1 if t.dim() == 1 else 0
+            tt = t.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+            if not t_scalar and tt.numel() <= topo.max_sample_id:
+                raise _capi.OardError("t has fewer rows than samples")
+            cond = None
+            if self.condition_nf > 0:
+                cond = conditions.detach().to(device=dev, dtype=torch.float32).contiguous()
+                if cond.shape[0] <= topo.max_sample_id or cond.shape[1] != self.condition_nf:
+                    raise _capi.OardError("conditions has the wrong shape")
+            need = L.oard_workspace_bytes(C.byref(cfg), topo.handle)
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            status = torch.zeros(2, dtype=torch.int32, device=dev)
+            xp = (C.c_void_p * n_obj)(*[x.data_ptr() for x in xs])
+            op = (C.c_void_p * n_obj)(*[o.data_ptr() for o in outs])
+            rc = L.oard_forward(C.byref(cfg), topo.handle, packed.data_ptr(), xp, tt.data_ptr(), t_scalar,
+                                cond.data_ptr() if cond is not None else None, op, self._ws.data_ptr(),
+                                self._ws.numel(), status.data_ptr(), stream)
+            _capi.check(rc, "oard_forward")
+            self._last_topo = topo
+            self.last_status = status
+            if self.nan_check == "sync" and int(status[0].item()) != 0:   # egnn_dynamics.py:138-143
+                print("Warning: detected nan in pos, resetting EGNN output to randn.")
+                for k in range(n_obj):
+                    v = torch.randn_like(outs[k][:, : self.pos_dim])
+                    idx = topo.obj_masks[k]
+                    if v.shape[0]:
+                        mean = torch.zeros(int(idx.max()) + 1, self.pos_dim, device=dev).index_add_(0, idx, v)
+                        cnt = torch.zeros(int(idx.max()) + 1, device=dev).index_add_(0, idx, torch.ones_like(idx, dtype=v.dtype))
+                        v = v - (mean / cnt.clamp(min=1).unsqueeze(1))[idx]
+                    outs[k][:, : self.pos_dim] = v
+        return outs, None
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def debug_tap(self, which: int) -> Tensor:
+        """Intermediate tensor of the last forward (reference node/edge order); tests only."""
+        topo = self._last_topo
+        assert topo is not None and self._ws is not None
+        H, R, L_, Cc = self._dims
+        cfg = self._config()
+        shape = {
+            _capi.TAP_S: (topo.n_nodes, H), _capi.TAP_VEC: (topo.n_nodes, 3 * H), _capi.TAP_EDGE: (topo.n_edges, 3 * H + R),
+            _capi.TAP_POS_FRAME: (topo.n_nodes, 3), _capi.TAP_DPOS: (topo.n_nodes, 3), _capi.TAP_HOUT: (topo.n_nodes, Cc),
+            _capi.TAP_LABELS: (topo.n_nodes, 1), _capi.TAP_NE1: (topo.n_nodes, 3 * H),
+        }[which]
+        dst = torch.empty(shape, dtype=torch.float32, device=self._ws.device)
+        with torch.cuda.device(dst.device):
+            stream = torch.cuda.current_stream(dst.device).cuda_stream
+            _capi.check(_capi.lib().oard_tap(C.byref(cfg), topo.handle, self._ws.data_ptr(), which, 0, dst.data_ptr(), stream),
+                        "oard_tap")
+        return dst
+
+    @staticmethod
+    def compute_frag_index(n_frag_switch: Tensor):
+        """egnn_dynamics.py:177-182."""
+        import numpy as np
+        counts = [int((n_frag_switch == ii).sum()) for ii in torch.unique(n_frag_switch)]
+        return np.concatenate([np.array([0]), np.cumsum(counts)])
+
+    @staticmethod
+    def remove_mean_batch(x: Tensor, indices: Tensor) -> Tensor:
+        """egnn_dynamics.py:268-271."""
+        n = int(indices.max()) + 1 if indices.numel() else 0
+        s = torch.zeros(n, x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, indices, x)
+        c = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, indices, torch.ones_like(indices, dtype=x.dtype))
+        return x - (s / c.clamp(min=1).unsqueeze(1))[indices]
+
+
+class _Topology:
+    """Device index tables for one (combined_mask, n_frag_switch, edge_index) triple."""
+
+    def __init__(self, cfg, edge_index: Tensor, n_frag_switch: Tensor, combined_mask: Tensor, stream: int):
+        L = _capi.lib()
+        cm = combined_mask.detach().to("cpu", torch.int64).contiguous()          # one-off host copy
+        nfs = n_frag_switch.detach().to("cpu", torch.int64).contiguous()
+        if cm.numel() != nfs.numel() or cm.numel() == 0:
+            raise _capi.OardError("combined_mask / n_frag_switch size mismatch")
+        h = C.c_void_p()
+        rc = L.oard_topology_create(C.byref(cfg), C.cast(cm.data_ptr(), C.POINTER(C.c_int64)),
+                                    C.cast(nfs.data_ptr(), C.POINTER(C.c_int64)), cm.numel(), C.byref(h))
+        _capi.check(rc, "oard_topology_create (n_frag_switch must be object-major, group size <= 1024)")
+        self.handle = h
+        self._lib = L
+        self.n_nodes = int(L.oard_topology_num_nodes(h))
+        self.n_edges = int(L.oard_topology_num_edges(h))
+        self.n_inner = int(L.oard_topology_num_inner_edges(h))
+        self.n_samples = int(L.oard_topology_num_samples(h))
+        self.max_sample_id = int(cm.max())
+        n_obj = cfg.n_obj
+        self.obj_counts = [int((nfs == k).sum()) for k in range(n_obj)]
+        dev = combined_mask.device
+        starts = [0]
+        for c in self.obj_counts:
+            starts.append(starts[-1] + c)
+        self.obj_masks = [combined_mask.detach()[starts[k]: starts[k + 1]].to(torch.int64) for k in range(n_obj)]
+        # the kernels assume the complete-per-sample graph in the reference's edge order: verify once
+        ei = edge_index.detach()
+        if ei.dim() != 2 or ei.shape[0] != 2 or ei.dtype != torch.int64 or ei.device != dev:
+            raise _capi.OardError("edge_index must be an int64 [2, E] tensor on the same device")
+        ei = ei.contiguous()
+        ok = torch.zeros(1, dtype=torch.int32, device=dev)
+        _capi.check(L.oard_topology_check_edge_index(h, ei.data_ptr(), ei.shape[1], ok.data_ptr(), stream),
+                    "oard_topology_check_edge_index")
+        if int(ok.item()) != 1:
+            L.oard_topology_destroy(h)
+            self.handle = None
+            raise _capi.OardError(
+                "edge_index is not get_edges_index(combined_mask, remove_self_edge=True): the MI355X backend "
+                "implements the complete-graph-per-sample topology the diffusion sampler/trainer uses")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.oard_topology_destroy(self.handle)
+        except Exception:
+            pass
