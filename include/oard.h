@@ -122,6 +122,9 @@ int oard_tap(const oard_config* cfg, const oard_topology* topo, const void* work
  * initial edgeweight); 100 + 10*l + 1 = after layer l's GCL node update; 100 + 10*l + 2 = after
  * layer l's EquiUpdate. */
 int oard_debug_stop_after(int code);
+/* Kernel-variant switches for A/B measurements: "gcl_variant" / "equi_variant" (0 = weights straight
+ * from L2, >= 1 = LDS-streamed variants, see oard_hip.hip). */
+int oard_debug_option(const char* name, int value);
 
 /* Average duration (ms) and launch count per kernel family since the last reset, measured with
  * HIP events on the launch stream when timing is enabled (bench.py's roofline leg).

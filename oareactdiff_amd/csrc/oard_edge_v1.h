@@ -1,0 +1,432 @@
+// oard_edge_v1.h — the two hot per-layer edge kernels with the weights streamed through LDS.
+//
+// All waves of a workgroup walk the same sequence of weight chunks, so the sequence is packed once
+// per layer in consumption order ("stream") and moved HBM/L2 -> LDS by global_load_lds (LDS-DMA, no
+// VGPR round trip) one phase ahead of its use: two slabs, one __syncthreads() per phase.  Every wave
+// reads its A operand from LDS (ds_read_b128, lane-linear, conflict-free) and keeps its B operands and
+// accumulators in registers.  Per-feature biases travel in the same stream as "bias chunks", node-side
+// terms initialise the accumulators before the first DMA is issued, and the only ordinary global loads
+// inside the phase loop are the edge-state blocks, prefetched one phase ahead in the same rhythm —
+// so no s_waitcnt vmcnt(0) ever has to wait for an in-flight DMA except the one at the phase barrier.
+#pragma once
+#include "oard_kernels.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// one 1-KiB chunk: per-lane global source, wave-uniform LDS destination (+ lane*16 by hardware)
+OARD_DEV void glds16(const float* gsrc_lane, float* lds_chunk) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc_lane, (lds_ptr_t)lds_chunk, 16, 0, 0);
+}
+
+// acc[i] += a x b[i] for NA independent accumulators, k-steps outermost so consecutive MFMAs never
+// depend on each other (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency)
+template <int NA>
+OARD_DEV void mma_shared_a(f4 a, const f4 (&b)[NA], f4 (&acc)[NA]) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[i].x, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[i].y, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[i].z, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[i].w, acc[i], 0, 0, 0);
+}
+// two (a, b, acc) triples interleaved
+OARD_DEV void mma_pair(f4 a0, f4 b0, f4& c0, f4 a1, f4 b1, f4& c1) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, c1, 0, 0, 0);
+}
+
+// =====================================================================================================
+// GCLMessage edge part, all edges.  Stream (chunks): S1 = WB groups x HT  [W1c, K-outer];
+// S2 = (HT+1) groups x (1+HT)  [bias b2 | W2 tile t] + gate group [batt | watt as a 1-row tile];
+// S3 = WB groups x (1+HT)  [bias b3 | W3 tile t].
+// =====================================================================================================
+template <class D, int GP>
+struct GclStream {
+    static constexpr int HT = D::HT, WB = D::WB, G1 = HT, G2 = HT + 1, NG2 = HT + 1;
+    static constexpr int SLAB = GP * G2;                       // chunks per slab
+    static constexpr int NP1 = (WB + GP - 1) / GP, NP2 = (NG2 + GP - 1) / GP, NP3 = NP1, NPH = NP1 + NP2 + NP3;
+    static constexpr int C1 = WB * G1, C2 = NG2 * G2, C3 = WB * G2, CHUNKS = C1 + C2 + C3;
+    static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
+};
+
+template <class D, int NB, int WAVES, int GP>
+__global__ __launch_bounds__(WAVES * 64) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
+                                                            const float* __restrict__ P, const float* __restrict__ Q,
+                                                            float* __restrict__ ew, float* __restrict__ mbuf) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using S = GclStream<D, GP>;
+    constexpr int HT = D::HT, WB = D::WB, G1 = S::G1, G2 = S::G2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+
+    auto issue = [&](int p) {
+        if (p >= S::NPH) return;
+        int start, n;
+        if (p < S::NP1) { start = p * GP * G1; n = min(GP, WB - p * GP) * G1; }
+        else if (p < S::NP1 + S::NP2) { const int q = p - S::NP1; start = S::C1 + q * GP * G2; n = min(GP, S::NG2 - q * GP) * G2; }
+        else { const int q = p - S::NP1 - S::NP2; start = S::C1 + S::C2 + q * GP * G2; n = min(GP, WB - q * GP) * G2; }
+        float* dst = smem + (size_t)(p & 1) * S::SLAB * 256;
+        const float* src = stream + (size_t)start * 256 + lane * 4;
+        for (int j = wave; j < n; j += WAVES) glds16(src + (size_t)j * 256, dst + j * 256);
+    };
+    auto A = [&](int p, int j) -> f4 {
+        return *reinterpret_cast<const f4*>(smem + ((size_t)(p & 1) * S::SLAB + j) * 256 + lane * 4);
+    };
+
+    // columns of this wave; every wave stays in the barrier protocol even if its columns are padding
+    const long long colbase = ((long long)blockIdx.x * WAVES + wave) * (NB * 16) + (lane & 15);
+    bool valid[NB];
+    size_t e[NB];
+    float* erow[NB];
+    f4 h1[NB][HT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const long long c = colbase + nb * 16;
+        valid[nb] = c < tp.E;
+        e[nb] = (size_t)(valid[nb] ? c : tp.E - 1);
+        erow[nb] = ew + e[nb] * D::WP + 4 * g;
+        const int src = tp.edge_src[e[nb]], tgt = tp.edge_tgt[e[nb]];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) h1[nb][t] = ld_blk(P, src, D::HP, t, lane) + ld_blk(Q, tgt, D::HP, t, lane);
+    }
+    f4 xn[GP][NB];
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) xn[gg][nb] = gg < WB ? ld_f4(erow[nb] + 16 * gg) : f4zero();
+    issue(0);
+
+    int p = 0;
+    // ---- S1: h1 += W1c . ew   (K-outer) -------------------------------------------------------------
+    for (int p1 = 0; p1 < S::NP1; ++p1, ++p) {
+        __syncthreads();
+        f4 x[GP][NB];
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) x[gg][nb] = xn[gg][nb];
+        issue(p + 1);
+        if (p1 + 1 < S::NP1) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) {
+                const int b = (p1 + 1) * GP + gg;
+                if (b < WB)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) xn[gg][nb] = ld_f4(erow[nb] + 16 * b);
+            }
+        }
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) {
+            if (p1 * GP + gg < WB) {
+                if (NB >= 2) {
+#pragma unroll
+                    for (int t = 0; t < HT; ++t) {
+                        const f4 a = A(p, gg * G1 + t);
+                        f4 acc[NB], xb[NB];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) { acc[nb] = h1[nb][t]; xb[nb] = x[gg][nb]; }
+                        mma_shared_a<NB>(a, xb, acc);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) h1[nb][t] = acc[nb];
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t + 1 < HT; t += 2)
+                        mma_pair(A(p, gg * G1 + t), x[gg][0], h1[0][t], A(p, gg * G1 + t + 1), x[gg][0], h1[0][t + 1]);
+                    if (HT & 1) h1[0][HT - 1] = mma_chunk(A(p, gg * G1 + HT - 1), x[gg][0], h1[0][HT - 1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int t = 0; t < HT; ++t) h1[nb][t] = silu4(h1[nb][t]);
+
+    // ---- S2: m = SiLU(W2 h1 + b2); gate = SiLU(watt . m + batt) ---------------------------------------
+    f4 m[NB][HT];
+    f4 on[GP][NB];
+    // note: the gate tile is computed from h1?  no — from m; it is the last group of S2 and uses m as B operand
+#pragma unroll
+    for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
+        __syncthreads();
+        issue(p + 1);
+        if (p2 == S::NP2 - 1) {                     // prefetch the old edge-state tiles of S3's first phase
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) on[gg][nb] = gg < WB ? ld_f4(erow[nb] + 16 * gg) : f4zero();
+        }
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) {
+            const int tg = p2 * GP + gg;            // compile-time after unrolling
+            if (tg < S::NG2) {
+                const f4 bias = A(p, gg * G2);
+                if (NB >= 2) {
+                    f4 acc[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = bias;
+#pragma unroll
+                    for (int b = 0; b < HT; ++b) {
+                        f4 xb[NB];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) xb[nb] = tg < HT ? h1[nb][b] : m[nb][b];
+                        mma_shared_a<NB>(A(p, gg * G2 + 1 + b), xb, acc);
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        if (tg < HT) m[nb][tg] = silu4(acc[nb]);
+                        else {
+                            const float gate = silu1(__shfl(acc[nb].x, lane & 15, 64));
+#pragma unroll
+                            for (int t = 0; t < HT; ++t) m[nb][t] *= gate;
+                        }
+                    }
+                } else {
+                    f4 c0 = bias, c1 = f4zero();
+#pragma unroll
+                    for (int b = 0; b + 1 < HT; b += 2)
+                        mma_pair(A(p, gg * G2 + 1 + b), tg < HT ? h1[0][b] : m[0][b], c0,
+                                 A(p, gg * G2 + 2 + b), tg < HT ? h1[0][b + 1] : m[0][b + 1], c1);
+                    if (HT & 1) c0 = mma_chunk(A(p, gg * G2 + HT), tg < HT ? h1[0][HT - 1] : m[0][HT - 1], c0);
+                    const f4 acc = c0 + c1;
+                    if (tg < HT) m[0][tg] = silu4(acc);
+                    else {
+                        const float gate = silu1(__shfl(acc.x, lane & 15, 64));
+#pragma unroll
+                        for (int t = 0; t < HT; ++t) m[0][t] *= gate;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        if (valid[nb])
+#pragma unroll
+            for (int t = 0; t < HT; ++t) st_blk(mbuf, e[nb], D::HP, t, lane, m[nb][t]);
+
+    // ---- S3: ew += SiLU(W3 m + b3), one output tile per group ----------------------------------------
+    for (int p3 = 0; p3 < S::NP3; ++p3, ++p) {
+        __syncthreads();
+        f4 o[GP][NB];
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) o[gg][nb] = on[gg][nb];
+        issue(p + 1);
+        if (p3 + 1 < S::NP3) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) {
+                const int t = (p3 + 1) * GP + gg;
+                if (t < WB)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) on[gg][nb] = ld_f4(erow[nb] + 16 * t);
+            }
+        }
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) {
+            const int t = p3 * GP + gg;
+            if (t < WB) {
+                const f4 bias = A(p, gg * G2);
+                if (NB >= 2) {
+                    f4 acc[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = bias;
+#pragma unroll
+                    for (int b = 0; b < HT; ++b) {
+                        f4 xb[NB];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) xb[nb] = m[nb][b];
+                        mma_shared_a<NB>(A(p, gg * G2 + 1 + b), xb, acc);
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        if (valid[nb]) st_f4(erow[nb] + 16 * t, o[gg][nb] + silu4(acc[nb]));
+                } else {
+                    f4 c0 = bias, c1 = f4zero();
+#pragma unroll
+                    for (int b = 0; b + 1 < HT; b += 2)
+                        mma_pair(A(p, gg * G2 + 1 + b), m[0][b], c0, A(p, gg * G2 + 2 + b), m[0][b + 1], c1);
+                    if (HT & 1) c0 = mma_chunk(A(p, gg * G2 + HT), m[0][HT - 1], c0);
+                    if (valid[0]) st_f4(erow[0] + 16 * t, o[gg][0] + silu4(c0 + c1));
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// EquiMessage edge part, inner edges sorted by target.  Stream: T1 = WB groups x D1T [dir_proj.0, K-outer];
+// T2 = 3*HT groups (order tt-major, third-minor) x (1 + D1T + RB) [bias dp2b | dir_proj.2 tile | rbf_proj tile].
+// Output: q[a][third][feature] = (dir_proj(ew))[..] * (rbf_proj(rbf))[..]  — the node kernel forms the messages.
+// =====================================================================================================
+template <class D>
+struct EquiStream {
+    static constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT;
+    static constexpr int G1 = D1T, G2 = 1 + D1T + RB, NG2 = 3 * HT;
+    static constexpr int SLAB = G2 > G1 ? G2 : G1;
+    static constexpr int NPH = WB + NG2;
+    static constexpr int C1 = WB * G1, CHUNKS = C1 + NG2 * G2;
+    static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
+};
+
+template <class D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const float* __restrict__ stream,
+                                                             const float* __restrict__ dp0b,
+                                                             const float* __restrict__ ew, const float* __restrict__ rbuf,
+                                                             float* __restrict__ qbuf) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using S = EquiStream<D>;
+    constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT, G1 = S::G1, G2 = S::G2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+
+    auto issue = [&](int p) {
+        if (p >= S::NPH) return;
+        const int start = p < WB ? p * G1 : S::C1 + (p - WB) * G2;
+        const int n = p < WB ? G1 : G2;
+        float* dst = smem + (size_t)(p & 1) * S::SLAB * 256;
+        const float* src = stream + (size_t)start * 256 + lane * 4;
+        for (int j = wave; j < n; j += WAVES) glds16(src + (size_t)j * 256, dst + j * 256);
+    };
+    auto A = [&](int p, int j) -> f4 {
+        return *reinterpret_cast<const f4*>(smem + ((size_t)(p & 1) * S::SLAB + j) * 256 + lane * 4);
+    };
+
+    const long long c = ((long long)blockIdx.x * WAVES + wave) * 16 + (lane & 15);
+    const bool valid = c < tp.A;
+    const size_t a = (size_t)(valid ? c : tp.A - 1);
+    const float* erow = ew + (size_t)tp.act_edge[a] * D::WP + 4 * g;
+    f4 d1[D1T];
+#pragma unroll
+    for (int t = 0; t < D1T; ++t) d1[t] = ld_vec(dp0b, t, lane);
+    f4 rb[RB];
+#pragma unroll
+    for (int b = 0; b < RB; ++b) rb[b] = ld_blk(rbuf, a, D::RP, b, lane);
+    f4 xn = ld_f4(erow);
+    issue(0);
+
+    int p = 0;
+    for (int b = 0; b < WB; ++b, ++p) {
+        __syncthreads();
+        const f4 x = xn;
+        issue(p + 1);
+        if (b + 1 < WB) xn = ld_f4(erow + 16 * (b + 1));
+#pragma unroll
+        for (int t = 0; t + 1 < D1T; t += 2) mma_pair(A(p, t), x, d1[t], A(p, t + 1), x, d1[t + 1]);
+        if (D1T & 1) d1[D1T - 1] = mma_chunk(A(p, D1T - 1), x, d1[D1T - 1]);
+    }
+#pragma unroll
+    for (int t = 0; t < D1T; ++t) d1[t] = silu4(d1[t]);
+
+    float* qrow = qbuf + a * (size_t)(3 * D::HP) + 4 * g;
+    for (int i = 0; i < S::NG2; ++i, ++p) {
+        __syncthreads();
+        issue(p + 1);
+        f4 c0 = A(p, 0), c1 = f4zero(), cr = f4zero();
+        // three independent chains: even / odd K blocks of dir_proj.2 and the rbf_proj tile
+#pragma unroll
+        for (int b = 0; b + 1 < D1T; b += 2) {
+            mma_pair(A(p, 1 + b), d1[b], c0, A(p, 2 + b), d1[b + 1], c1);
+            if (b / 2 < RB) cr = mma_chunk(A(p, 1 + D1T + b / 2), rb[b / 2], cr);
+        }
+        if (D1T & 1) c0 = mma_chunk(A(p, D1T), d1[D1T - 1], c0);
+#pragma unroll
+        for (int b = (D1T / 2 < RB ? D1T / 2 : RB); b < RB; ++b) cr = mma_chunk(A(p, 1 + D1T + b), rb[b], cr);
+        const int tt = i / 3, th = i - 3 * tt;
+        if (valid) st_f4(qrow + th * D::HP + 16 * tt, (c0 + c1) * cr);
+    }
+}
+
+// =====================================================================================================
+// message formation + aggregation (:264-283, 857-859) + first half of EquiUpdate, from q:
+//   (x, a2, a3) = (xq[src] + xq[n]) * q;  dx = sum x;  dvec = sum (vec[src] * a2/sqrt3 + a3 * coord_diff)/sqrt(H)
+// reads vec_in (all nodes), writes vec_out (own node) — the two must be different buffers.
+// =====================================================================================================
+template <class D>
+__global__ __launch_bounds__(256) void k_equi_agg_v1(TopoDev tp, const float* __restrict__ wb, LayerOff lo,
+                                                     const float* __restrict__ qbuf, const float* __restrict__ xq,
+                                                     const float* __restrict__ geo, const float* __restrict__ x1,
+                                                     float* __restrict__ s, const float* __restrict__ vec_in,
+                                                     float* __restrict__ vec_out, float* __restrict__ v2buf,
+                                                     float* __restrict__ scal, float* __restrict__ vdot) {
+    bool live; const ColId id = col_id(tp.N, live);
+    if (!live) return;
+    const int n = id.col, a0 = tp.act_ptr[n], cnt = tp.act_ptr[n + 1] - a0;
+    const int mx = wave_max(cnt);
+    const float inv_sqrt2 = 0.70710678118654752f, inv_sqrt3 = 0.57735026918962576f,
+                inv_sqrt_h = 1.0f / sqrtf((float)D::H);
+    f4 vx[3][D::HT], dx[D::HT];
+#pragma unroll
+    for (int t = 0; t < D::HT; ++t) { dx[t] = f4zero(); vx[0][t] = f4zero(); vx[1][t] = f4zero(); vx[2][t] = f4zero(); }
+    for (int k = 0; k < mx; ++k)
+        if (k < cnt) {
+            const size_t a = (size_t)a0 + k;
+            const int m = tp.act_src[a];
+            const float* g = geo + a * GEO_STRIDE;
+            const float ux = g[2], uy = g[3], uz = g[4];
+#pragma unroll
+            for (int t = 0; t < D::HT; ++t) {
+                const f4 q0 = ld_blk(qbuf, a, 3 * D::HP, t, id.lane);
+                const f4 q1 = ld_blk(qbuf, a, 3 * D::HP, D::HT + t, id.lane);
+                const f4 q2 = ld_blk(qbuf, a, 3 * D::HP, 2 * D::HT + t, id.lane);
+                const f4 xs0 = ld_blk(xq, m, 3 * D::HP, t, id.lane) + ld_blk(xq, n, 3 * D::HP, t, id.lane);
+                const f4 xs1 = ld_blk(xq, m, 3 * D::HP, D::HT + t, id.lane) + ld_blk(xq, n, 3 * D::HP, D::HT + t, id.lane);
+                const f4 xs2 = ld_blk(xq, m, 3 * D::HP, 2 * D::HT + t, id.lane) + ld_blk(xq, n, 3 * D::HP, 2 * D::HT + t, id.lane);
+                dx[t] += xs0 * q0;
+                const f4 a2 = xs1 * q1 * inv_sqrt3, a3 = xs2 * q2;
+                vx[0][t] += (ld_blk(vec_in, (size_t)m * 3 + 0, D::HP, t, id.lane) * a2 + a3 * ux) * inv_sqrt_h;
+                vx[1][t] += (ld_blk(vec_in, (size_t)m * 3 + 1, D::HP, t, id.lane) * a2 + a3 * uy) * inv_sqrt_h;
+                vx[2][t] += (ld_blk(vec_in, (size_t)m * 3 + 2, D::HP, t, id.lane) * a2 + a3 * uz) * inv_sqrt_h;
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < D::HT; ++t) {
+        const f4 sn = (ld_blk(s, n, D::HP, t, id.lane) + dx[t]) * inv_sqrt2;
+        if (id.valid) st_blk(s, n, D::HP, t, id.lane, sn);
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            vx[x][t] += ld_blk(vec_in, (size_t)n * 3 + x, D::HP, t, id.lane);
+            if (id.valid) st_blk(vec_out, (size_t)n * 3 + x, D::HP, t, id.lane, vx[x][t]);
+        }
+    }
+    const float fx = x1[n * 3], fy = x1[n * 3 + 1], fz = x1[n * 3 + 2];
+    const float* l3 = wb + lo.l3u;
+    for (int t = 0; t < D::HT; ++t) {
+        f4 v1[3] = {f4zero(), f4zero(), f4zero()}, v2[3] = {f4zero(), f4zero(), f4zero()};
+        const float* w1 = wb + lo.vp + ((size_t)t * D::HT * 64 + id.lane) * 4;
+        const float* w2 = wb + lo.vp + ((size_t)(D::HT + t) * D::HT * 64 + id.lane) * 4;
+#pragma unroll
+        for (int b = 0; b < D::HT; ++b) {
+            const f4 c1 = ld_f4(w1 + (size_t)b * 256), c2 = ld_f4(w2 + (size_t)b * 256);
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                v1[x] = mma_chunk(c1, vx[x][b], v1[x]);
+                v2[x] = mma_chunk(c2, vx[x][b], v2[x]);
+            }
+        }
+        const f4 sc = v1[0] * fx + v1[1] * fy + v1[2] * fz;
+        const f4 vd = (v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2]) * inv_sqrt_h;
+        f4 sca;
+        const int f0 = 16 * t + 4 * id.g;
+        sca.x = f0 + 0 < D::H ? lin3u(l3, sc.x) : 0.f;
+        sca.y = f0 + 1 < D::H ? lin3u(l3, sc.y) : 0.f;
+        sca.z = f0 + 2 < D::H ? lin3u(l3, sc.z) : 0.f;
+        sca.w = f0 + 3 < D::H ? lin3u(l3, sc.w) : 0.f;
+        if (id.valid) {
+            st_blk(scal, n, D::HP, t, id.lane, sca);
+            st_blk(vdot, n, D::HP, t, id.lane, vd);
+            st_blk(v2buf, (size_t)n * 3 + 0, D::HP, t, id.lane, v2[0]);
+            st_blk(v2buf, (size_t)n * 3 + 1, D::HP, t, id.lane, v2[1]);
+            st_blk(v2buf, (size_t)n * 3 + 2, D::HP, t, id.lane, v2[2]);
+        }
+    }
+}

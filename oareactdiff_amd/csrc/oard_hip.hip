@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "oard_kernels.h"
+#include "oard_edge_v1.h"
 
 #define OARD_VERSION 1001
 
@@ -45,6 +46,9 @@ struct Timing {
     }
 } g_timing;
 int g_stop_after = 0;
+int g_gcl_variant = 2;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
+int g_equi_variant = 2;
+size_t g_vec_final = 0;    // workspace offset of the vec buffer holding the final state (taps)
 
 struct ScopedLaunch {
     hipStream_t st; hipEvent_t a; int fam; bool on;
@@ -135,6 +139,8 @@ PackOff make_layout(const oard_config* c) {
         lo.xv0 = mat(d.HT, 2 * d.HT);
         lo.xv2 = mat(3 * d.HT, d.HT);
         lo.l3u = take(593);
+        lo.gcl_stream = take((size_t)(d.WB * d.HT + (d.HT + 1) * (d.HT + 1) + d.WB * (d.HT + 1)) * 256);
+        lo.equi_stream = take((size_t)(d.WB * d.D1T + 3 * d.HT * (1 + d.D1T + d.RB)) * 256);
     }
     po.total = cur;
     return po;
@@ -165,8 +171,9 @@ struct ParamIdx {
 struct Packer {
     const float* const* p; float* blob; hipStream_t st;
     void matrix(int src, int src_ld, int col_off, int msl, int msp, int ms, int ksl, int ksp, int ks, int MT, int KB,
-                size_t dst) {
-        PackJob j{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst};
+                size_t dst, size_t tstride = 0, size_t bstride = 256, int perm_ht = 0) {
+        if (tstride == 0) tstride = (size_t)KB * 256;
+        PackJob j{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst, tstride, bstride, perm_ht};
         const size_t total = (size_t)MT * KB * 256;
         hipLaunchKernelGGL(k_pack_matrix, dim3((unsigned)std::min<size_t>(cdiv(total, 256), 4096)), dim3(256), 0, st, j, blob);
     }
@@ -177,6 +184,11 @@ struct Packer {
     void vec(int src, int sect_len, int sect_pad, int sects, int n_dst, size_t dst) {
         hipLaunchKernelGGL(k_pack_vector, dim3((unsigned)cdiv(n_dst, 256)), dim3(256), 0, st,
                            src >= 0 ? p[src] : nullptr, blob + dst, sect_len, sect_pad, sects, n_dst);
+    }
+    void bias_chunks(int src, int sect_len, int sect_pad, int sects, int n_tiles, size_t dst, size_t tstride,
+                     int perm_ht = 0) {
+        hipLaunchKernelGGL(k_pack_bias_chunks, dim3((unsigned)cdiv((long long)n_tiles * 256, 256)), dim3(256), 0, st,
+                           p[src], blob + dst, sect_len, sect_pad, sects, n_tiles, tstride, perm_ht);
     }
     void raw(int src, int n, size_t dst) {
         hipLaunchKernelGGL(k_copy_raw, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, p[src], blob + dst, n);
@@ -192,7 +204,7 @@ static WsOff make_ws(const oard_config* c, const oard_topology* tp) {
     w.pp0 = take(N * 4); w.labels = take(N * 4); w.hin = take(N * 16 * 4);
     w.zemb = take(N * d.HP * 4); w.nb = take(N * d.HP * 4); w.s = take(N * d.HP * 4); w.s1 = take(N * d.HP * 4);
     w.ne1 = take(N * 3 * d.HP * 4); w.xh = take(N * d.HP * 4); w.P = take(N * d.HP * 4); w.Q = take(N * d.HP * 4);
-    w.xq = take(N * 3 * d.HP * 4); w.vec = take(N * 3 * d.HP * 4); w.v2buf = take(N * 3 * d.HP * 4);
+    w.xq = take(N * 3 * d.HP * 4); w.vec = take(N * 3 * d.HP * 4); w.vec2 = take(N * 3 * d.HP * 4); w.v2buf = take(N * 3 * d.HP * 4);
     w.sc0 = take(N * d.HP * 4); w.vdot = take(N * d.HP * 4);
     w.geo = take(A * GEO_STRIDE * 4); w.d64 = take(A * 8); w.rbuf = take(A * d.RP * 4);
     w.ew = take(E * d.WP * 4); w.mbuf = take(E * d.HP * 4);
@@ -202,6 +214,69 @@ static WsOff make_ws(const oard_config* c, const oard_topology* tp) {
     return w;
 }
 
+
+
+template <class K>
+int set_lds(K kernel, size_t bytes) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return OARD_OK;
+}
+#define LAUNCH_LDS(fam, kern, grid, block, lds, stream, ...) do { \
+    static bool attr_done_ = false; \
+    if (!attr_done_) { int rc_ = set_lds(kern, lds); if (rc_ != OARD_OK) return rc_; attr_done_ = true; } \
+    ScopedLaunch sl_(fam, stream); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), lds, stream, __VA_ARGS__); } while (0)
+
+template <class D>
+int launch_gcl_v1(int variant, const TopoDev& tp, const float* stream, const float* P, const float* Q, float* ew,
+                  float* mbuf, hipStream_t st) {
+    switch (variant) {
+        case 1: {   // 4 waves x 32 edges, one wave per SIMD
+            constexpr int NB = 2, WV = 4, GP = 2;
+            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB, WV, GP>), cdiv(tp.E, NB * 16 * WV), WV * 64,
+                       (GclStream<D, GP>::LDS_BYTES), st, tp, stream, P, Q, ew, mbuf);
+            return OARD_OK;
+        }
+        case 2: {   // 8 waves x 16 edges, two waves per SIMD
+            constexpr int NB = 1, WV = 8, GP = 2;
+            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB, WV, GP>), cdiv(tp.E, NB * 16 * WV), WV * 64,
+                       (GclStream<D, GP>::LDS_BYTES), st, tp, stream, P, Q, ew, mbuf);
+            return OARD_OK;
+        }
+        case 3: {   // 4 waves x 16 edges
+            constexpr int NB = 1, WV = 4, GP = 2;
+            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB, WV, GP>), cdiv(tp.E, NB * 16 * WV), WV * 64,
+                       (GclStream<D, GP>::LDS_BYTES), st, tp, stream, P, Q, ew, mbuf);
+            return OARD_OK;
+        }
+        case 4: {   // 4 waves x 32 edges, 4 groups per phase
+            constexpr int NB = 2, WV = 4, GP = 4;
+            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB, WV, GP>), cdiv(tp.E, NB * 16 * WV), WV * 64,
+                       (GclStream<D, GP>::LDS_BYTES), st, tp, stream, P, Q, ew, mbuf);
+            return OARD_OK;
+        }
+        default: return OARD_EINVAL;
+    }
+}
+template <class D>
+int launch_equi_v1(int variant, const TopoDev& tp, const float* stream, const float* dp0b, const float* ew,
+                   const float* rbuf, float* qbuf, hipStream_t st) {
+    switch (variant) {
+        case 1: {
+            constexpr int WV = 4;
+            LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV>), cdiv(tp.A, 16 * WV), WV * 64, (EquiStream<D>::LDS_BYTES), st,
+                       tp, stream, dp0b, ew, rbuf, qbuf);
+            return OARD_OK;
+        }
+        case 2: {
+            constexpr int WV = 8;
+            LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV>), cdiv(tp.A, 16 * WV), WV * 64, (EquiStream<D>::LDS_BYTES), st,
+                       tp, stream, dp0b, ew, rbuf, qbuf);
+            return OARD_OK;
+        }
+        default: return OARD_EINVAL;
+    }
+}
 
 template <class D>
 static int forward_impl(const oard_config* c, const oard_topology* topo, const float* wb, const float* const* xh,
@@ -250,21 +325,42 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
     HIP_TRY(hipMemsetAsync(vec, 0, (size_t)N * 3 * D::HP * sizeof(float), st));
     if (g_stop_after == 1) return OARD_OK;
 
+    float* vec2 = (float*)(ws + w.vec2);
+    float* vcur = vec;          // holds the current vec; v1 ping-pongs between vec and vec2
+    float* vnext = vec2;
     for (int l = 0; l < c->num_layers; ++l) {
         const LayerOff lo = po.layer[l];
         LAUNCH(F_NODE, (k_node_pre<D>), gN, 256, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
-        if (E > 0) LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew, mbuf);
+        if (E > 0) {
+            if (g_gcl_variant == 0) {
+                LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew, mbuf);
+            } else {
+                int rc = launch_gcl_v1<D>(g_gcl_variant, tp, wb + lo.gcl_stream, P, Q, ew, mbuf, st);
+                if (rc != OARD_OK) return rc;
+            }
+        }
         LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
-        if (g_stop_after == 100 + 10 * l + 1) return OARD_OK;
-        if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew, (const float*)rbuf,
-                          (const float*)geo, (const float*)xq, (const float*)vec, xmsg, vmsg);
-        LAUNCH(F_NODE, (k_equi_agg<D>), gN, 256, st, tp, wb, lo, (const float*)xmsg, (const float*)vmsg, (const float*)x1,
-               s, vec, v2buf, scal, vdot);
+        if (g_stop_after == 100 + 10 * l + 1) { g_vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
+        if (g_equi_variant == 0) {
+            if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew, (const float*)rbuf,
+                              (const float*)geo, (const float*)xq, (const float*)vcur, xmsg, vmsg);
+            LAUNCH(F_NODE, (k_equi_agg<D>), gN, 256, st, tp, wb, lo, (const float*)xmsg, (const float*)vmsg, (const float*)x1,
+                   s, vcur, v2buf, scal, vdot);
+        } else {
+            if (A > 0) {
+                int rc = launch_equi_v1<D>(g_equi_variant, tp, wb + lo.equi_stream, wb + lo.dp0b, ew, rbuf, vmsg, st);
+                if (rc != OARD_OK) return rc;
+            }
+            LAUNCH(F_NODE, (k_equi_agg_v1<D>), gN, 256, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
+                   (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext, v2buf, scal, vdot);
+            std::swap(vcur, vnext);
+        }
         LAUNCH(F_NODE, (k_equi_upd<D>), gN, 256, st, tp, wb, lo, (const float*)scal, (const float*)vdot,
-               (const float*)v2buf, s, vec);
-        if (g_stop_after == 100 + 10 * l + 2) return OARD_OK;
+               (const float*)v2buf, s, vcur);
+        if (g_stop_after == 100 + 10 * l + 2) { g_vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
     }
-    LAUNCH(F_NODE, (k_out<D>), gN, 256, st, tp, wb, po, (const float*)s, (const float*)vec, dpos, hout, status);
+    g_vec_final = (size_t)((char*)vcur - ws);
+    LAUNCH(F_NODE, (k_out<D>), gN, 256, st, tp, wb, po, (const float*)s, (const float*)vcur, dpos, hout, status);
     LAUNCH(F_OTHER, k_post, cdiv(N, 128), 128, st, tp, op, wb, (const float*)dpos, (const float*)hout, emb);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
@@ -359,6 +455,24 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
         pk.matrix(u + 2, H, 0, H, d.HP, 3, H, d.HP, 1, 3 * d.HT, d.HT, lo.xv2);
         pk.raw(u + 3, 144, lo.l3u); pk.raw(u + 4, 48, lo.l3u + 144); pk.raw(u + 5, 384, lo.l3u + 192);
         pk.raw(u + 6, 8, lo.l3u + 576); pk.raw(u + 7, 8, lo.l3u + 584); pk.raw(u + 8, 1, lo.l3u + 592);
+        // ---- LDS weight streams (consumption order, see oard_edge_v1.h) ----
+        {
+            const size_t G2 = (size_t)(d.HT + 1) * 256;
+            const size_t s1 = lo.gcl_stream, s2 = s1 + (size_t)d.WB * d.HT * 256, s3 = s2 + (size_t)(d.HT + 1) * G2;
+            pk.matrix(g + 0, ld0, 2 * H, H, d.HP, 1, W, d.WP, 1, d.HT, d.WB, s1, 256, (size_t)d.HT * 256);      // W1c, K-outer
+            pk.matrix(g + 2, H, 0, H, d.HP, 1, H, d.HP, 1, d.HT, d.HT, s2 + 256, G2, 256);                       // W2 tiles
+            pk.bias_chunks(g + 3, H, d.HP, 1, d.HT, s2, G2);
+            pk.matrix(g + 10, H, 0, 1, 16, 1, H, d.HP, 1, 1, d.HT, s2 + d.HT * G2 + 256, G2, 256);               // watt as a 1-row tile
+            pk.bias_chunks(g + 11, 1, 16, 1, 1, s2 + d.HT * G2, G2);
+            pk.matrix(g + 8, H, 0, W, d.WP, 1, H, d.HP, 1, d.WB, d.HT, s3 + 256, G2, 256);                       // W3 tiles
+            pk.bias_chunks(g + 9, W, d.WP, 1, d.WB, s3, G2);
+            const size_t GE = (size_t)(1 + d.D1T + d.RB) * 256;
+            const size_t t1 = lo.equi_stream, t2 = t1 + (size_t)d.WB * d.D1T * 256;
+            pk.matrix(m + 0, W, 0, 3 * H, d.D1P, 1, W, d.WP, 1, d.D1T, d.WB, t1, 256, (size_t)d.D1T * 256);       // dir_proj.0, K-outer
+            pk.matrix(m + 2, 3 * H, 0, H, d.HP, 3, 3 * H, d.D1P, 1, 3 * d.HT, d.D1T, t2 + 256, GE, 256, d.HT);    // dir_proj.2 tiles
+            pk.matrix(m + 6, R, 0, H, d.HP, 3, R, d.RP, 1, 3 * d.HT, d.RB, t2 + (size_t)(1 + d.D1T) * 256, GE, 256, d.HT);
+            pk.bias_chunks(m + 3, H, d.HP, 3, 3 * d.HT, t2, GE, d.HT);
+        }
     }
     hipLaunchKernelGGL(k_c0row, dim3((unsigned)cdiv(d.WP, 256)), dim3(256), 0, st, params[pi.lin30_b], params[pi.lin32_w],
                        params[pi.lin32_b], params[pi.rl0_b], params[pi.rl2_w], params[pi.rl2_b],
@@ -554,7 +668,7 @@ int oard_tap(const oard_config* c, const oard_topology* topo, const void* ws_, i
     };
     switch (which) {
         case OARD_TAP_S: nodes((const float*)(ws + w.s), d.HP, 1, d.HP, d.H); break;
-        case OARD_TAP_VEC: nodes((const float*)(ws + w.vec), 3 * d.HP, 3, d.HP, d.H); break;
+        case OARD_TAP_VEC: nodes((const float*)(ws + g_vec_final), 3 * d.HP, 3, d.HP, d.H); break;
         case OARD_TAP_NE1: nodes((const float*)(ws + w.ne1), 3 * d.HP, 3, d.HP, d.H); break;
         case OARD_TAP_POS_FRAME: nodes((const float*)(ws + w.pf32), 3, 1, 3, 3); break;
         case OARD_TAP_DPOS: nodes((const float*)(ws + w.dpos), 3, 1, 3, 3); break;
@@ -574,6 +688,12 @@ int oard_tap(const oard_config* c, const oard_topology* topo, const void* ws_, i
 }
 
 int oard_debug_stop_after(int code) { g_stop_after = code; return OARD_OK; }
+int oard_debug_option(const char* name, int value) {
+    if (!name) return OARD_EINVAL;
+    if (strcmp(name, "gcl_variant") == 0) { g_gcl_variant = value; return OARD_OK; }
+    if (strcmp(name, "equi_variant") == 0) { g_equi_variant = value; return OARD_OK; }
+    return OARD_EINVAL;
+}
 int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }
 int oard_timing_reset(void) {
     g_timing.flush();

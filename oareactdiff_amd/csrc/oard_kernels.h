@@ -45,6 +45,10 @@ struct PackJob {
     int ksect_len, ksect_pad, ksects;
     int MT, KB;
     size_t dst;
+    // destination of chunk (t, b): dst + slot(t) * tstride + b * bstride  (floats); slot(t) = t, or with
+    // perm_ht > 0 (thirds interleave): slot(t) = (t % perm_ht) * 3 + t / perm_ht
+    size_t tstride, bstride;
+    int perm_ht;
 };
 
 // matrix -> MFMA chunks: dst[((t*KB + b)*64 + lane)*4 + c] = W[row(16t + (lane&15))][col(16b + 4(lane>>4) + c)]
@@ -60,8 +64,21 @@ __global__ void k_pack_matrix(PackJob j, float* __restrict__ blob) {
         float v = 0.f;
         if (rs < j.msects && rw < j.msect_len && ks < j.ksects && kw < j.ksect_len)
             v = j.src[(size_t)(rs * j.msect_len + rw) * j.src_ld + j.col_off + ks * j.ksect_len + kw];
-        blob[j.dst + i] = v;
+        const int slot = j.perm_ht > 0 ? (t % j.perm_ht) * 3 + t / j.perm_ht : t;
+        blob[j.dst + (size_t)slot * j.tstride + (size_t)b * j.bstride + (i & 255)] = v;
     }
+}
+// per-feature vector as "bias chunks" for the LDS weight stream: chunk of tile t holds, for lane (g, o),
+// the float4 vec[16t + 4g .. +3] (i.e. ld_vec's layout, replicated over o); same sectioning as k_pack_vector
+__global__ void k_pack_bias_chunks(const float* __restrict__ src, float* __restrict__ dst, int sect_len, int sect_pad,
+                                   int sects, int n_tiles, size_t tstride, int perm_ht) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles * 256) return;
+    const int t = i >> 8, lane = (i >> 2) & 63, c = i & 3;
+    const int r = 16 * t + 4 * (lane >> 4) + c;
+    const int s = r / sect_pad, w = r % sect_pad;
+    const int slot = perm_ht > 0 ? (t % perm_ht) * 3 + t / perm_ht : t;
+    dst[(size_t)slot * tstride + (i & 255)] = (src != nullptr && s < sects && w < sect_len) ? src[s * sect_len + w] : 0.f;
 }
 // vector with the same row sectioning, padded with zeros; n_dst = msects * msect_pad (or MT*16)
 __global__ void k_pack_vector(const float* __restrict__ src, float* __restrict__ dst, int sect_len, int sect_pad,

@@ -39,6 +39,8 @@ struct LayerOff {
     size_t ln_q_w, ln_q_b, xp0, xp2, dp0, dp0b, dp2, dp2b, rbfp;
     // EquiUpdate (leftnet.py:292-346)
     size_t vp, xv0, xv2, l3u;   // l3u raw: w0[48*3] b0[48] w2[8*48] b2[8] w4[8] b4[1]
+    // LDS weight streams of the two hot edge kernels, chunks in consumption order (oard_edge_v1.h)
+    size_t gcl_stream, equi_stream;
 };
 struct PackOff {
     size_t emb, emb_b, nbemb, nbemb_b, s2v, s2v_b, rl0, rl0_b, rl2, rl2_b;
@@ -72,6 +74,6 @@ struct oard_topology {
 
 // ---- workspace carving (byte offsets) --------------------------------------------------------------
 struct WsOff {
-    size_t pos, pf64, pf32, x1, pp0, labels, hin, zemb, nb, s, s1, ne1, xh, P, Q, xq, vec, v2buf, sc0, vdot,
-        geo, d64, rbuf, ew, mbuf, xmsg, vmsg, dpos, hout, total;
+    size_t pos, pf64, pf32, x1, pp0, labels, hin, zemb, nb, s, s1, ne1, xh, P, Q, xq, vec, vec2, v2buf, sc0, vdot,
+        geo, d64, rbuf, ew, mbuf, xmsg, vmsg, dpos, hout, total;   // xmsg..vmsg double as qbuf [A][3][HP] (v1)
 };
