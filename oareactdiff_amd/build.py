@@ -8,7 +8,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liboard_hip.so")
 SOURCES = ["oard_hip.hip"]
-HEADERS = ["oard_engine.h", "oard_kernels.h", "oard_layout.h", "oard_edge_v1.h", os.path.join("..", "..", "include", "oard.h")]
+HEADERS = ["oard_engine.h", "oard_kernels.h", "oard_layout.h", "oard_edge_v1.h", "oard_node_v1.h", os.path.join("..", "..", "include", "oard.h")]
 
 
 def _stale() -> bool:

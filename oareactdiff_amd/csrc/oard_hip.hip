@@ -10,6 +10,7 @@
 
 #include "oard_kernels.h"
 #include "oard_edge_v1.h"
+#include "oard_node_v1.h"
 
 #define OARD_VERSION 1001
 
@@ -48,6 +49,7 @@ struct Timing {
 int g_stop_after = 0;
 int g_gcl_variant = 2;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
 int g_equi_variant = 2;
+int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
 size_t g_vec_final = 0;    // workspace offset of the vec buffer holding the final state (taps)
 
 struct ScopedLaunch {
@@ -330,7 +332,10 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
     float* vnext = vec2;
     for (int l = 0; l < c->num_layers; ++l) {
         const LayerOff lo = po.layer[l];
-        LAUNCH(F_NODE, (k_node_pre<D>), gN, 256, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
+        const bool nv1 = g_node_variant == 1 && g_equi_variant != 0;
+        const unsigned gN16 = (unsigned)cdiv(N, 16);
+        if (nv1) LAUNCH(F_NODE, (k_node_pre_v1<D, 8>), gN16, 512, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
+        else LAUNCH(F_NODE, (k_node_pre<D>), gN, 256, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
         if (E > 0) {
             if (g_gcl_variant == 0) {
                 LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew, mbuf);
@@ -339,7 +344,8 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
                 if (rc != OARD_OK) return rc;
             }
         }
-        LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
+        if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, 8>), gN16, 512, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
+        else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
         if (g_stop_after == 100 + 10 * l + 1) { g_vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
         if (g_equi_variant == 0) {
             if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew, (const float*)rbuf,
@@ -351,12 +357,17 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
                 int rc = launch_equi_v1<D>(g_equi_variant, tp, wb + lo.equi_stream, wb + lo.dp0b, ew, rbuf, vmsg, st);
                 if (rc != OARD_OK) return rc;
             }
-            LAUNCH(F_NODE, (k_equi_agg_v1<D>), gN, 256, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
-                   (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext, v2buf, scal, vdot);
+            if (nv1) {
+                LAUNCH(F_NODE, (k_equi_node_v1<D, 8>), gN16, 512, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
+                       (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext);
+            } else {
+                LAUNCH(F_NODE, (k_equi_agg_v1<D>), gN, 256, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
+                       (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext, v2buf, scal, vdot);
+            }
             std::swap(vcur, vnext);
         }
-        LAUNCH(F_NODE, (k_equi_upd<D>), gN, 256, st, tp, wb, lo, (const float*)scal, (const float*)vdot,
-               (const float*)v2buf, s, vcur);
+        if (!nv1) LAUNCH(F_NODE, (k_equi_upd<D>), gN, 256, st, tp, wb, lo, (const float*)scal, (const float*)vdot,
+                         (const float*)v2buf, s, vcur);
         if (g_stop_after == 100 + 10 * l + 2) { g_vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
     }
     g_vec_final = (size_t)((char*)vcur - ws);
@@ -692,6 +703,7 @@ int oard_debug_option(const char* name, int value) {
     if (!name) return OARD_EINVAL;
     if (strcmp(name, "gcl_variant") == 0) { g_gcl_variant = value; return OARD_OK; }
     if (strcmp(name, "equi_variant") == 0) { g_equi_variant = value; return OARD_OK; }
+    if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
     return OARD_EINVAL;
 }
 int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }
