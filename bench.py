@@ -120,7 +120,8 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert int(dyn.last_status[0].item()) == 0, "NaN in the timed region"
+    if not os.environ.get("OARD_BENCH_ALLOW_NAN"):          # (kernel ablation experiments produce garbage on purpose)
+        assert int(dyn.last_status[0].item()) == 0, "NaN in the timed region"
 
     # per-kernel durations (HIP events on the launch stream), outside the timed region
     E = B * 3 * nf * (3 * nf - 1)

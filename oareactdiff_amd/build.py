@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB = os.path.join(CSRC, "liboard_hip.so")
+LIB = os.environ.get("OARD_LIB") or os.path.join(CSRC, "liboard_hip.so")
 SOURCES = ["oard_hip.hip"]
 HEADERS = ["oard_engine.h", "oard_kernels.h", "oard_layout.h", "oard_edge_v1.h", "oard_node_v1.h", os.path.join("..", "..", "include", "oard.h")]
 

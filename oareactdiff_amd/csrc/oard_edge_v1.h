@@ -16,7 +16,18 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // one 1-KiB chunk: per-lane global source, wave-uniform LDS destination (+ lane*16 by hardware)
 OARD_DEV void glds16(const float* gsrc_lane, float* lds_chunk) {
+#ifndef OARD_DBG_NODMA
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc_lane, (lds_ptr_t)lds_chunk, 16, 0, 0);
+#endif
+}
+
+// Phase barrier: every LDS-DMA piece this wave issued must have landed before any wave reads the slab.
+// hipcc's own "vmcnt(0) before the workgroup barrier" is NOT emitted once the DMA issues sit in
+// data-dependent control flow inside a loop (observed: only lgkmcnt(0) before s_barrier), so the wait
+// is stated explicitly.
+OARD_DEV void phase_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 // acc[i] += a x b[i] for NA independent accumulators, k-steps outermost so consecutive MFMAs never
@@ -44,6 +55,67 @@ OARD_DEV void mma_pair(f4 a0, f4 b0, f4& c0, f4 a1, f4 b1, f4& c1) {
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, c1, 0, 0, 0);
 }
 
+// ---- software-pipelined LDS -> MFMA chains ---------------------------------------------------------
+// `sl` = this lane's pointer into the current slab (slab base + lane*4); chunk j is at sl + j*256.
+// The A fragments of the NEXT pair of chunks are read from LDS while the current pair's 8 MFMAs issue,
+// so the ds_read latency (~100+ cycles) is covered; sched_group_barrier pins that order.
+#ifdef OARD_DBG_NOLDS
+OARD_DEV f4 lds_a(const float* sl, int j) { return (f4){1.0f + j, 0.5f, 0.25f, 2.0f}; }       // timing experiment only
+#else
+OARD_DEV f4 lds_a(const float* sl, int j) { return *reinterpret_cast<const f4*>(sl + j * 256); }
+#endif
+#ifdef OARD_DBG_NOEPI
+#define EPI_SILU4(x) (x)
+#else
+#define EPI_SILU4(x) silu4(x)
+#endif
+#ifdef OARD_USE_SCHED
+#define OARD_SCHED_PAIR() do { __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); \
+                               __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); } while (0)
+#define OARD_SCHED_OPEN() __builtin_amdgcn_sched_group_barrier(0x100, 2, 0)
+#else
+#define OARD_SCHED_PAIR() do { } while (0)
+#define OARD_SCHED_OPEN() do { } while (0)
+#endif
+
+// M-outer: one output tile = sum over KB chunks (slots j0..j0+KB-1) x in[b]; even/odd accumulators
+struct NoHook { OARD_DEV void operator()() const {} };
+template <int KB, class Hook = NoHook>
+OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hook hook = Hook()) {
+    f4 c0 = init, c1 = f4zero();
+    f4 a0 = lds_a(sl, j0), a1 = KB > 1 ? lds_a(sl, j0 + 1) : f4zero();
+    OARD_SCHED_OPEN();      // the first pair's reads open the pipeline
+#pragma unroll
+    for (int b = 0; b + 1 < KB; b += 2) {
+        f4 n0 = a0, n1 = a1;
+        if (b + 2 < KB) n0 = lds_a(sl, j0 + b + 2);
+        if (b + 3 < KB) n1 = lds_a(sl, j0 + b + 3);
+        mma_pair(a0, in[b], c0, a1, in[b + 1], c1);
+        OARD_SCHED_PAIR();
+        hook();
+        a0 = n0; a1 = n1;
+    }
+    if (KB & 1) c0 = mma_chunk(a0, in[KB - 1], c0);
+    return c0 + c1;
+}
+// K-outer: acc[t] += chunk(j0 + t) x x for t < MT, pairs of tiles interleaved
+template <int MT, class Hook = NoHook>
+OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook hook = Hook()) {
+    f4 a0 = lds_a(sl, j0), a1 = MT > 1 ? lds_a(sl, j0 + 1) : f4zero();
+    OARD_SCHED_OPEN();
+#pragma unroll
+    for (int t = 0; t + 1 < MT; t += 2) {
+        f4 n0 = a0, n1 = a1;
+        if (t + 2 < MT) n0 = lds_a(sl, j0 + t + 2);
+        if (t + 3 < MT) n1 = lds_a(sl, j0 + t + 3);
+        mma_pair(a0, x, acc[t], a1, x, acc[t + 1]);
+        OARD_SCHED_PAIR();
+        hook();
+        a0 = n0; a1 = n1;
+    }
+    if (MT & 1) acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]);
+}
+
 // =====================================================================================================
 // GCLMessage edge part, all edges.  Stream (chunks): S1 = WB groups x HT  [W1c, K-outer];
 // S2 = (HT+1) groups x (1+HT)  [bias b2 | W2 tile t] + gate group [batt | watt as a 1-row tile];
@@ -58,40 +130,89 @@ struct GclStream {
     static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
 };
 
-template <class D, int NB, int WAVES, int GP>
-__global__ __launch_bounds__(WAVES * 64) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
+// NB == 1 variants are held to <= 256 registers (2 waves per SIMD).  Besides occupancy this keeps the
+// accumulators out of the AGPR half of the file: with the default bound hipcc (ROCm 7.2) put some S1
+// accumulators in AGPRs for the 4-wave variant and the result drifted to 6e-5 of the oracle (a missed
+// MFMA->v_accvgpr_read hazard is the suspect); with the bound every variant is at 2.5e-7.
+template <class D, int NB, int WAVES, int GP, int PRIO>
+__global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                             const float* __restrict__ P, const float* __restrict__ Q,
                                                             float* __restrict__ ew, float* __restrict__ mbuf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = GclStream<D, GP>;
     constexpr int HT = D::HT, WB = D::WB, G1 = S::G1, G2 = S::G2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
+    // static priority for the younger half: the two waves sharing a SIMD then take the matrix pipe in
+    // turns (one runs its MFMA chain while the other does its VALU epilogue) instead of in lockstep
+    if (PRIO && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
 
-    auto issue = [&](int p) {
-        if (p >= S::NPH) return;
-        int start, n;
+    // DMA prefetch of the next phase, spread over the current phase: one global_load_lds costs the
+    // issuing wave ~100-180 cycles, so the pieces are issued one at a time between MFMA pairs (every
+    // third pair), staggered between the two waves that share a SIMD, instead of in a burst after the barrier
+    constexpr int KMAX = (S::SLAB + WAVES - 1) / WAVES;        // pieces per wave per phase (upper bound)
+    const float* pf_src = stream;
+    float* pf_dst = smem;
+    int pf_n = 0, pf_k = 0, pf_next = 0;
+    auto pf_begin = [&](int p) {                               // p = phase to prefetch
+        int start = 0, n = 0;
         if (p < S::NP1) { start = p * GP * G1; n = min(GP, WB - p * GP) * G1; }
         else if (p < S::NP1 + S::NP2) { const int q = p - S::NP1; start = S::C1 + q * GP * G2; n = min(GP, S::NG2 - q * GP) * G2; }
-        else { const int q = p - S::NP1 - S::NP2; start = S::C1 + S::C2 + q * GP * G2; n = min(GP, WB - q * GP) * G2; }
-        float* dst = smem + (size_t)(p & 1) * S::SLAB * 256;
-        const float* src = stream + (size_t)start * 256 + lane * 4;
-        for (int j = wave; j < n; j += WAVES) glds16(src + (size_t)j * 256, dst + j * 256);
+        else if (p < S::NPH) { const int q = p - S::NP1 - S::NP2; start = S::C1 + S::C2 + q * GP * G2; n = min(GP, WB - q * GP) * G2; }
+        pf_src = stream + (size_t)start * 256 + lane * 4;
+        pf_dst = smem + (size_t)(p & 1) * S::SLAB * 256;
+        pf_n = n; pf_k = 0; pf_next = 1 + (wave >= WAVES / 2 ? 1 : 0);
     };
+#ifdef OARD_STAGE_REG_GCL
+    // register-staged alternative: plain 1-KiB loads right after the barrier, ds_write_b128 before the next one
+    f4 stage[KMAX];
+    auto hook = [&]() {};
+    auto pf_flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int j = wave + k * WAVES;
+            if (j < pf_n) *reinterpret_cast<f4*>(pf_dst + j * 256 + lane * 4) = stage[k];
+        }
+    };
+    auto pf_load = [&]() {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int j = wave + k * WAVES;
+            if (j < pf_n) stage[k] = ld_f4(pf_src + (size_t)j * 256);
+        }
+    };
+    auto issue = [&](int p) { pf_begin(p); pf_load(); pf_flush(); };
+    auto pf_start = [&](int p) { pf_begin(p); pf_load(); };
+#else
+    auto pf_one = [&]() {
+        const int j = wave + pf_k * WAVES;
+        if (j < pf_n) glds16(pf_src + (size_t)j * 256, pf_dst + j * 256);
+        ++pf_k;
+    };
+#ifndef OARD_NO_HOOK
+    auto hook = [&]() { if (--pf_next == 0) { pf_one(); pf_next = 3; } };
+#else
+    auto hook = [&]() { while (pf_k < KMAX) pf_one(); };       // burst at the first hook
+#endif
+    auto pf_flush = [&]() { while (pf_k < KMAX) pf_one(); };
+    auto issue = [&](int p) { pf_begin(p); pf_flush(); };      // burst form (prologue only)
+    auto pf_start = [&](int p) { pf_begin(p); };
+#endif
     auto A = [&](int p, int j) -> f4 {
         return *reinterpret_cast<const f4*>(smem + ((size_t)(p & 1) * S::SLAB + j) * 256 + lane * 4);
     };
+    auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
 
-    // columns of this wave; every wave stays in the barrier protocol even if its columns are padding
+    // columns of this wave; padding columns work on the spare row E of ew / mbuf (allocated for that
+    // purpose), so the kernel has no validity branches and every wave stays in the barrier protocol
     const long long colbase = ((long long)blockIdx.x * WAVES + wave) * (NB * 16) + (lane & 15);
-    bool valid[NB];
     size_t e[NB];
     float* erow[NB];
     f4 h1[NB][HT];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const long long c = colbase + nb * 16;
-        valid[nb] = c < tp.E;
-        e[nb] = (size_t)(valid[nb] ? c : tp.E - 1);
+        e[nb] = (size_t)(c < tp.E ? c : tp.E);
         erow[nb] = ew + e[nb] * D::WP + 4 * g;
         const int src = tp.edge_src[e[nb]], tgt = tp.edge_tgt[e[nb]];
 #pragma unroll
@@ -107,13 +228,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_edge_v1(TopoDev tp, const fl
     int p = 0;
     // ---- S1: h1 += W1c . ew   (K-outer) -------------------------------------------------------------
     for (int p1 = 0; p1 < S::NP1; ++p1, ++p) {
-        __syncthreads();
+        phase_barrier();
         f4 x[GP][NB];
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) x[gg][nb] = xn[gg][nb];
-        issue(p + 1);
+        pf_start(p + 1);
         if (p1 + 1 < S::NP1) {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
@@ -138,18 +259,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_edge_v1(TopoDev tp, const fl
                         for (int nb = 0; nb < NB; ++nb) h1[nb][t] = acc[nb];
                     }
                 } else {
-#pragma unroll
-                    for (int t = 0; t + 1 < HT; t += 2)
-                        mma_pair(A(p, gg * G1 + t), x[gg][0], h1[0][t], A(p, gg * G1 + t + 1), x[gg][0], h1[0][t + 1]);
-                    if (HT & 1) h1[0][HT - 1] = mma_chunk(A(p, gg * G1 + HT - 1), x[gg][0], h1[0][HT - 1]);
+                    chain_kouter<HT>(SL(p), gg * G1, x[gg][0], h1[0], hook);
                 }
             }
         }
+        pf_flush();
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int t = 0; t < HT; ++t) h1[nb][t] = silu4(h1[nb][t]);
+        for (int t = 0; t < HT; ++t) h1[nb][t] = EPI_SILU4(h1[nb][t]);
 
     // ---- S2: m = SiLU(W2 h1 + b2); gate = SiLU(watt . m + batt) ---------------------------------------
     f4 m[NB][HT];
@@ -157,8 +276,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_edge_v1(TopoDev tp, const fl
     // note: the gate tile is computed from h1?  no — from m; it is the last group of S2 and uses m as B operand
 #pragma unroll
     for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
-        __syncthreads();
-        issue(p + 1);
+        phase_barrier();
+        pf_start(p + 1);
         if (p2 == S::NP2 - 1) {                     // prefetch the old edge-state tiles of S3's first phase
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg)
@@ -183,7 +302,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_edge_v1(TopoDev tp, const fl
                     }
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        if (tg < HT) m[nb][tg] = silu4(acc[nb]);
+                        if (tg < HT) m[nb][tg] = EPI_SILU4(acc[nb]);
                         else {
                             const float gate = silu1(__shfl(acc[nb].x, lane & 15, 64));
 #pragma unroll
@@ -191,14 +310,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_edge_v1(TopoDev tp, const fl
                         }
                     }
                 } else {
-                    f4 c0 = bias, c1 = f4zero();
-#pragma unroll
-                    for (int b = 0; b + 1 < HT; b += 2)
-                        mma_pair(A(p, gg * G2 + 1 + b), tg < HT ? h1[0][b] : m[0][b], c0,
-                                 A(p, gg * G2 + 2 + b), tg < HT ? h1[0][b + 1] : m[0][b + 1], c1);
-                    if (HT & 1) c0 = mma_chunk(A(p, gg * G2 + HT), tg < HT ? h1[0][HT - 1] : m[0][HT - 1], c0);
-                    const f4 acc = c0 + c1;
-                    if (tg < HT) m[0][tg] = silu4(acc);
+                    const f4 acc = tg < HT ? chain_tile<HT>(SL(p), gg * G2 + 1, h1[0], bias, hook)
+                                           : chain_tile<HT>(SL(p), gg * G2 + 1, m[0], bias, hook);
+                    if (tg < HT) m[0][tg] = EPI_SILU4(acc);
                     else {
                         const float gate = silu1(__shfl(acc.x, lane & 15, 64));
 #pragma unroll
@@ -207,22 +321,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_edge_v1(TopoDev tp, const fl
                 }
             }
         }
+        pf_flush();
     }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-        if (valid[nb])
-#pragma unroll
-            for (int t = 0; t < HT; ++t) st_blk(mbuf, e[nb], D::HP, t, lane, m[nb][t]);
-
     // ---- S3: ew += SiLU(W3 m + b3), one output tile per group ----------------------------------------
+    // stores are issued one phase late (right after the next barrier) so that the barrier's vmcnt(0)
+    // never waits for a store that was issued a few cycles earlier
+    f4 pend[GP][NB];
     for (int p3 = 0; p3 < S::NP3; ++p3, ++p) {
-        __syncthreads();
+        phase_barrier();
+        if (p3 == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int t = 0; t < HT; ++t) st_blk(mbuf, e[nb], D::HP, t, lane, m[nb][t]);
+        } else {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) st_f4(erow[nb] + 16 * ((p3 - 1) * GP + gg), pend[gg][nb]);   // (p3-1)*GP+gg < WB always
+        }
         f4 o[GP][NB];
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) o[gg][nb] = on[gg][nb];
-        issue(p + 1);
+        pf_start(p + 1);
         if (p3 + 1 < S::NP3) {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
@@ -249,18 +372,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_edge_v1(TopoDev tp, const fl
                         mma_shared_a<NB>(A(p, gg * G2 + 1 + b), xb, acc);
                     }
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        if (valid[nb]) st_f4(erow[nb] + 16 * t, o[gg][nb] + silu4(acc[nb]));
+                    for (int nb = 0; nb < NB; ++nb) pend[gg][nb] = o[gg][nb] + EPI_SILU4(acc[nb]);
                 } else {
-                    f4 c0 = bias, c1 = f4zero();
-#pragma unroll
-                    for (int b = 0; b + 1 < HT; b += 2)
-                        mma_pair(A(p, gg * G2 + 1 + b), m[0][b], c0, A(p, gg * G2 + 2 + b), m[0][b + 1], c1);
-                    if (HT & 1) c0 = mma_chunk(A(p, gg * G2 + HT), m[0][HT - 1], c0);
-                    if (valid[0]) st_f4(erow[0] + 16 * t, o[gg][0] + silu4(c0 + c1));
+                    pend[gg][0] = o[gg][0] + EPI_SILU4(chain_tile<HT>(SL(p), gg * G2 + 1, m[0], bias, hook));
                 }
             }
         }
+        pf_flush();
+    }
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg) {
+        const int t = (S::NP3 - 1) * GP + gg;
+        if (t < WB)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) st_f4(erow[nb] + 16 * t, pend[gg][nb]);
     }
 }
 
@@ -279,7 +404,7 @@ struct EquiStream {
     static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
 };
 
-template <class D, int WAVES>
+template <class D, int WAVES, int PRIO>
 __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                              const float* __restrict__ dp0b,
                                                              const float* __restrict__ ew, const float* __restrict__ rbuf,
@@ -287,23 +412,62 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = EquiStream<D>;
     constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT, G1 = S::G1, G2 = S::G2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (PRIO && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
 
-    auto issue = [&](int p) {
-        if (p >= S::NPH) return;
+    constexpr int KMAX = (S::SLAB + WAVES - 1) / WAVES;
+    const float* pf_src = stream;
+    float* pf_dst = smem;
+    int pf_n = 0, pf_k = 0, pf_next = 0;
+    auto pf_begin = [&](int p) {
         const int start = p < WB ? p * G1 : S::C1 + (p - WB) * G2;
-        const int n = p < WB ? G1 : G2;
-        float* dst = smem + (size_t)(p & 1) * S::SLAB * 256;
-        const float* src = stream + (size_t)start * 256 + lane * 4;
-        for (int j = wave; j < n; j += WAVES) glds16(src + (size_t)j * 256, dst + j * 256);
+        pf_n = p >= S::NPH ? 0 : (p < WB ? G1 : G2);
+        pf_src = stream + (size_t)start * 256 + lane * 4;
+        pf_dst = smem + (size_t)(p & 1) * S::SLAB * 256;
+        pf_k = 0; pf_next = 1 + (wave >= WAVES / 2 ? 1 : 0);
     };
+#ifdef OARD_STAGE_REG_EQUI
+    f4 stage[KMAX];
+    auto hook = [&]() {};
+    auto pf_flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int j = wave + k * WAVES;
+            if (j < pf_n) *reinterpret_cast<f4*>(pf_dst + j * 256 + lane * 4) = stage[k];
+        }
+    };
+    auto pf_load = [&]() {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int j = wave + k * WAVES;
+            if (j < pf_n) stage[k] = ld_f4(pf_src + (size_t)j * 256);
+        }
+    };
+    auto issue = [&](int p) { pf_begin(p); pf_load(); pf_flush(); };
+    auto pf_start = [&](int p) { pf_begin(p); pf_load(); };
+#else
+    auto pf_one = [&]() {
+        const int j = wave + pf_k * WAVES;
+        if (j < pf_n) glds16(pf_src + (size_t)j * 256, pf_dst + j * 256);
+        ++pf_k;
+    };
+#ifndef OARD_NO_HOOK
+    auto hook = [&]() { if (--pf_next == 0) { pf_one(); pf_next = 3; } };
+#else
+    auto hook = [&]() { while (pf_k < KMAX) pf_one(); };
+#endif
+    auto pf_flush = [&]() { while (pf_k < KMAX) pf_one(); };
+    auto issue = [&](int p) { pf_begin(p); pf_flush(); };
+    auto pf_start = [&](int p) { pf_begin(p); };
+#endif
     auto A = [&](int p, int j) -> f4 {
         return *reinterpret_cast<const f4*>(smem + ((size_t)(p & 1) * S::SLAB + j) * 256 + lane * 4);
     };
+    auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
 
     const long long c = ((long long)blockIdx.x * WAVES + wave) * 16 + (lane & 15);
-    const bool valid = c < tp.A;
-    const size_t a = (size_t)(valid ? c : tp.A - 1);
+    const size_t a = (size_t)(c < tp.A ? c : tp.A);           // padding columns use the spare entry A
     const float* erow = ew + (size_t)tp.act_edge[a] * D::WP + 4 * g;
     f4 d1[D1T];
 #pragma unroll
@@ -316,34 +480,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
 
     int p = 0;
     for (int b = 0; b < WB; ++b, ++p) {
-        __syncthreads();
+        phase_barrier();
         const f4 x = xn;
-        issue(p + 1);
+        pf_start(p + 1);
         if (b + 1 < WB) xn = ld_f4(erow + 16 * (b + 1));
-#pragma unroll
-        for (int t = 0; t + 1 < D1T; t += 2) mma_pair(A(p, t), x, d1[t], A(p, t + 1), x, d1[t + 1]);
-        if (D1T & 1) d1[D1T - 1] = mma_chunk(A(p, D1T - 1), x, d1[D1T - 1]);
+        chain_kouter<D1T>(SL(p), 0, x, d1, hook);
+        pf_flush();
     }
 #pragma unroll
-    for (int t = 0; t < D1T; ++t) d1[t] = silu4(d1[t]);
+    for (int t = 0; t < D1T; ++t) d1[t] = EPI_SILU4(d1[t]);
 
     float* qrow = qbuf + a * (size_t)(3 * D::HP) + 4 * g;
+    f4 pend = f4zero();
+    int pend_off = 0;
     for (int i = 0; i < S::NG2; ++i, ++p) {
-        __syncthreads();
-        issue(p + 1);
-        f4 c0 = A(p, 0), c1 = f4zero(), cr = f4zero();
-        // three independent chains: even / odd K blocks of dir_proj.2 and the rbf_proj tile
-#pragma unroll
-        for (int b = 0; b + 1 < D1T; b += 2) {
-            mma_pair(A(p, 1 + b), d1[b], c0, A(p, 2 + b), d1[b + 1], c1);
-            if (b / 2 < RB) cr = mma_chunk(A(p, 1 + D1T + b / 2), rb[b / 2], cr);
-        }
-        if (D1T & 1) c0 = mma_chunk(A(p, D1T), d1[D1T - 1], c0);
-#pragma unroll
-        for (int b = (D1T / 2 < RB ? D1T / 2 : RB); b < RB; ++b) cr = mma_chunk(A(p, 1 + D1T + b), rb[b], cr);
+        phase_barrier();
+        if (i > 0) st_f4(qrow + pend_off, pend);               // store of the previous phase, issued one phase late
+        pf_start(p + 1);
+        const f4 cd = chain_tile<D1T>(SL(p), 1, d1, A(p, 0), hook);
+        const f4 cr = chain_tile<RB>(SL(p), 1 + D1T, rb, f4zero(), hook);
+        pf_flush();
         const int tt = i / 3, th = i - 3 * tt;
-        if (valid) st_f4(qrow + th * D::HP + 16 * tt, (c0 + c1) * cr);
+        pend = cd * cr;
+        pend_off = th * D::HP + 16 * tt;
     }
+    st_f4(qrow + pend_off, pend);
 }
 
 // =====================================================================================================

@@ -47,7 +47,7 @@ struct Timing {
     }
 } g_timing;
 int g_stop_after = 0;
-int g_gcl_variant = 2;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
+int g_gcl_variant = 3;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
 int g_equi_variant = 2;
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
 size_t g_vec_final = 0;    // workspace offset of the vec buffer holding the final state (taps)
@@ -198,7 +198,7 @@ struct Packer {
 };
 static WsOff make_ws(const oard_config* c, const oard_topology* tp) {
     const RDims d(c->hidden, c->num_radial);
-    const size_t N = tp->d.N, E = std::max<long long>(tp->d.E, 1), A = std::max<long long>(tp->d.A, 1);
+    const size_t N = tp->d.N, E = tp->d.E + 1, A = tp->d.A + 1;   // + the spare row of the padding columns
     WsOff w;
     size_t cur = 0;
     auto take = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
@@ -229,53 +229,31 @@ int set_lds(K kernel, size_t bytes) {
     ScopedLaunch sl_(fam, stream); \
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), lds, stream, __VA_ARGS__); } while (0)
 
+#define GCL_CASE(id, NB_, WV_, GP_, PR_) case id: { \
+        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB_, WV_, GP_, PR_>), cdiv(tp.E, NB_ * 16 * WV_), WV_ * 64, \
+                   (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, P, Q, ew, mbuf); return OARD_OK; }
 template <class D>
 int launch_gcl_v1(int variant, const TopoDev& tp, const float* stream, const float* P, const float* Q, float* ew,
                   float* mbuf, hipStream_t st) {
     switch (variant) {
-        case 1: {   // 4 waves x 32 edges, one wave per SIMD
-            constexpr int NB = 2, WV = 4, GP = 2;
-            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB, WV, GP>), cdiv(tp.E, NB * 16 * WV), WV * 64,
-                       (GclStream<D, GP>::LDS_BYTES), st, tp, stream, P, Q, ew, mbuf);
-            return OARD_OK;
-        }
-        case 2: {   // 8 waves x 16 edges, two waves per SIMD
-            constexpr int NB = 1, WV = 8, GP = 2;
-            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB, WV, GP>), cdiv(tp.E, NB * 16 * WV), WV * 64,
-                       (GclStream<D, GP>::LDS_BYTES), st, tp, stream, P, Q, ew, mbuf);
-            return OARD_OK;
-        }
-        case 3: {   // 4 waves x 16 edges
-            constexpr int NB = 1, WV = 4, GP = 2;
-            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB, WV, GP>), cdiv(tp.E, NB * 16 * WV), WV * 64,
-                       (GclStream<D, GP>::LDS_BYTES), st, tp, stream, P, Q, ew, mbuf);
-            return OARD_OK;
-        }
-        case 4: {   // 4 waves x 32 edges, 4 groups per phase
-            constexpr int NB = 2, WV = 4, GP = 4;
-            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB, WV, GP>), cdiv(tp.E, NB * 16 * WV), WV * 64,
-                       (GclStream<D, GP>::LDS_BYTES), st, tp, stream, P, Q, ew, mbuf);
-            return OARD_OK;
-        }
+        GCL_CASE(1, 2, 4, 2, 0)      // 4 waves x 32 edges, one wave per SIMD
+        GCL_CASE(2, 1, 8, 2, 0)      // 8 waves x 16 edges, two waves per SIMD
+        GCL_CASE(3, 1, 4, 2, 0)      // 4 waves x 16 edges (two workgroups per CU)
+        GCL_CASE(4, 1, 8, 2, 1)      // as 2, static priority for waves 4-7
+        GCL_CASE(5, 1, 8, 4, 1)      // as 4, four groups per phase
         default: return OARD_EINVAL;
     }
 }
+#define EQUI_CASE(id, WV_, PR_) case id: { \
+        LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV_, PR_>), cdiv(tp.A, 16 * WV_), WV_ * 64, (EquiStream<D>::LDS_BYTES), st, \
+                   tp, stream, dp0b, ew, rbuf, qbuf); return OARD_OK; }
 template <class D>
 int launch_equi_v1(int variant, const TopoDev& tp, const float* stream, const float* dp0b, const float* ew,
                    const float* rbuf, float* qbuf, hipStream_t st) {
     switch (variant) {
-        case 1: {
-            constexpr int WV = 4;
-            LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV>), cdiv(tp.A, 16 * WV), WV * 64, (EquiStream<D>::LDS_BYTES), st,
-                       tp, stream, dp0b, ew, rbuf, qbuf);
-            return OARD_OK;
-        }
-        case 2: {
-            constexpr int WV = 8;
-            LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV>), cdiv(tp.A, 16 * WV), WV * 64, (EquiStream<D>::LDS_BYTES), st,
-                       tp, stream, dp0b, ew, rbuf, qbuf);
-            return OARD_OK;
-        }
+        EQUI_CASE(1, 4, 0)
+        EQUI_CASE(2, 8, 0)
+        EQUI_CASE(3, 8, 1)
         default: return OARD_EINVAL;
     }
 }
@@ -312,8 +290,8 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
     LAUNCH(F_OTHER, k_prep, cdiv(N, 128), 128, st, tp, op, wb, pos, hin, t, t_scalar, cond,
            c->condition_nf > 0 ? c->condition_nf : 0, c->condition_time, emb);
     LAUNCH(F_INIT, k_geom, tp.n_groups, 64, st, tp, (const float*)pos, cutoff, pf64, pf32, x1, pp0, labels);
-    if (E > 0) LAUNCH(F_INIT, k_fill_edges, std::min<long long>(cdiv(E * (D::WP / 4), 256), 8192), 256, st,
-                      wb + po.c0row, ew, E, D::WP);
+    LAUNCH(F_INIT, k_fill_edges, std::min<long long>(cdiv((E + 1) * (D::WP / 4), 256), 8192), 256, st,
+           wb + po.c0row, ew, E + 1, D::WP);
     if (A > 0) {
         LAUNCH(F_INIT, k_edge_geo, cdiv(A, 256), 256, st, tp, (const float*)pos, (const double*)pf64, cutoff, geo, d64);
         LAUNCH(F_INIT, k_rbf, cdiv(A * D::RP, 256), 256, st, tp, (const double*)d64, (const float*)geo,
@@ -544,7 +522,8 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
         A += ng * (ng - 1);
     }
     if (max_group > OARD_MAX_GROUP || A > 0x7fffffffLL) return OARD_EINVAL;
-    std::vector<int> edge_src((size_t)std::max<long long>(E, 1)), edge_tgt((size_t)std::max<long long>(E, 1));
+    // one spare entry (index E / A) for the padding columns of the edge kernels
+    std::vector<int> edge_src((size_t)E + 1, 0), edge_tgt((size_t)E + 1, 0);
     for (int b = 0; b < B; ++b) {
         const int s0 = sample_ptr[b], s1 = sample_ptr[b + 1];
         for (int n = s0; n < s1; ++n) {
@@ -552,8 +531,7 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
             for (int m = s0; m < s1; ++m) if (m != n) { edge_src[e] = n; edge_tgt[e] = m; ++e; }
         }
     }
-    std::vector<int> act_src((size_t)std::max<long long>(A, 1)), act_tgt((size_t)std::max<long long>(A, 1)),
-        act_edge((size_t)std::max<long long>(A, 1));
+    std::vector<int> act_src((size_t)A + 1, 0), act_tgt((size_t)A + 1, 0), act_edge((size_t)A + 1, (int)E);
     {
         size_t a = 0;
         for (int n = 0; n < N; ++n) {
