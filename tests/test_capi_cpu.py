@@ -1,0 +1,97 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/oard.h declares, the module reproduces the reference state-dict layout, and the product path
+fails loudly (no CPU fallback) when asked to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from _cases import Case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from oareactdiff_amd import _capi
+    from oareactdiff_amd.build import build
+    build()
+    return _capi, _capi.lib()
+
+
+def test_library_exports_every_declared_symbol():
+    _capi, L = _lib()
+    header = open(os.path.join(ROOT, "include", "oard.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(oard_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/oard.h but not exported"
+    assert set(_capi.EXPORTS) <= declared
+    assert L.oard_version() >= 1001
+
+
+def test_config_support_and_param_count():
+    _capi, L = _lib()
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    for name in ("g1_wrapper_small", "g2_prod_b2_n23", "g6_h32_r32"):
+        c = Case(name)
+        d = EGNNDynamics(model_config=dict(c.cfg), fragment_names=[f"o{k}" for k in range(c.n_obj)],
+                         node_nfs=c.node_nfs, edge_nf=0, condition_nf=c.cnf, device=torch.device("cpu"))
+        cfg = d._config()
+        assert L.oard_supported(C.byref(cfg)) == 0
+        assert L.oard_param_count(C.byref(cfg)) == len(c.spec) == len(d._ordered_tensors())
+        assert L.oard_packed_bytes(C.byref(cfg)) > 4 * sum(v.numel() for v in c.state_dict().values()) // 2
+    bad = _capi.OardConfig()
+    bad.hidden, bad.num_radial, bad.num_layers, bad.in_hidden, bad.n_obj, bad.pos_dim, bad.reflect_equiv = 100, 96, 6, 8, 3, 3, 1
+    assert L.oard_supported(C.byref(bad)) != 0
+
+
+def test_state_dict_layout_matches_reference_names():
+    """Names/shapes are those of the reference's EGNNDynamics(model=LEFTNet).state_dict() (pinned when the
+    goldens were generated: the reference loaded this spec's tensors with strict=True)."""
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    c = Case("g2_prod_b2_n23")
+    d = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=c.node_nfs, edge_nf=0,
+                     condition_nf=c.cnf, device=torch.device("cpu"))
+    sd = c.state_dict()
+    assert list(d.state_dict().keys()) == list(sd.keys())
+    assert all(d.state_dict()[k].shape == sd[k].shape for k in sd)
+    d.load_state_dict(sd, strict=True)
+    assert sum(p.numel() for p in d.parameters()) == 10645719
+    assert d.pos_dim == 3 and d.node_nfs == c.node_nfs and d.embed_dim == 6 and d.edge_encoder is None
+    # enforce_same_encoding aliases encoder/decoder 0 (reference _base.py:110-113)
+    d2 = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=c.node_nfs, edge_nf=0,
+                      condition_nf=c.cnf, device=torch.device("cpu"), enforce_same_encoding=[1, 2])
+    assert d2.encoders[1] is d2.encoders[0] and d2.decoders[2] is d2.decoders[0]
+    assert len(d2.state_dict()) == len(sd)
+    # the constructor mutates model_config exactly like the reference (_base.py:47-51)
+    cfg = dict(c.cfg)
+    EGNNDynamics(model_config=cfg, fragment_names=["R", "TS", "P"], node_nfs=c.node_nfs, edge_nf=0,
+                 condition_nf=c.cnf, device=torch.device("cpu"))
+    assert cfg["act_fn"] == "swish" and cfg["in_node_nf"] == cfg["in_hidden_channels"]
+
+
+def test_no_cpu_fallback_and_config_errors():
+    from oareactdiff_amd._capi import OardError
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    c = Case("g1_wrapper_small")
+    d = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["a", "b", "c"], node_nfs=c.node_nfs, edge_nf=0,
+                     condition_nf=c.cnf, device=torch.device("cpu"))
+    d.load_state_dict(c.state_dict())
+    with torch.no_grad(), pytest.raises(OardError):
+        d(c.xh, c.edge_index, c.t, c.conditions, c.n_frag_switch, c.combined_mask)
+    with pytest.raises(NotImplementedError):                    # forward-only in this release
+        d(c.xh, c.edge_index, c.t, c.conditions, c.n_frag_switch, c.combined_mask)
+    with pytest.raises(NotImplementedError):                    # update_pocket_coords=False (egnn_dynamics.py:125)
+        d2 = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["a", "b", "c"], node_nfs=c.node_nfs, edge_nf=0,
+                          condition_nf=c.cnf, update_pocket_coords=False, device=torch.device("cpu"))
+        with torch.no_grad():
+            d2(c.xh, c.edge_index, c.t, c.conditions, c.n_frag_switch, c.combined_mask)
+    with pytest.raises(AssertionError):                         # _base.py:44-46
+        EGNNDynamics(model_config=dict(c.cfg), fragment_names=["a"], node_nfs=c.node_nfs, edge_nf=0,
+                     device=torch.device("cpu"))
+    with pytest.raises(NotImplementedError):
+        EGNNDynamics(model_config=dict(c.cfg, reflect_equiv=False), fragment_names=["a", "b", "c"],
+                     node_nfs=c.node_nfs, edge_nf=0, condition_nf=c.cnf, device=torch.device("cpu"))
