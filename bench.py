@@ -37,23 +37,46 @@ def cpu_baseline(n_atoms: int, threads: int):
     torch.set_num_threads(threads)
     cfg = dict(PRODUCTION_LEFTNET_CONFIG)
     sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg)
-    B = 2
+    B = 4
     cm, nfs, ei, masks = make_topology(B, n_atoms)
     xh = make_inputs(B, n_atoms, masks, 7, "cpu")
     t = torch.full((B, 1), 0.5)
     cond = torch.zeros(B, 1)
-    calls, t0 = 0, None
-    for it in range(4):
-        if it == 1:
-            t0 = time.perf_counter()
+    with torch.no_grad():                                   # warm-up
+        oracle.dynamics_forward(sd, cfg, xh, ei, t, cond, nfs, cm, 1, nodeframe="literal")
+    calls, t0 = 0, time.perf_counter()
+    while calls < 3 or (time.perf_counter() - t0 < 12.0 and calls < 40):      # ~12-20 s of CPU work
         with torch.no_grad():
             oracle.dynamics_forward(sd, cfg, xh, ei, t, cond, nfs, cm, 1, nodeframe="literal")
-        if it >= 1:
-            calls += 1
+        calls += 1
     dt = time.perf_counter() - t0
     return {"value": B * calls / dt, "unit": "reaction-steps/s", "cores": threads, "kind": "port",
             "sample": f"oracle/leftnet_oracle.py, float32, B={B} x {n_atoms}-atom triples, {calls} calls after 1 warm-up, "
                       f"{dt:.1f} s"}
+
+
+def pmc_traffic(kernel: str, batch: int, atoms: int):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/round1_pmc_{fetch,write}.txt,
+    collected at the default workload): FETCH_SIZE (KiB; x2 — it under-reports wide streaming reads by 2x on
+    gfx950, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KiB).  None for any other workload."""
+    if (batch, atoms) != (64, 23):
+        return None
+    import re
+    vals = {}
+    for key, fn in (("FETCH_SIZE", "round1_pmc_fetch.txt"), ("WRITE_SIZE", "round1_pmc_write.txt")):
+        path = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(path):
+            return None
+        cur = None
+        for line in open(path):
+            if line.startswith("=="):
+                cur = line
+            m = re.search(key + r"\s+avg/launch = ([0-9.e+]+)", line)
+            if m and cur and kernel in cur:
+                vals[key] = float(m.group(1))
+    if len(vals) != 2:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
 def main():
@@ -72,11 +95,17 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     dist = None
+    backend = os.environ.get("OARD_BENCH_BACKEND", "nccl")    # "gloo" only to exercise the N>1 code path on a 1-GPU box
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -117,7 +146,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if not os.environ.get("OARD_BENCH_ALLOW_NAN"):          # (kernel ablation experiments produce garbage on purpose)
@@ -143,7 +172,7 @@ def main():
         dom = max(flops, key=lambda f: fam[f]["ms_per_step"])
         ach = flops[dom] / (fam[dom]["avg_ms"] * 1e-3)
         roof = {"bound": "mfma", "kernel": "k_" + dom, "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "traffic": None,
+                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "traffic": pmc_traffic("k_" + dom, B, nf),
                 "algorithmic_flops_per_launch": flops[dom], "avg_launch_ms": fam[dom]["avg_ms"],
                 "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},
                 "other_kernel": {"kernel": "k_" + [f for f in flops if f != dom][0],

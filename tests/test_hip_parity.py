@@ -97,3 +97,82 @@ def test_rejects_non_complete_topology():
     with pytest.raises(OardError):
         with torch.no_grad():
             dyn(*a)
+
+
+def _random_case(sizes, pos_scale, seed, cfg):
+    """Ragged synthetic batch (reactions of different atom counts), production feature layout."""
+    from oareactdiff_amd.graph_tools import get_edges_index, get_mask_for_frag, get_n_frag_switch
+    g = torch.Generator().manual_seed(seed)
+    natm = [torch.tensor(sizes) for _ in range(3)]
+    masks = [get_mask_for_frag(n) for n in natm]
+    cm = torch.cat(masks)
+    nfs = get_n_frag_switch(natm)
+    ei = get_edges_index(cm, remove_self_edge=True)
+    xh = []
+    for m in masks:
+        n = m.numel()
+        pos = torch.randn(n, 3, generator=g)
+        mean = torch.zeros(len(sizes), 3).index_add_(0, m, pos) / torch.tensor(sizes, dtype=torch.float32).unsqueeze(1)
+        pos = (pos - mean[m]) * pos_scale
+        typ = torch.randint(0, 4, (n,), generator=g)
+        feat = torch.zeros(n, 6)
+        feat[torch.arange(n), typ] = 1.0
+        feat[:, 5] = torch.tensor([1.0, 6.0, 7.0, 8.0])[typ]
+        xh.append(torch.cat([pos, feat], 1))
+    B = len(sizes)
+    return xh, ei, torch.rand(B, 1, generator=g), torch.rand(B, 1, generator=g), nfs, cm
+
+
+@pytest.mark.parametrize("sizes,pos_scale", [([7, 23, 12, 1, 16], 1.0), ([9, 30, 5], 2.5), ([40, 3], 1.5)])
+def test_ragged_production_dims_vs_oracle(sizes, pos_scale):
+    """Ragged reactions (incl. a single-atom-per-object sample and groups > 32 atoms), with and without the
+    cutoff biting, production dims, against the float64 oracle evaluated here on the same inputs."""
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    cfg = dict(PRODUCTION_LEFTNET_CONFIG, num_layers=3)
+    spec = state_spec(cfg, [9, 9, 9], 1)
+    sd = synthetic_state_dict(spec, cfg, seed=7)
+    xh, ei, t, cond, nfs, cm = _random_case(sizes, pos_scale, 11, cfg)
+    dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
+                       condition_nf=1, device=dev)
+    dyn.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        out, _ = dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+    ref = oracle.dynamics_forward({k: v.double() for k, v in sd.items()}, cfg, [x.double() for x in xh], ei,
+                                  t.double(), cond.double(), nfs, cm, 1, nodeframe="exact")
+    v = torch.cat([o[:, :3].cpu().double().reshape(-1) for o in out])
+    h = torch.cat([o[:, 3:].cpu().double().reshape(-1) for o in out])
+    rv = torch.cat([o[:, :3].reshape(-1) for o in ref])
+    rh = torch.cat([o[:, 3:].reshape(-1) for o in ref])
+    assert rel(v, rv) <= TOL and rel(h, rh) <= TOL, (rel(v, rv), rel(h, rh))
+
+
+def test_scalar_t_equals_per_sample_t_and_input_is_not_mutated():
+    dev = torch.device("cuda:0")
+    c = Case("g3_cutoff_ragged")
+    dyn = _dyn(c, dev)
+    a = list(_args(c, dev))
+    keep = [x.clone() for x in a[0]]
+    with torch.no_grad():
+        o1, _ = dyn(a[0], a[1], torch.tensor([0.25], device=dev), a[3], a[4], a[5])
+        B = int(c.combined_mask.max()) + 1
+        o2, _ = dyn(a[0], a[1], torch.full((B, 1), 0.25, device=dev), a[3], a[4], a[5])
+    for x, y in zip(o1, o2):
+        assert torch.equal(x, y)
+    for x, y in zip(a[0], keep):
+        assert torch.equal(x, y)                       # egnn_dynamics.py:92,97 clone the inputs
+
+
+def test_condition_and_time_change_the_output():
+    """oa_reactdiff/tests/dynamics/test_egnn_dynamics.py:181-228 restated."""
+    dev = torch.device("cuda:0")
+    c = Case("g1_wrapper_small")
+    dyn = _dyn(c, dev)
+    a = list(_args(c, dev))
+    with torch.no_grad():
+        o0, _ = dyn(*a)
+        o1, _ = dyn(a[0], a[1], torch.tensor([0.9], device=dev), a[3], a[4], a[5])
+        o2, _ = dyn(a[0], a[1], a[2], a[3] + 0.5, a[4], a[5])
+    k = 1                                              # object 1 has nodes in both samples
+    assert (o0[k] - o1[k]).abs().max() > 1e-6 and (o0[k] - o2[k]).abs().max() > 1e-6
