@@ -179,6 +179,24 @@ def main():
                                  "achieved": flops[[f for f in flops if f != dom][0]] /
                                  (fam[[f for f in flops if f != dom][0]]["avg_ms"] * 1e-3) / 1e12}}
 
+    # the real sampling loop (row N1): T_probe genuine ancestral steps (network + fused sampler kernel + RNG)
+    sampler_leg = None
+    if rank == 0:
+        from oareactdiff_amd.sampler import DiffusionSampler
+        T_probe = 12
+        smp = DiffusionSampler(dyn, "polynomial_2", T_probe, 1e-5, pos_only=True)
+        frag = [torch.full((B,), nf, dtype=torch.long) for _ in range(3)]
+        h0 = [x[:, 3:].clone() for x in inputs[0]]
+        smp.sample(B, frag, conditions=cond, h0=h0)                      # warm-up (topology, buffers)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        smp.sample(B, frag, conditions=cond, h0=h0)
+        torch.cuda.synchronize(dev)
+        dts = time.perf_counter() - t1
+        per_call = dts / (T_probe + 1)
+        sampler_leg = {"ms_per_network_call_incl_sampler_step": per_call * 1e3, "network_calls": T_probe + 1,
+                       "reactions_per_sec_T1000_projected": B / (1001 * per_call)}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
@@ -192,6 +210,7 @@ def main():
             "batch_steps_per_sec_per_gpu": args.steps / dt,
             "reactions_per_sec_T1000": value / 1001.0,
             "roofline": roof,
+            "sampler_loop": sampler_leg,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nf, os.cpu_count() or 1)

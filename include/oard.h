@@ -102,6 +102,22 @@ int oard_forward(const oard_config* cfg, const oard_topology* topo, const void* 
                  void* workspace_dev, size_t workspace_bytes, int32_t* status_dev,
                  oard_stream_t stream);
 
+/* ---- sampler step (next row N1) ----------------------------------------------------------------
+ * Replaces the element-wise part of EnVariationalDiffusion.sample_p_zs_given_zt / sample_normal /
+ * sample_p_xh_given_z0 (oa_reactdiff/diffusion/en_diffusion.py:562-702) and the CoM-free noise of
+ * sample_combined_position_feature_noise (:278-305), per object k, rows in the reference's order:
+ *   eps      = [ noise_pos - mean_group(noise_pos) | zero_feature_noise ? 0 : noise_feat ]
+ *   mode 0:  out = z / a - eps_hat * b + c * eps ;  out_pos -= mean_group(out_pos)     (a = alpha_t|s, b, c = sigma)
+ *   mode 1:  out = a * (z - b * eps_hat) + c * eps                                     (a = 1/alpha_0, b = sigma_0, c = sigma_x)
+ *   mode 2:  out = eps                                                                 (initial z_T)
+ *   h0_dev[k] != NULL: the feature columns of out are overwritten by h0 (pos_only sampling, :526-530).
+ * group = nodes of one object in one sample.  The scalars are host values (the schedule is a host table),
+ * so a sampling loop built on this and oard_forward never synchronises. */
+int oard_sampler_step(const oard_config* cfg, const oard_topology* topo, int mode,
+                      const float* const* z_dev, const float* const* eps_hat_dev, const float* const* noise_dev,
+                      const float* const* h0_dev, float a, float b, float c, int zero_feature_noise,
+                      float* const* out_dev, oard_stream_t stream);
+
 /* ---- introspection (tests / profiling) --------------------------------------------------------
  * Copies an intermediate tensor of the LAST oard_forward on this workspace into dst_dev, in the
  * reference's node / edge order, dense [rows, cols] fp32.  `which`: see OARD_TAP_*.  `layer`

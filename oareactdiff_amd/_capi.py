@@ -17,7 +17,7 @@ TAP_S, TAP_VEC, TAP_EDGE, TAP_POS_FRAME, TAP_DPOS, TAP_HOUT, TAP_LABELS, TAP_NE1
 EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_bytes", "oard_pack_weights",
            "oard_topology_create", "oard_topology_destroy", "oard_topology_num_nodes", "oard_topology_num_edges",
            "oard_topology_num_inner_edges", "oard_topology_num_samples", "oard_topology_check_edge_index",
-           "oard_workspace_bytes", "oard_forward", "oard_tap", "oard_debug_stop_after", "oard_debug_option", "oard_timing_enable", "oard_timing_reset",
+           "oard_workspace_bytes", "oard_forward", "oard_sampler_step", "oard_tap", "oard_debug_stop_after", "oard_debug_option", "oard_timing_enable", "oard_timing_reset",
            "oard_timing_get"]
 
 
@@ -68,6 +68,9 @@ def lib() -> C.CDLL:
     L.oard_workspace_bytes.argtypes = [cfgp, vp]; L.oard_workspace_bytes.restype = sz
     L.oard_forward.argtypes = [cfgp, vp, vp, C.POINTER(vp), vp, C.c_int, vp, C.POINTER(vp), vp, sz, vp, vp]
     L.oard_forward.restype = C.c_int
+    L.oard_sampler_step.argtypes = [cfgp, vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                    C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(vp), vp]
+    L.oard_sampler_step.restype = C.c_int
     L.oard_tap.argtypes = [cfgp, vp, vp, C.c_int, C.c_int, vp, vp]; L.oard_tap.restype = C.c_int
     L.oard_debug_stop_after.argtypes = [C.c_int]; L.oard_debug_stop_after.restype = C.c_int
     L.oard_debug_option.argtypes = [C.c_char_p, C.c_int]; L.oard_debug_option.restype = C.c_int
@@ -75,7 +78,7 @@ def lib() -> C.CDLL:
     L.oard_timing_reset.argtypes = []; L.oard_timing_reset.restype = C.c_int
     L.oard_timing_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]; L.oard_timing_get.restype = C.c_int
     for env, opt in (("OARD_GCL_VARIANT", b"gcl_variant"), ("OARD_EQUI_VARIANT", b"equi_variant"),
-                     ("OARD_NODE_VARIANT", b"node_variant")):
+                     ("OARD_NODE_VARIANT", b"node_variant"), ("OARD_OVERLAP", b"overlap")):
         if os.environ.get(env):
             check(L.oard_debug_option(opt, int(os.environ[env])), f"oard_debug_option({opt.decode()})")
     _lib = L

@@ -50,6 +50,9 @@ int g_stop_after = 0;
 int g_gcl_variant = 3;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
 int g_equi_variant = 2;
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
+int g_overlap = 0;         // run the GCL node stage on a side stream underneath the Equi edge kernel
+hipStream_t g_side = nullptr;
+hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
 size_t g_vec_final = 0;    // workspace offset of the vec buffer holding the final state (taps)
 
 struct ScopedLaunch {
@@ -241,6 +244,8 @@ int launch_gcl_v1(int variant, const TopoDev& tp, const float* stream, const flo
         GCL_CASE(3, 1, 4, 2, 0)      // 4 waves x 16 edges (two workgroups per CU)
         GCL_CASE(4, 1, 8, 2, 1)      // as 2, static priority for waves 4-7
         GCL_CASE(5, 1, 8, 4, 1)      // as 4, four groups per phase
+        GCL_CASE(6, 3, 4, 2, 0)      // 4 waves x 48 edges, one wave per SIMD
+        GCL_CASE(7, 4, 4, 2, 0)      // 4 waves x 64 edges, one wave per SIMD
         default: return OARD_EINVAL;
     }
 }
@@ -311,7 +316,7 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
     for (int l = 0; l < c->num_layers; ++l) {
         const LayerOff lo = po.layer[l];
         const bool nv1 = g_node_variant == 1 && g_equi_variant != 0;
-        const unsigned gN16 = (unsigned)cdiv(N, 16);
+        const unsigned gN16 = (unsigned)cdiv(N, OARD_NPB);
         if (nv1) LAUNCH(F_NODE, (k_node_pre_v1<D, 8>), gN16, 512, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
         else LAUNCH(F_NODE, (k_node_pre<D>), gN, 256, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
         if (E > 0) {
@@ -322,8 +327,23 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
                 if (rc != OARD_OK) return rc;
             }
         }
-        if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, 8>), gN16, 512, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
-        else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
+        // k_equi_edge_v1 needs only the edge state, not the node update: the GCL node stage (s, xq) runs on a
+        // side stream underneath it and is joined before the Equi node stage
+        const bool fork = nv1 && g_overlap && g_equi_variant != 0 && A > 0 && g_stop_after == 0 && !g_timing.on;
+        hipStream_t sn = st;
+        if (fork) {
+            if (!g_side) {
+                HIP_TRY(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventRecord(g_ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(g_side, g_ev_fork, 0));
+            sn = g_side;
+        }
+        if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, 8>), gN16, 512, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
+        else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
+        if (fork) HIP_TRY(hipEventRecord(g_ev_join, g_side));
         if (g_stop_after == 100 + 10 * l + 1) { g_vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
         if (g_equi_variant == 0) {
             if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew, (const float*)rbuf,
@@ -335,6 +355,7 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
                 int rc = launch_equi_v1<D>(g_equi_variant, tp, wb + lo.equi_stream, wb + lo.dp0b, ew, rbuf, vmsg, st);
                 if (rc != OARD_OK) return rc;
             }
+            if (fork) HIP_TRY(hipStreamWaitEvent(st, g_ev_join, 0));
             if (nv1) {
                 LAUNCH(F_NODE, (k_equi_node_v1<D, 8>), gN16, 512, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
                        (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext);
@@ -643,6 +664,28 @@ int oard_forward(const oard_config* c, const oard_topology* topo, const void* pa
     return rc;
 }
 
+int oard_sampler_step(const oard_config* c, const oard_topology* topo, int mode, const float* const* z,
+                      const float* const* eh, const float* const* noise, const float* const* h0, float a, float b,
+                      float cc, int zero_feature_noise, float* const* out, oard_stream_t stream) {
+    if (!config_ok(c) || !topo || !noise || !out || mode < 0 || mode > 2) return OARD_EINVAL;
+    if (mode != 2 && (!z || !eh)) return OARD_EINVAL;
+    if (c->n_obj != topo->d.n_obj) return OARD_EINVAL;
+    SamplerPtrs sp;
+    memset(&sp, 0, sizeof(sp));
+    for (int k = 0; k < c->n_obj; ++k) {
+        sp.z[k] = mode == 2 ? noise[k] : z[k];
+        sp.eh[k] = mode == 2 ? noise[k] : eh[k];
+        sp.noise[k] = noise[k];
+        sp.h0[k] = h0 ? h0[k] : nullptr;
+        sp.out[k] = out[k];
+        sp.node_nf[k] = c->node_nf[k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    LAUNCH(F_OTHER, k_sampler_step, cdiv(topo->d.N, 128), 128, st, topo->d, sp, mode, a, b, cc, zero_feature_noise);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
 int oard_tap(const oard_config* c, const oard_topology* topo, const void* ws_, int which, int layer, float* dst,
              oard_stream_t stream) {
     if (!config_ok(c) || !topo || !ws_ || !dst || layer != 0) return OARD_EINVAL;
@@ -682,6 +725,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "gcl_variant") == 0) { g_gcl_variant = value; return OARD_OK; }
     if (strcmp(name, "equi_variant") == 0) { g_equi_variant = value; return OARD_OK; }
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
+    if (strcmp(name, "overlap") == 0) { g_overlap = value; return OARD_OK; }
     return OARD_EINVAL;
 }
 int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }

@@ -199,6 +199,55 @@ __global__ void k_post(TopoDev tp, ObjPtrs op, const float* __restrict__ wb, con
 }
 
 // =====================================================================================================
+// sampler step (en_diffusion.py:562-702, 278-305; _utils.py:9-31): one thread per node
+// =====================================================================================================
+struct SamplerPtrs {
+    const float* z[OARD_MAX_OBJECTS];
+    const float* eh[OARD_MAX_OBJECTS];
+    const float* noise[OARD_MAX_OBJECTS];
+    const float* h0[OARD_MAX_OBJECTS];
+    float* out[OARD_MAX_OBJECTS];
+    int node_nf[OARD_MAX_OBJECTS];
+};
+__global__ void k_sampler_step(TopoDev tp, SamplerPtrs sp, int mode, float a, float b, float c, int zero_h) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= tp.N) return;
+    const int obj = tp.node_obj[n], row = tp.node_row[n], nf = sp.node_nf[obj];
+    const int q = tp.node_sample[n] * tp.n_obj + obj;
+    const int g0 = tp.grp_ptr[q], g1 = tp.grp_ptr[q + 1];
+    const float inv = 1.0f / (float)(g1 - g0);
+    const float* Z = sp.z[obj]; const float* E = sp.eh[obj]; const float* R = sp.noise[obj];
+    // group means: raw noise, then the un-projected update (scatter_mean order = ascending row)
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (int k = g0; k < g1; ++k) {
+        const float* r = R + (size_t)tp.node_row[k] * nf;
+        m0 += r[0]; m1 += r[1]; m2 += r[2];
+    }
+    m0 *= inv; m1 *= inv; m2 *= inv;
+    auto upd = [&](float z, float e, float eps) -> float {
+        if (mode == 0) return z / a - e * b + c * eps;
+        if (mode == 1) return a * (z - b * e) + c * eps;
+        return eps;
+    };
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (mode == 0) {
+        for (int k = g0; k < g1; ++k) {
+            const size_t o = (size_t)tp.node_row[k] * nf;
+            s0 += upd(Z[o], E[o], R[o] - m0); s1 += upd(Z[o + 1], E[o + 1], R[o + 1] - m1); s2 += upd(Z[o + 2], E[o + 2], R[o + 2] - m2);
+        }
+        s0 *= inv; s1 *= inv; s2 *= inv;
+    }
+    const size_t o = (size_t)row * nf;
+    float* out = sp.out[obj] + o;
+    out[0] = upd(Z[o], E[o], R[o] - m0) - s0;
+    out[1] = upd(Z[o + 1], E[o + 1], R[o + 1] - m1) - s1;
+    out[2] = upd(Z[o + 2], E[o + 2], R[o + 2] - m2) - s2;
+    const float* h0 = sp.h0[obj];
+    for (int j = 3; j < nf; ++j)
+        out[j] = h0 ? h0[o - 3 * (size_t)row + (size_t)(j - 3)] : upd(Z[o + j], E[o + j], zero_h ? 0.f : R[o + j]);
+}
+
+// =====================================================================================================
 // geometry block in float64 (leftnet.py:747-761, 707-722, 812-834)
 // =====================================================================================================
 // one 64-thread block per (sample, object) group: cutoff graph inside the group, the reference's

@@ -70,11 +70,16 @@ struct NodeBlk {
     int lane, wave, g, n;
     bool valid;
 };
+// NPB = real nodes per workgroup (<= 16): fewer than 16 leaves MFMA columns empty but doubles the
+// number of workgroups, which is what these latency-bound stages need at N = 4416
+#ifndef OARD_NPB
+#define OARD_NPB 16
+#endif
 OARD_DEV NodeBlk node_blk(int N) {
     NodeBlk b;
     b.lane = threadIdx.x & 63; b.wave = threadIdx.x >> 6; b.g = b.lane >> 4;
-    const int c = blockIdx.x * 16 + (b.lane & 15);
-    b.valid = c < N;
+    const int c = blockIdx.x * OARD_NPB + (b.lane & 15);
+    b.valid = (b.lane & 15) < OARD_NPB && c < N;
     b.n = b.valid ? c : N - 1;
     return b;
 }

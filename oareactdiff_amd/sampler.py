@@ -1,0 +1,124 @@
+"""On-device ancestral sampler around the HIP denoising call.
+
+`DiffusionSampler.sample` mirrors `EnVariationalDiffusion.sample`
+(oa_reactdiff/diffusion/en_diffusion.py:459-560): same arguments, same return value
+`(out_samples, fragments_masks)`.  Per step it issues one `oard_forward` and one `oard_sampler_step`
+(mu, CoM-free noise, CoM projection, pos_only feature reset fused); the schedule scalars come from a host
+table, the NaN flag stays on the device, and the reference's four `.item()` asserts per step are gone, so
+the loop never synchronises the host with the GPU."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _capi
+from .dynamics import EGNNDynamics
+from .graph_tools import get_edges_index, get_mask_for_frag, get_n_frag_switch
+from .schedule import Schedule
+
+
+class DiffusionSampler:
+    def __init__(self, dynamics: EGNNDynamics, noise_schedule: str = "polynomial_2", timesteps: int = 1000,
+                 precision: float = 1e-5, pos_only: bool = False,
+                 norm_values: Sequence[float] = (1.0, 1.0, 1.0), norm_biases: Sequence[float] = (0.0, 0.0, 0.0)):
+        self.dynamics = dynamics
+        self.schedule = Schedule(noise_schedule, timesteps, precision)
+        self.T = timesteps
+        self.pos_only = pos_only
+        self.pos_dim = dynamics.pos_dim
+        self.node_nfs = dynamics.node_nfs
+        self.norm_values = tuple(norm_values)
+        self.norm_biases = tuple(norm_biases)
+
+    # --------------------------------------------------------------------------------------------
+    def _step_kernel(self, topo, mode, z, eh, noise, h0, a, b, c, out, stream):
+        L = _capi.lib()
+        cfg = self.dynamics._config()
+        n = len(self.node_nfs)
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts]) if ts is not None else None
+        rc = L.oard_sampler_step(C.byref(cfg), topo.handle, mode, arr(z), arr(eh), arr(noise), arr(h0),
+                                 C.c_float(a), C.c_float(b), C.c_float(c), 1 if self.pos_only else 0, arr(out), stream)
+        _capi.check(rc, "oard_sampler_step")
+
+    @torch.no_grad()
+    def sample(self, n_samples: int, fragments_nodes: List[Tensor], conditions: Optional[Tensor] = None,
+               return_frames: int = 1, timesteps: Optional[int] = None, h0: Optional[List[Tensor]] = None,
+               noise_fn: Optional[Callable[[int], List[Tensor]]] = None) -> Tuple[list, List[Tensor]]:
+        """`noise_fn(i)` (tests) supplies the i-th set of raw N(0,1) draws, one [n_k, node_nf_k] tensor per
+        object (i = 0 initial state, 1..T the steps, T+1 the final draw); default: torch.randn on the device."""
+        timesteps = self.T if timesteps is None else timesteps
+        assert 0 < return_frames <= timesteps and timesteps % return_frames == 0       # en_diffusion.py:473-475
+        assert h0 is not None if self.pos_only else True
+        dyn = self.dynamics
+        dev = next(dyn.parameters()).device
+        if dev.type != "cuda":
+            raise _capi.OardError("DiffusionSampler needs the dynamics on a ROCm device (no CPU fallback)")
+        n_obj = len(self.node_nfs)
+        fragments_nodes = [f.to(dev) for f in fragments_nodes]
+        masks = [get_mask_for_frag(f) for f in fragments_nodes]
+        combined_mask = torch.cat(masks)
+        edge_index = get_edges_index(combined_mask, remove_self_edge=True)
+        n_frag_switch = get_n_frag_switch(fragments_nodes)
+        if conditions is None:
+            conditions = torch.zeros(n_samples, max(dyn.condition_nf, 1), device=dev)
+        conditions = conditions.to(dev)
+        h0d = [h.to(device=dev, dtype=torch.float32).contiguous() for h in h0] if h0 is not None else None
+        sizes = [int(m.numel()) for m in masks]
+        old_nan = dyn.nan_check
+        dyn.nan_check = "async"
+        try:
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                cfg = dyn._config()
+                topo = dyn._get_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+
+                def draw(i):
+                    if noise_fn is not None:
+                        return [x.to(device=dev, dtype=torch.float32).contiguous() for x in noise_fn(i)]
+                    return [torch.randn(sizes[k], self.node_nfs[k], device=dev) for k in range(n_obj)]
+
+                za = [torch.empty(sizes[k], self.node_nfs[k], device=dev) for k in range(n_obj)]
+                zb = [torch.empty_like(z) for z in za]
+                self._step_kernel(topo, 2, None, None, draw(0), h0d if self.pos_only else None, 0.0, 0.0, 1.0, za, stream)
+                t_table = torch.arange(timesteps + 1, device=dev, dtype=torch.float32) / timesteps
+                out_samples = [None] * return_frames
+                call = 1
+                for s in reversed(range(timesteps)):
+                    co = self.schedule.step(s, timesteps)
+                    eps_hat, _ = dyn(za, edge_index, t_table[s + 1: s + 2], conditions, n_frag_switch, combined_mask)
+                    self._step_kernel(topo, 0, za, eps_hat, draw(call), h0d if self.pos_only else None,
+                                      co.alpha_ts, co.c_eps, co.sigma, zb, stream)
+                    call += 1
+                    za, zb = zb, za
+                    if (s * return_frames) % timesteps == 0 and return_frames > 1:
+                        out_samples[(s * return_frames) // timesteps] = self._unnormalize_z([z.clone() for z in za])
+                fc = self.schedule.final()
+                eps_hat, _ = dyn(za, edge_index, t_table[0:1], conditions, n_frag_switch, combined_mask)
+                self._step_kernel(topo, 1, za, eps_hat, draw(call), None, fc.inv_alpha_0, fc.sigma_0, fc.sigma_x, zb, stream)
+                x = zb
+                self.last_x = x
+                self.last_status = dyn.last_status
+        finally:
+            dyn.nan_check = old_nan
+        nv, nb, pd = self.norm_values, self.norm_biases, self.pos_dim
+        pos = [x[k][:, :pd] * nv[0] + nb[0] for k in range(n_obj)]                              # :680-683
+        if self.pos_only:
+            cat = [h[:, :-1] for h in h0d]                                                      # :542-544
+            charge = [h[:, -1:] for h in h0d]
+        else:
+            cat = [torch.nn.functional.one_hot(torch.argmax(x[k][:, pd:-1] * nv[1] + nb[1], dim=1),
+                                               self.node_nfs[k] - 4).long() for k in range(n_obj)]
+            charge = [torch.round(x[k][:, -1:] * nv[2] + nb[2]).long() for k in range(n_obj)]
+        out_samples[0] = [torch.cat([pos[k], cat[k], charge[k]], dim=1) for k in range(n_obj)]  # :554-557
+        return out_samples, masks
+
+    def _unnormalize_z(self, z: List[Tensor]) -> List[Tensor]:
+        nv, nb, pd = self.norm_values, self.norm_biases, self.pos_dim
+        for k in range(len(z)):
+            z[k][:, :pd] = z[k][:, :pd] * nv[0] + nb[0]
+            z[k][:, pd:-1] = z[k][:, pd:-1] * nv[1] + nb[1]
+            z[k][:, -1:] = z[k][:, -1:] * nv[2] + nb[2]
+        return z

@@ -1,0 +1,106 @@
+"""Sampling loop (row N1): the oracle restatement against the reference's own
+EnVariationalDiffusion.sample (golden g4_*, replayed noise), the host schedule against the oracle's,
+and — on the GPU — the on-device sampler against a float64 replay of the same trajectory."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import leftnet_oracle as oracle
+import sampler_oracle as so
+from _cases import GOLDEN, rel
+from oareactdiff_amd.graph_tools import get_edges_index, get_mask_for_frag, get_n_frag_switch
+from oareactdiff_amd.schedule import Schedule
+from oareactdiff_amd.spec import state_spec, synthetic_state_dict
+
+CASES = ["g4_sampler_posonly", "g4_sampler_full"]
+
+
+class SCase:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.z = z
+        self.meta = json.loads(str(z["meta"]))
+        self.cfg, self.T, self.sizes, self.pos_only = (self.meta["model_config"], self.meta["T"], self.meta["sizes"],
+                                                       self.meta["pos_only"])
+        sd = synthetic_state_dict(state_spec(self.cfg, [9, 9, 9], 1), self.cfg, seed=42)
+        for k in list(sd):
+            if "out_pos" in k and "update_net.2" in k:
+                sd[k] = sd[k] * self.meta["head_scale"]
+        self.sd = sd
+        self.frag = [torch.tensor(self.sizes) for _ in range(3)]
+        self.masks = [get_mask_for_frag(f) for f in self.frag]
+        self.cm = torch.cat(self.masks)
+        self.ei = get_edges_index(self.cm, remove_self_edge=True)
+        self.nfs = get_n_frag_switch(self.frag)
+        self.B = len(self.sizes)
+        self.cond = torch.zeros(self.B, 1)
+        self.h0 = [torch.from_numpy(z[f"h0_{k}"]) for k in range(3)] if self.pos_only else None
+        self.noise = lambda i: [torch.from_numpy(z[f"noise{i}_{k}"]) for k in range(3)]
+        self.table = torch.from_numpy(z["table"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_sampler_replays_reference_bitwise(name):
+    c = SCase(name)
+
+    def dyn(zt, t):
+        return oracle.dynamics_forward(c.sd, c.cfg, zt, c.ei, t, c.cond, c.nfs, c.cm, 1, nodeframe="literal",
+                                       direct_vel=False)
+
+    x = so.sample(dyn, c.table, c.T, c.masks, c.B, c.noise, c.cond, c.pos_only, c.h0)
+    for k in range(3):
+        assert torch.equal(x[k][:, :3], torch.from_numpy(c.z[f"ref_pos{k}"]))       # reference sampler output
+        assert torch.equal(x[k], torch.from_numpy(c.z[f"oracle_x{k}"]))
+
+
+def test_host_schedule_matches_oracle_and_fixture():
+    for name, T, prec in (("polynomial_2", 20, 1e-5), ("polynomial_2", 1000, 1e-5), ("cosine", 100, 1e-5)):
+        s = Schedule(name, T, prec)
+        assert torch.equal(s.gamma, so.gamma_table(name, T, prec))
+    c = SCase("g4_sampler_posonly")
+    assert torch.equal(Schedule("polynomial_2", c.T, c.meta["precision"]).gamma, c.table)
+    s = Schedule("polynomial_2", 1000, 1e-5)
+    co = s.step(499)
+    assert 0.9 < co.alpha_ts <= 1.0 and co.sigma > 0 and co.c_eps > 0
+    assert s.index(500, 1000) == 500 and s.index(3, 10) == 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_device_sampler_tracks_f64_replay(name):
+    from oareactdiff_amd import DiffusionSampler, EGNNDynamics
+    dev = torch.device("cuda:0")
+    c = SCase(name)
+    dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
+                       condition_nf=1, device=dev)
+    dyn.load_state_dict(c.sd, strict=True)
+    smp = DiffusionSampler(dyn, "polynomial_2", c.T, c.meta["precision"], pos_only=c.pos_only)
+    out, masks = smp.sample(c.B, c.frag, conditions=c.cond, h0=c.h0, noise_fn=c.noise)
+    assert int(smp.last_status[0].item()) == 0
+    # float64 replay of the same noise: float64 oracle dynamics (exact node frame), float64 sampler arithmetic
+    sd64 = {k: v.double() for k, v in c.sd.items()}
+
+    def dyn64(zt, t):
+        return oracle.dynamics_forward(sd64, c.cfg, zt, c.ei, t, c.cond.double(), c.nfs, c.cm, 1, nodeframe="exact")
+
+    torch.set_default_dtype(torch.float64)
+    try:
+        x64 = so.sample(dyn64, c.table.double(), c.T, c.masks, c.B, lambda i: [n.double() for n in c.noise(i)],
+                        c.cond.double(), c.pos_only, [h.double() for h in c.h0] if c.h0 else None)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    got = torch.cat([smp.last_x[k][:, :3].cpu().double().reshape(-1) for k in range(3)])
+    want = torch.cat([x64[k][:, :3].reshape(-1) for k in range(3)])
+    e = rel(got, want)
+    print(f"{name}: device sampler vs float64 replay, positions rel = {e:.2e} over {c.T + 1} network calls")
+    assert e <= 5e-5
+    if not c.pos_only:
+        goth = torch.cat([smp.last_x[k][:, 3:].cpu().double().reshape(-1) for k in range(3)])
+        wanth = torch.cat([x64[k][:, 3:].reshape(-1) for k in range(3)])
+        assert rel(goth, wanth) <= 5e-5
+    # returned structure as en_diffusion.py:554-560
+    assert len(out) == 1 and len(out[0]) == 3 and out[0][0].shape == (sum(c.sizes), 9)
+    assert all(torch.equal(m.cpu(), mm) for m, mm in zip(masks, c.masks))
