@@ -22,7 +22,8 @@ H, R, L = 196, 96, 6
 W = 3 * H + R
 # MACs per edge per layer executed by the two hot kernels, as the reference formulates them
 #  minus the node-only part of edge_mlp.0 that k_node_pre evaluates per node
-MAC_GCL_EDGE = W * H + H * H + H + H * W            # 306,740  (k_gcl_edge; reference form incl. 2H*H: 383,572)
+MAC_GCL_S1, MAC_GCL_S2, MAC_GCL_S3 = W * H, H * H + H, H * W   # stages of k_gcl_edge: W1c.ew | W2, gate | W3 (residual)
+MAC_GCL_EDGE = MAC_GCL_S1 + MAC_GCL_S2 + MAC_GCL_S3  # 306,740  (k_gcl_edge; reference form incl. 2H*H: 383,572)
 MAC_EQUI_EDGE = 3 * R * H + 3 * H * W + 9 * H * H    # 804,384  (k_equi_edge)
 PEAK_F32_MFMA = 157.3e12
 
@@ -168,16 +169,21 @@ def main():
         for f in ("gcl_edge", "equi_edge", "node", "init", "other"):
             ms, n = _capi.timing_get(f)
             fam[f] = {"avg_ms": ms / max(n, 1), "launches_per_step": n / 3, "ms_per_step": ms / 3}
-        flops = {"gcl_edge": 2.0 * MAC_GCL_EDGE * E, "equi_edge": 2.0 * MAC_EQUI_EDGE * A}
+        # algorithmic FLOPs per STEP of each hot kernel family (L launches of the Equi kernel; the GCL kernel runs
+        # once per layer on all edges, except that on inter-object edges the first layer has no S1 (constant
+        # initial state: exact structural shortcut) and the last layer no S3 (its result is never read)
+        flops = {"gcl_edge": 2.0 * (L * MAC_GCL_EDGE * E - (MAC_GCL_S1 + MAC_GCL_S3) * (E - A)),
+                 "equi_edge": 2.0 * L * MAC_EQUI_EDGE * A}
         dom = max(flops, key=lambda f: fam[f]["ms_per_step"])
-        ach = flops[dom] / (fam[dom]["avg_ms"] * 1e-3)
+        oth = [f for f in flops if f != dom][0]
+        ach = flops[dom] / (fam[dom]["ms_per_step"] * 1e-3)
         roof = {"bound": "mfma", "kernel": "k_" + dom, "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                 "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "traffic": pmc_traffic("k_" + dom, B, nf),
-                "algorithmic_flops_per_launch": flops[dom], "avg_launch_ms": fam[dom]["avg_ms"],
+                "algorithmic_flops_per_step": flops[dom], "launches_per_step": fam[dom]["launches_per_step"],
+                "kernel_ms_per_step": fam[dom]["ms_per_step"], "avg_launch_ms": fam[dom]["avg_ms"],
                 "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},
-                "other_kernel": {"kernel": "k_" + [f for f in flops if f != dom][0],
-                                 "achieved": flops[[f for f in flops if f != dom][0]] /
-                                 (fam[[f for f in flops if f != dom][0]]["avg_ms"] * 1e-3) / 1e12}}
+                "other_kernel": {"kernel": "k_" + oth, "achieved": flops[oth] / (fam[oth]["ms_per_step"] * 1e-3) / 1e12,
+                                 "algorithmic_flops_per_step": flops[oth], "kernel_ms_per_step": fam[oth]["ms_per_step"]}}
 
     # the real sampling loop (row N1): T_probe genuine ancestral steps (network + fused sampler kernel + RNG)
     sampler_leg = None

@@ -134,9 +134,15 @@ struct GclStream {
 // accumulators out of the AGPR half of the file: with the default bound hipcc (ROCm 7.2) put some S1
 // accumulators in AGPRs for the 4-wave variant and the result drifted to 6e-5 of the oracle (a missed
 // MFMA->v_accvgpr_read hazard is the suspect); with the bound every variant is at 2.5e-7.
-template <class D, int NB, int WAVES, int GP, int PRIO>
+// DO_S1 = false: the columns are inter-object edges of layer 0, whose state is the constant row: stage S1
+//   collapses to the precomputed vector u0 (added to the accumulator init) and its DMA is skipped.
+// DO_S3 = false: the columns are inter-object edges of the last layer, whose updated state nobody reads
+//   (EquiMessage only touches inner edges): the residual stage and its edge-state traffic are skipped.
+// Columns are the physical rows [r0, r1).
+template <class D, int NB, int WAVES, int GP, int PRIO, bool DO_S1, bool DO_S3>
 __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                             const float* __restrict__ P, const float* __restrict__ Q,
+                                                            const float* __restrict__ u0, long long r0, long long r1,
                                                             float* __restrict__ ew, float* __restrict__ mbuf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = GclStream<D, GP>;
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(Top
         int start = 0, n = 0;
         if (p < S::NP1) { start = p * GP * G1; n = min(GP, WB - p * GP) * G1; }
         else if (p < S::NP1 + S::NP2) { const int q = p - S::NP1; start = S::C1 + q * GP * G2; n = min(GP, S::NG2 - q * GP) * G2; }
-        else if (p < S::NPH) { const int q = p - S::NP1 - S::NP2; start = S::C1 + S::C2 + q * GP * G2; n = min(GP, WB - q * GP) * G2; }
+        else if (p < S::NPH && DO_S3) { const int q = p - S::NP1 - S::NP2; start = S::C1 + S::C2 + q * GP * G2; n = min(GP, WB - q * GP) * G2; }
         pf_src = stream + (size_t)start * 256 + lane * 4;
         pf_dst = smem + (size_t)(p & 1) * S::SLAB * 256;
         pf_n = n; pf_k = 0; pf_next = 1 + (wave >= WAVES / 2 ? 1 : 0);
@@ -205,29 +211,32 @@ __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(Top
 
     // columns of this wave; padding columns work on the spare row E of ew / mbuf (allocated for that
     // purpose), so the kernel has no validity branches and every wave stays in the barrier protocol
-    const long long colbase = ((long long)blockIdx.x * WAVES + wave) * (NB * 16) + (lane & 15);
+    const long long colbase = r0 + ((long long)blockIdx.x * WAVES + wave) * (NB * 16) + (lane & 15);
     size_t e[NB];
     float* erow[NB];
     f4 h1[NB][HT];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const long long c = colbase + nb * 16;
-        e[nb] = (size_t)(c < tp.E ? c : tp.E);
+        e[nb] = (size_t)(c < r1 ? c : tp.E);
         erow[nb] = ew + e[nb] * D::WP + 4 * g;
-        const int src = tp.edge_src[e[nb]], tgt = tp.edge_tgt[e[nb]];
+        const int src = tp.row_src[e[nb]], tgt = tp.row_tgt[e[nb]];
 #pragma unroll
-        for (int t = 0; t < HT; ++t) h1[nb][t] = ld_blk(P, src, D::HP, t, lane) + ld_blk(Q, tgt, D::HP, t, lane);
+        for (int t = 0; t < HT; ++t) {
+            h1[nb][t] = ld_blk(P, src, D::HP, t, lane) + ld_blk(Q, tgt, D::HP, t, lane);
+            if (!DO_S1) h1[nb][t] += ld_vec(u0, t, lane);
+        }
     }
     f4 xn[GP][NB];
 #pragma unroll
     for (int gg = 0; gg < GP; ++gg)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) xn[gg][nb] = gg < WB ? ld_f4(erow[nb] + 16 * gg) : f4zero();
-    issue(0);
+        for (int nb = 0; nb < NB; ++nb) xn[gg][nb] = (DO_S1 && gg < WB) ? ld_f4(erow[nb] + 16 * gg) : f4zero();
+    int p = DO_S1 ? 0 : S::NP1;
+    issue(p);
 
-    int p = 0;
     // ---- S1: h1 += W1c . ew   (K-outer) -------------------------------------------------------------
-    for (int p1 = 0; p1 < S::NP1; ++p1, ++p) {
+    for (int p1 = 0; DO_S1 && p1 < S::NP1; ++p1, ++p) {
         phase_barrier();
         f4 x[GP][NB];
 #pragma unroll
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(Top
     for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
         phase_barrier();
         pf_start(p + 1);
-        if (p2 == S::NP2 - 1) {                     // prefetch the old edge-state tiles of S3's first phase
+        if (DO_S3 && p2 == S::NP2 - 1) {            // prefetch the old edge-state tiles of S3's first phase
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg)
 #pragma unroll
@@ -326,6 +335,13 @@ __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(Top
     // ---- S3: ew += SiLU(W3 m + b3), one output tile per group ----------------------------------------
     // stores are issued one phase late (right after the next barrier) so that the barrier's vmcnt(0)
     // never waits for a store that was issued a few cycles earlier
+    if (!DO_S3) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e[nb]], D::HP, t, lane, m[nb][t]);
+        return;
+    }
     f4 pend[GP][NB];
     for (int p3 = 0; p3 < S::NP3; ++p3, ++p) {
         phase_barrier();
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(Top
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int t = 0; t < HT; ++t) st_blk(mbuf, e[nb], D::HP, t, lane, m[nb][t]);
+                for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e[nb]], D::HP, t, lane, m[nb][t]);
         } else {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg)
@@ -468,7 +484,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
 
     const long long c = ((long long)blockIdx.x * WAVES + wave) * 16 + (lane & 15);
     const size_t a = (size_t)(c < tp.A ? c : tp.A);           // padding columns use the spare entry A
-    const float* erow = ew + (size_t)tp.act_edge[a] * D::WP + 4 * g;
+    const float* erow = ew + (c < tp.A ? a : (size_t)tp.E) * D::WP + 4 * g;     // inner entry a == physical row a
     f4 d1[D1T];
 #pragma unroll
     for (int t = 0; t < D1T; ++t) d1[t] = ld_vec(dp0b, t, lane);

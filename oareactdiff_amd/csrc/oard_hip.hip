@@ -49,6 +49,7 @@ struct Timing {
 int g_stop_after = 0;
 int g_gcl_variant = 3;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
 int g_equi_variant = 2;
+int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
 int g_overlap = 0;         // run the GCL node stage on a side stream underneath the Equi edge kernel
 hipStream_t g_side = nullptr;
@@ -117,6 +118,7 @@ PackOff make_layout(const oard_config* c) {
     po.un0 = mat(d.HT, 2 * d.HT); po.un0_b = take(d.HP);
     po.un2 = mat(1, d.HT); po.un2_b = take(16);
     po.c0row = take(d.WP);
+    po.u0 = take(d.HP);
     po.rbf_means = take(d.RP); po.rbf_betas = take(d.RP);
     for (int k = 0; k < c->n_obj; ++k) {
         const int dd = c->node_nf[k] - 3;
@@ -233,21 +235,32 @@ int set_lds(K kernel, size_t bytes) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), lds, stream, __VA_ARGS__); } while (0)
 
 #define GCL_CASE(id, NB_, WV_, GP_, PR_) case id: { \
-        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB_, WV_, GP_, PR_>), cdiv(tp.E, NB_ * 16 * WV_), WV_ * 64, \
-                   (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, P, Q, ew, mbuf); return OARD_OK; }
-template <class D>
-int launch_gcl_v1(int variant, const TopoDev& tp, const float* stream, const float* P, const float* Q, float* ew,
-                  float* mbuf, hipStream_t st) {
+        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB_, WV_, GP_, PR_, S1, S3>), cdiv(r1 - r0, NB_ * 16 * WV_), WV_ * 64, \
+                   (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, P, Q, u0, r0, r1, ew, mbuf); return OARD_OK; }
+template <class D, bool S1, bool S3>
+int launch_gcl_v1s(int variant, const TopoDev& tp, const float* stream, const float* P, const float* Q, const float* u0,
+                   long long r0, long long r1, float* ew, float* mbuf, hipStream_t st) {
+    if (r1 <= r0) return OARD_OK;
     switch (variant) {
         GCL_CASE(1, 2, 4, 2, 0)      // 4 waves x 32 edges, one wave per SIMD
         GCL_CASE(2, 1, 8, 2, 0)      // 8 waves x 16 edges, two waves per SIMD
         GCL_CASE(3, 1, 4, 2, 0)      // 4 waves x 16 edges (two workgroups per CU)
         GCL_CASE(4, 1, 8, 2, 1)      // as 2, static priority for waves 4-7
-        GCL_CASE(5, 1, 8, 4, 1)      // as 4, four groups per phase
-        GCL_CASE(6, 3, 4, 2, 0)      // 4 waves x 48 edges, one wave per SIMD
-        GCL_CASE(7, 4, 4, 2, 0)      // 4 waves x 64 edges, one wave per SIMD
         default: return OARD_EINVAL;
     }
+}
+// one GCL edge pass of layer l: inner edges always run every stage; inter-object edges skip S1 in the first
+// layer (constant initial state) and S3 in the last (their updated state is never read)
+template <class D>
+int launch_gcl_v1(int variant, const TopoDev& tp, const float* stream, const float* P, const float* Q, const float* u0,
+                  bool first, bool last, float* ew, float* mbuf, hipStream_t st) {
+    const long long A = tp.A, E = tp.E;
+    if (!g_gcl_skip || (!first && !last)) return launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, 0, E, ew, mbuf, st);
+    int rc = launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, 0, A, ew, mbuf, st);
+    if (rc != OARD_OK) return rc;
+    if (first && last) return launch_gcl_v1s<D, false, false>(variant, tp, stream, P, Q, u0, A, E, ew, mbuf, st);
+    if (first) return launch_gcl_v1s<D, false, true>(variant, tp, stream, P, Q, u0, A, E, ew, mbuf, st);
+    return launch_gcl_v1s<D, true, false>(variant, tp, stream, P, Q, u0, A, E, ew, mbuf, st);
 }
 #define EQUI_CASE(id, WV_, PR_) case id: { \
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV_, PR_>), cdiv(tp.A, 16 * WV_), WV_ * 64, (EquiStream<D>::LDS_BYTES), st, \
@@ -295,8 +308,8 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
     LAUNCH(F_OTHER, k_prep, cdiv(N, 128), 128, st, tp, op, wb, pos, hin, t, t_scalar, cond,
            c->condition_nf > 0 ? c->condition_nf : 0, c->condition_time, emb);
     LAUNCH(F_INIT, k_geom, tp.n_groups, 64, st, tp, (const float*)pos, cutoff, pf64, pf32, x1, pp0, labels);
-    LAUNCH(F_INIT, k_fill_edges, std::min<long long>(cdiv((E + 1) * (D::WP / 4), 256), 8192), 256, st,
-           wb + po.c0row, ew, E + 1, D::WP);
+    LAUNCH(F_INIT, k_fill_edges, std::min<long long>(cdiv((E - A + 1) * (D::WP / 4), 256), 8192), 256, st,
+           wb + po.c0row, ew + (size_t)A * D::WP, E - A + 1, D::WP);      // inter-object rows + the spare row
     if (A > 0) {
         LAUNCH(F_INIT, k_edge_geo, cdiv(A, 256), 256, st, tp, (const float*)pos, (const double*)pf64, cutoff, geo, d64);
         LAUNCH(F_INIT, k_rbf, cdiv(A * D::RP, 256), 256, st, tp, (const double*)d64, (const float*)geo,
@@ -323,7 +336,8 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
             if (g_gcl_variant == 0) {
                 LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew, mbuf);
             } else {
-                int rc = launch_gcl_v1<D>(g_gcl_variant, tp, wb + lo.gcl_stream, P, Q, ew, mbuf, st);
+                int rc = launch_gcl_v1<D>(g_gcl_variant, tp, wb + lo.gcl_stream, P, Q, wb + po.u0, l == 0,
+                                          l == c->num_layers - 1, ew, mbuf, st);
                 if (rc != OARD_OK) return rc;
             }
         }
@@ -487,6 +501,8 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
     hipLaunchKernelGGL(k_c0row, dim3((unsigned)cdiv(d.WP, 256)), dim3(256), 0, st, params[pi.lin30_b], params[pi.lin32_w],
                        params[pi.lin32_b], params[pi.rl0_b], params[pi.rl2_w], params[pi.rl2_b],
                        (float*)packed + po.c0row, H, d.H4, d.WP);
+    hipLaunchKernelGGL(k_u0, dim3((unsigned)cdiv(d.HP, 64)), dim3(64), 0, st, params[pi.gcl0 + 0],
+                       (const float*)packed + po.c0row, (float*)packed + po.u0, H, W, d.HP);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
@@ -567,6 +583,18 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
         }
         act_ptr[N] = (int)a;
     }
+    // physical rows: inner edges first (row a == inner entry a, target-sorted), then inter-object edges in
+    // logical order, then the spare row
+    std::vector<int> edge_row((size_t)std::max<long long>(E, 1), -1), row_src((size_t)E + 1, 0), row_tgt((size_t)E + 1, 0),
+        row_eid((size_t)E + 1, (int)E);
+    {
+        for (long long a = 0; a < A; ++a) {
+            edge_row[act_edge[a]] = (int)a; row_src[a] = act_src[a]; row_tgt[a] = act_tgt[a]; row_eid[a] = act_edge[a];
+        }
+        long long r = A;
+        for (long long e = 0; e < E; ++e)
+            if (edge_row[e] < 0) { edge_row[e] = (int)r; row_src[r] = edge_src[e]; row_tgt[r] = edge_tgt[e]; row_eid[r] = (int)e; ++r; }
+    }
     // reference-order edge offsets: prefix of (n_s - 1) over reference node order
     std::vector<long long> ref_ptr_ref(N), ref_edge_ptr(N);
     {
@@ -592,7 +620,9 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
                  o_esrc = add(edge_src.data(), edge_src.size() * 4), o_etgt = add(edge_tgt.data(), edge_tgt.size() * 4),
                  o_gptr = add(grp_ptr.data(), grp_ptr.size() * 4), o_aptr = add(act_ptr.data(), (N + 1) * 4),
                  o_asrc = add(act_src.data(), act_src.size() * 4), o_atgt = add(act_tgt.data(), act_tgt.size() * 4),
-                 o_aedge = add(act_edge.data(), act_edge.size() * 4), o_rptr = add(ref_edge_ptr.data(), N * 8);
+                 o_aedge = add(act_edge.data(), act_edge.size() * 4), o_rptr = add(ref_edge_ptr.data(), N * 8),
+                 o_erow = add(edge_row.data(), edge_row.size() * 4), o_rsrc = add(row_src.data(), row_src.size() * 4),
+                 o_rtgt = add(row_tgt.data(), row_tgt.size() * 4), o_reid = add(row_eid.data(), row_eid.size() * 4);
     char* dev = nullptr;
     HIP_TRY(hipMalloc((void**)&dev, cur));
     for (auto& it : items) {
@@ -609,6 +639,8 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
     d.grp_ptr = (const int*)(dev + o_gptr); d.act_ptr = (const int*)(dev + o_aptr); d.act_src = (const int*)(dev + o_asrc);
     d.act_tgt = (const int*)(dev + o_atgt); d.act_edge = (const int*)(dev + o_aedge);
     d.ref_edge_ptr = (const long long*)(dev + o_rptr);
+    d.edge_row = (const int*)(dev + o_erow); d.row_src = (const int*)(dev + o_rsrc); d.row_tgt = (const int*)(dev + o_rtgt);
+    d.row_eid = (const int*)(dev + o_reid);
     *out = tp;
     return OARD_OK;
 }
@@ -726,6 +758,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "equi_variant") == 0) { g_equi_variant = value; return OARD_OK; }
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
     if (strcmp(name, "overlap") == 0) { g_overlap = value; return OARD_OK; }
+    if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
     return OARD_EINVAL;
 }
 int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }

@@ -114,6 +114,20 @@ __global__ void k_c0row(const float* __restrict__ lin3w0b /*b0*/, const float* _
     c0[i] = v;
 }
 
+// u0 = W1c(layer 0) . c0row (+ nothing else): what stage S1 of the first GCL layer yields on every
+// inter-object edge, whose initial state is the constant row
+__global__ void k_u0(const float* __restrict__ w_edge_mlp0 /*[H][2H+W]*/, const float* __restrict__ c0,
+                     float* __restrict__ u0, int H, int W, int HP) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= HP) return;
+    float a = 0.f;
+    if (f < H) {
+        const float* w = w_edge_mlp0 + (size_t)f * (2 * H + W) + 2 * H;
+        for (int k = 0; k < W; ++k) a += w[k] * c0[k];
+    }
+    u0[f] = a;
+}
+
 // =====================================================================================================
 // topology check: is edge_index exactly get_edges_index(combined_mask, remove_self_edge=True)?
 // =====================================================================================================
@@ -348,14 +362,14 @@ __global__ void k_rbf(TopoDev tp, const double* __restrict__ d64, const float* _
         rb = d < cutoff ? rb : 0.0;
         const double q = exp(-d) - (double)means[k];
         v = (float)(rb * exp(-(double)betas[k] * q * q) * m);
-        ew[(size_t)tp.act_edge[a] * WP + 3 * H + k] = v;
+        ew[(size_t)a * WP + 3 * H + k] = v;
     }
     rbuf[i] = v;
 }
 
 // every edge starts as the masked-edge constant row; inner edges are then overwritten
 __global__ void k_fill_edges(const float* __restrict__ c0, float* __restrict__ ew, long long E, int WP) {
-    const int per = WP / 4;
+    const int per = WP / 4;                    // E = number of rows to fill starting at `ew`
     const long long total = E * per;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
         st_f4(ew + i * 4, ld_f4(c0 + (i % per) * 4));
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(256) void k_radial_lin(TopoDev tp, const float* __r
     f4 h1[D::HT];
     dense_regs<D::RB, D::HT, true, true>(wb + po.rl0, wb + po.rl0_b, rb, h1, id.lane);
     const float env = geo[id.c * GEO_STRIDE + 1];
-    const size_t row = (size_t)tp.act_edge[id.c] * D::WP + 2 * D::H;
+    const size_t row = (size_t)id.c * D::WP + 2 * D::H;
 #pragma unroll
     for (int t = 0; t < D::HT; ++t) {
         f4 f = dense_tile<D::HT>(wb + po.rl2, t, h1, id.lane, ld_vec(wb + po.rl2_b, t, id.lane));
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(256) void k_neighbor(TopoDev tp, const float* __res
     for (int k = 0; k < mx; ++k) {
         const int m = s0 + k;
         if (k < ns && m != n) {
-            const size_t row = ((size_t)tp.edge_ptr[m] + (n - s0) - (n > m ? 1 : 0)) * D::WP + 2 * D::H;
+            const size_t row = (size_t)tp.edge_row[tp.edge_ptr[m] + (n - s0) - (n > m ? 1 : 0)] * D::WP + 2 * D::H;
 #pragma unroll
             for (int t = 0; t < D::HT; ++t)
                 if (16 * t + 4 * id.g < D::H)
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(256) void k_s2v_agg(TopoDev tp, const float* __rest
                 if (k < cnt) {
                     const int a = a0 + k, m = tp.act_src[a];
                     const float* g = geo + (size_t)a * GEO_STRIDE;
-                    const f4 p = ld_f4(ew + (size_t)tp.act_edge[a] * D::WP + 2 * D::H + 16 * t + 4 * id.g) *
+                    const f4 p = ld_f4(ew + (size_t)a * D::WP + 2 * D::H + 16 * t + 4 * id.g) *
                                  ld_blk(s1, m, D::HP, t, id.lane);
                     ax += p * g[2]; ay += p * g[3]; az += p * g[4];
                 }
@@ -487,7 +501,7 @@ __global__ __launch_bounds__(256) void k_scalarize(TopoDev tp, const float* __re
     const float* b0 = l3 + D::H4 * 3;
     const float* w2 = b0 + D::H4;
     const float b2 = w2[D::H4];
-    const size_t row = (size_t)tp.act_edge[a] * D::WP;
+    const size_t row = (size_t)a * D::WP;
     for (int t = 0; t < D::HT; ++t) {
         if (16 * t + 4 * id.g >= D::H) continue;
 #pragma unroll
@@ -728,8 +742,8 @@ __global__ __launch_bounds__(256) void k_gcl_edge(TopoDev tp, const float* __res
                                                   float* __restrict__ ew, float* __restrict__ mbuf) {
     bool live; const ColId id = col_id(tp.E, live);
     if (!live) return;
-    const size_t e = (size_t)id.c;
-    const int src = tp.edge_src[e], tgt = tp.edge_tgt[e];
+    const size_t e = (size_t)id.c;                      // physical row
+    const int src = tp.row_src[e], tgt = tp.row_tgt[e];
     float* erow = ew + e * D::WP + 4 * id.g;
 
     // stage 1: K-outer over the edge state
@@ -760,7 +774,7 @@ __global__ __launch_bounds__(256) void k_gcl_edge(TopoDev tp, const float* __res
 #pragma unroll
     for (int t = 0; t < D::HT; ++t) {
         m[t] *= gate;
-        if (id.valid) st_blk(mbuf, e, D::HP, t, id.lane, m[t]);
+        if (id.valid) st_blk(mbuf, (size_t)tp.row_eid[e], D::HP, t, id.lane, m[t]);
     }
 
     // stage 3: edge-state residual, one output tile at a time
@@ -784,7 +798,7 @@ __global__ __launch_bounds__(256) void k_equi_edge(TopoDev tp, const float* __re
     if (!live) return;
     const size_t a = (size_t)id.c;
     const int src = tp.act_src[a], tgt = tp.act_tgt[a];
-    const float* erow = ew + (size_t)tp.act_edge[a] * D::WP + 4 * id.g;
+    const float* erow = ew + a * D::WP + 4 * id.g;
     const float* g = geo + a * GEO_STRIDE;
     const float ux = g[2], uy = g[3], uz = g[4];
     const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt_h = 1.0f / sqrtf((float)D::H);
@@ -902,5 +916,5 @@ __global__ void k_tap_edges(TopoDev tp, const float* __restrict__ ew, int WP, in
     const int c = (int)(i % W);
     const int s = tp.edge_src[e];
     const long long rp = tp.ref_edge_ptr[s] + (e - tp.edge_ptr[s]);
-    dst[(size_t)rp * W + c] = ew[(size_t)e * WP + c];
+    dst[(size_t)rp * W + c] = ew[(size_t)tp.edge_row[e] * WP + c];
 }

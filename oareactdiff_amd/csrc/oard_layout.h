@@ -48,6 +48,7 @@ struct PackOff {
     size_t pe0;       // raw [H2*3]
     size_t pe1, embout, embout_b, v1p, v2p, un0, un0_b, un2, un2_b;
     size_t c0row;     // [WP] constant state of a masked edge
+    size_t u0;        // [HP] W1c(layer 0) . c0row: stage S1 of layer 0 on inter-object edges
     size_t rbf_means, rbf_betas;  // [RP]
     size_t enc[OARD_MAX_OBJECTS], dec[OARD_MAX_OBJECTS];  // raw MLP blocks
     LayerOff layer[OARD_MAX_LAYERS];
@@ -59,7 +60,13 @@ struct TopoDev {
     int N, B, n_obj, n_groups;
     long long E, A;
     const int *node_obj, *node_row, *node_ref, *node_tidx, *node_sample, *sample_ptr;
-    const int *edge_ptr, *edge_src, *edge_tgt;
+    const int *edge_ptr, *edge_src, *edge_tgt;   // implicit ("logical") edge ids: node n owns ids edge_ptr[n] + rank
+    // physical rows of the edge-state / message buffers: inner (same-object) edges first, in the
+    // target-sorted order of the act_* list (row a == inner entry a), then the inter-object edges in
+    // logical order, then one spare row (index E) for padding columns
+    const int *edge_row;                         // [E]   logical id -> physical row
+    const int *row_src, *row_tgt;                // [E+1] physical row -> nodes
+    const int *row_eid;                          // [E+1] physical row -> logical id (the message buffer m is kept in logical order)
     const int *grp_ptr;                       // [n_groups+1], group q = sample*n_obj + obj
     const int *act_ptr, *act_src, *act_tgt, *act_edge;
     const long long *ref_edge_ptr;            // [N] first reference-order edge of internal node n

