@@ -142,7 +142,8 @@ struct GclStream {
 template <class D, int NB, int WAVES, int GP, int PRIO, bool DO_S1, bool DO_S3>
 __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                             const float* __restrict__ P, const float* __restrict__ Q,
-                                                            const float* __restrict__ u0, long long r0, long long r1,
+                                                            const float* __restrict__ u0, const float* __restrict__ c0,
+                                                            long long r0, long long r1,
                                                             float* __restrict__ ew, float* __restrict__ mbuf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = GclStream<D, GP>;
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(Top
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) on[gg][nb] = gg < WB ? ld_f4(erow[nb] + 16 * gg) : f4zero();
+                for (int nb = 0; nb < NB; ++nb)
+                    on[gg][nb] = gg < WB ? (DO_S1 ? ld_f4(erow[nb] + 16 * gg) : ld_f4(c0 + 16 * gg + 4 * g)) : f4zero();
         }
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
@@ -368,7 +370,8 @@ __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(Top
                 const int t = (p3 + 1) * GP + gg;
                 if (t < WB)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) on[gg][nb] = ld_f4(erow[nb] + 16 * t);
+                    for (int nb = 0; nb < NB; ++nb)      // !DO_S1: the old state of these rows IS the constant row (never materialised)
+                        on[gg][nb] = DO_S1 ? ld_f4(erow[nb] + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
             }
         }
 #pragma unroll

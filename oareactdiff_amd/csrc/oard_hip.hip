@@ -236,10 +236,10 @@ int set_lds(K kernel, size_t bytes) {
 
 #define GCL_CASE(id, NB_, WV_, GP_, PR_) case id: { \
         LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB_, WV_, GP_, PR_, S1, S3>), cdiv(r1 - r0, NB_ * 16 * WV_), WV_ * 64, \
-                   (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, P, Q, u0, r0, r1, ew, mbuf); return OARD_OK; }
+                   (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew, mbuf); return OARD_OK; }
 template <class D, bool S1, bool S3>
 int launch_gcl_v1s(int variant, const TopoDev& tp, const float* stream, const float* P, const float* Q, const float* u0,
-                   long long r0, long long r1, float* ew, float* mbuf, hipStream_t st) {
+                   const float* c0, long long r0, long long r1, float* ew, float* mbuf, hipStream_t st) {
     if (r1 <= r0) return OARD_OK;
     switch (variant) {
         GCL_CASE(1, 2, 4, 2, 0)      // 4 waves x 32 edges, one wave per SIMD
@@ -253,14 +253,14 @@ int launch_gcl_v1s(int variant, const TopoDev& tp, const float* stream, const fl
 // layer (constant initial state) and S3 in the last (their updated state is never read)
 template <class D>
 int launch_gcl_v1(int variant, const TopoDev& tp, const float* stream, const float* P, const float* Q, const float* u0,
-                  bool first, bool last, float* ew, float* mbuf, hipStream_t st) {
+                  const float* c0, bool first, bool last, float* ew, float* mbuf, hipStream_t st) {
     const long long A = tp.A, E = tp.E;
-    if (!g_gcl_skip || (!first && !last)) return launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, 0, E, ew, mbuf, st);
-    int rc = launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, 0, A, ew, mbuf, st);
+    if (!g_gcl_skip || (!first && !last)) return launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, c0, 0, E, ew, mbuf, st);
+    int rc = launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, c0, 0, A, ew, mbuf, st);
     if (rc != OARD_OK) return rc;
-    if (first && last) return launch_gcl_v1s<D, false, false>(variant, tp, stream, P, Q, u0, A, E, ew, mbuf, st);
-    if (first) return launch_gcl_v1s<D, false, true>(variant, tp, stream, P, Q, u0, A, E, ew, mbuf, st);
-    return launch_gcl_v1s<D, true, false>(variant, tp, stream, P, Q, u0, A, E, ew, mbuf, st);
+    if (first && last) return launch_gcl_v1s<D, false, false>(variant, tp, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
+    if (first) return launch_gcl_v1s<D, false, true>(variant, tp, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
+    return launch_gcl_v1s<D, true, false>(variant, tp, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
 }
 #define EQUI_CASE(id, WV_, PR_) case id: { \
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV_, PR_>), cdiv(tp.A, 16 * WV_), WV_ * 64, (EquiStream<D>::LDS_BYTES), st, \
@@ -308,8 +308,11 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
     LAUNCH(F_OTHER, k_prep, cdiv(N, 128), 128, st, tp, op, wb, pos, hin, t, t_scalar, cond,
            c->condition_nf > 0 ? c->condition_nf : 0, c->condition_time, emb);
     LAUNCH(F_INIT, k_geom, tp.n_groups, 64, st, tp, (const float*)pos, cutoff, pf64, pf32, x1, pp0, labels);
-    LAUNCH(F_INIT, k_fill_edges, std::min<long long>(cdiv((E - A + 1) * (D::WP / 4), 256), 8192), 256, st,
-           wb + po.c0row, ew + (size_t)A * D::WP, E - A + 1, D::WP);      // inter-object rows + the spare row
+    // inter-object rows start as the constant row; with the layer-0 shortcut nobody reads them before layer 0
+    // writes them, so they are only materialised for the unspecialised paths and for the debug tap
+    if (!(g_gcl_skip && g_gcl_variant != 0) || g_stop_after == 1)
+        LAUNCH(F_INIT, k_fill_edges, std::min<long long>(cdiv((E - A + 1) * (D::WP / 4), 256), 8192), 256, st,
+               wb + po.c0row, ew + (size_t)A * D::WP, E - A + 1, D::WP);
     if (A > 0) {
         LAUNCH(F_INIT, k_edge_geo, cdiv(A, 256), 256, st, tp, (const float*)pos, (const double*)pf64, cutoff, geo, d64);
         LAUNCH(F_INIT, k_rbf, cdiv(A * D::RP, 256), 256, st, tp, (const double*)d64, (const float*)geo,
@@ -336,7 +339,7 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
             if (g_gcl_variant == 0) {
                 LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew, mbuf);
             } else {
-                int rc = launch_gcl_v1<D>(g_gcl_variant, tp, wb + lo.gcl_stream, P, Q, wb + po.u0, l == 0,
+                int rc = launch_gcl_v1<D>(g_gcl_variant, tp, wb + lo.gcl_stream, P, Q, wb + po.u0, wb + po.c0row, l == 0,
                                           l == c->num_layers - 1, ew, mbuf, st);
                 if (rc != OARD_OK) return rc;
             }

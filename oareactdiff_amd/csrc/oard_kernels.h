@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256) void k_neighbor(TopoDev tp, const float* __res
                                                   const float* __restrict__ zemb, const float* __restrict__ nb,
                                                   const float* __restrict__ ew, float* __restrict__ s,
                                                   float* __restrict__ s1) {
+    // inter-object rows (>= A) are not materialised at this point: their state is the constant row c0row
     bool live; const ColId id = col_id(tp.N, live);
     if (!live) return;
     const int n = id.col, smp = tp.node_sample[n], s0 = tp.sample_ptr[smp], ns = tp.sample_ptr[smp + 1] - s0;
@@ -436,11 +437,12 @@ __global__ __launch_bounds__(256) void k_neighbor(TopoDev tp, const float* __res
     for (int k = 0; k < mx; ++k) {
         const int m = s0 + k;
         if (k < ns && m != n) {
-            const size_t row = (size_t)tp.edge_row[tp.edge_ptr[m] + (n - s0) - (n > m ? 1 : 0)] * D::WP + 2 * D::H;
+            const int r = tp.edge_row[tp.edge_ptr[m] + (n - s0) - (n > m ? 1 : 0)];
+            const float* frow = (r < tp.A ? ew + (size_t)r * D::WP : wb + po.c0row) + 2 * D::H;
 #pragma unroll
             for (int t = 0; t < D::HT; ++t)
                 if (16 * t + 4 * id.g < D::H)
-                    acc[t] += ld_f4(ew + row + 16 * t + 4 * id.g) * ld_blk(nb, m, D::HP, t, id.lane);
+                    acc[t] += ld_f4(frow + 16 * t + 4 * id.g) * ld_blk(nb, m, D::HP, t, id.lane);
         }
     }
     if (id.valid)

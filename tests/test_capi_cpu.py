@@ -95,3 +95,24 @@ def test_no_cpu_fallback_and_config_errors():
     with pytest.raises(NotImplementedError):
         EGNNDynamics(model_config=dict(c.cfg, reflect_equiv=False), fragment_names=["a", "b", "c"],
                      node_nfs=c.node_nfs, edge_nf=0, condition_nf=c.cnf, device=torch.device("cpu"))
+
+
+def test_checkpoint_adapter_round_trip():
+    """A Lightning-style checkpoint dict (prefix `ddpm.dynamics.`, hyper_parameters as pl_trainer.py:147 saves them)
+    loads with strict=True; unrelated entries (EMA, optimiser state) are ignored."""
+    from oareactdiff_amd.checkpoint import dynamics_from_checkpoint, extract_dynamics_state
+    c = Case("g3_cutoff_ragged")
+    sd = c.state_dict()
+    ckpt = {
+        "state_dict": {**{"ddpm.dynamics." + k: v for k, v in sd.items()},
+                       "ddpm.schedule.gamma_module.gamma": torch.zeros(11), "some.other.module.weight": torch.ones(2)},
+        "hyper_parameters": dict(model_config=dict(c.cfg), node_nfs=c.node_nfs, edge_nf=0, condition_nf=c.cnf,
+                                 fragment_names=["R", "TS", "P"], pos_dim=3, update_pocket_coords=True,
+                                 condition_time=True, edge_cutoff=None, enforce_same_encoding=None),
+    }
+    dyn, hp = dynamics_from_checkpoint(ckpt, device=torch.device("cpu"))
+    got = dyn.state_dict()
+    assert list(got.keys()) == list(sd.keys()) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert set(extract_dynamics_state({"dynamics." + k: v for k, v in sd.items()})) == set(sd)
+    with pytest.raises(KeyError):
+        extract_dynamics_state({"foo.bar": torch.zeros(1)})
