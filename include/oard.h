@@ -110,6 +110,8 @@ int oard_forward(const oard_config* cfg, const oard_topology* topo, const void* 
  *   mode 0:  out = z / a - eps_hat * b + c * eps ;  out_pos -= mean_group(out_pos)     (a = alpha_t|s, b, c = sigma)
  *   mode 1:  out = a * (z - b * eps_hat) + c * eps                                     (a = 1/alpha_0, b = sigma_0, c = sigma_x)
  *   mode 2:  out = eps                                                                 (initial z_T)
+ *   mode 3:  out = a * z + c * eps                      (q(z_s | x): noised_representation, :269-287; a = alpha_s, c = sigma_s)
+ *   mode 4:  out = a * z + c * eps ;  out_pos -= mean_group(out_pos)   (sample_p_zt_given_zs, :1050-1074; a = alpha_t|s, c = sigma_t|s)
  *   h0_dev[k] != NULL: the feature columns of out are overwritten by h0 (pos_only sampling, :526-530).
  * group = nodes of one object in one sample.  The scalars are host values (the schedule is a host table),
  * so a sampling loop built on this and oard_forward never synchronises. */

@@ -702,14 +702,15 @@ int oard_forward(const oard_config* c, const oard_topology* topo, const void* pa
 int oard_sampler_step(const oard_config* c, const oard_topology* topo, int mode, const float* const* z,
                       const float* const* eh, const float* const* noise, const float* const* h0, float a, float b,
                       float cc, int zero_feature_noise, float* const* out, oard_stream_t stream) {
-    if (!config_ok(c) || !topo || !noise || !out || mode < 0 || mode > 2) return OARD_EINVAL;
-    if (mode != 2 && (!z || !eh)) return OARD_EINVAL;
+    if (!config_ok(c) || !topo || !noise || !out || mode < 0 || mode > 4) return OARD_EINVAL;
+    if (mode != 2 && !z) return OARD_EINVAL;
+    if (mode <= 1 && !eh) return OARD_EINVAL;
     if (c->n_obj != topo->d.n_obj) return OARD_EINVAL;
     SamplerPtrs sp;
     memset(&sp, 0, sizeof(sp));
     for (int k = 0; k < c->n_obj; ++k) {
         sp.z[k] = mode == 2 ? noise[k] : z[k];
-        sp.eh[k] = mode == 2 ? noise[k] : eh[k];
+        sp.eh[k] = (mode == 2 || !eh) ? noise[k] : eh[k];
         sp.noise[k] = noise[k];
         sp.h0[k] = h0 ? h0[k] : nullptr;
         sp.out[k] = out[k];

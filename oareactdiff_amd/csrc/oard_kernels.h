@@ -241,10 +241,11 @@ __global__ void k_sampler_step(TopoDev tp, SamplerPtrs sp, int mode, float a, fl
     auto upd = [&](float z, float e, float eps) -> float {
         if (mode == 0) return z / a - e * b + c * eps;
         if (mode == 1) return a * (z - b * e) + c * eps;
+        if (mode >= 3) return a * z + c * eps;
         return eps;
     };
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if (mode == 0) {
+    if (mode == 0 || mode == 4) {
         for (int k = g0; k < g1; ++k) {
             const size_t o = (size_t)tp.node_row[k] * nf;
             s0 += upd(Z[o], E[o], R[o] - m0); s1 += upd(Z[o + 1], E[o + 1], R[o + 1] - m1); s2 += upd(Z[o + 2], E[o + 2], R[o + 2] - m2);

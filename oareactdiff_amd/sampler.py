@@ -17,7 +17,7 @@ from torch import Tensor
 from . import _capi
 from .dynamics import EGNNDynamics
 from .graph_tools import get_edges_index, get_mask_for_frag, get_n_frag_switch
-from .schedule import Schedule
+from .schedule import Schedule, get_repaint_schedule
 
 
 class DiffusionSampler:
@@ -113,6 +113,100 @@ class DiffusionSampler:
                                                self.node_nfs[k] - 4).long() for k in range(n_obj)]
             charge = [torch.round(x[k][:, -1:] * nv[2] + nb[2]).long() for k in range(n_obj)]
         out_samples[0] = [torch.cat([pos[k], cat[k], charge[k]], dim=1) for k in range(n_obj)]  # :554-557
+        return out_samples, masks
+
+    @torch.no_grad()
+    def inpaint(self, n_samples: int, fragments_nodes: List[Tensor], conditions: Optional[Tensor] = None,
+                return_frames: int = 1, resamplings: int = 1, jump_length: int = 1, timesteps: Optional[int] = None,
+                xh_fixed: Optional[List[Tensor]] = None, frag_fixed: Optional[List[int]] = None,
+                noise_fn: Optional[Callable[[int], List[Tensor]]] = None) -> Tuple[list, List[Tensor]]:
+        """RePaint-style conditional generation, mirror of `EnVariationalDiffusion.inpaint`
+        (en_diffusion.py:722-883): objects in `frag_fixed` follow q(z_s | x_fixed), the others are denoised,
+        with `resamplings` x `jump_length` forward jumps.  Noise draws are consumed in the reference's order
+        (per step: known-branch noise, denoising noise, then the jump noise if any)."""
+        timesteps = self.T if timesteps is None else timesteps
+        assert 0 < return_frames <= timesteps and timesteps % return_frames == 0
+        assert xh_fixed is not None and len(xh_fixed)
+        frag_fixed = list(frag_fixed or [])
+        dyn = self.dynamics
+        dev = next(dyn.parameters()).device
+        if dev.type != "cuda":
+            raise _capi.OardError("DiffusionSampler needs the dynamics on a ROCm device (no CPU fallback)")
+        n_obj = len(self.node_nfs)
+        fragments_nodes = [f.to(dev) for f in fragments_nodes]
+        masks = [get_mask_for_frag(f) for f in fragments_nodes]
+        combined_mask = torch.cat(masks)
+        edge_index = get_edges_index(combined_mask, remove_self_edge=True)
+        n_frag_switch = get_n_frag_switch(fragments_nodes)
+        if conditions is None:
+            conditions = torch.zeros(n_samples, max(dyn.condition_nf, 1), device=dev)
+        conditions = conditions.to(dev)
+        pd = self.pos_dim
+        xf = [x.to(device=dev, dtype=torch.float32).clone() for x in xh_fixed]
+        h0 = [x[:, pd:].long().to(torch.float32).contiguous() for x in xf]                 # :753
+        for k in range(n_obj):                                                              # :755-759
+            xf[k][:, :pd] = EGNNDynamics.remove_mean_batch(xf[k][:, :pd], masks[k])
+        sizes = [int(m.numel()) for m in masks]
+        old_nan = dyn.nan_check
+        dyn.nan_check = "async"
+        try:
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                cfg = dyn._config()
+                topo = dyn._get_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+                counter = [0]
+
+                def draw():
+                    i = counter[0]
+                    counter[0] += 1
+                    if noise_fn is not None:
+                        return [x.to(device=dev, dtype=torch.float32).contiguous() for x in noise_fn(i)]
+                    return [torch.randn(sizes[k], self.node_nfs[k], device=dev) for k in range(n_obj)]
+
+                new = lambda: [torch.empty(sizes[k], self.node_nfs[k], device=dev) for k in range(n_obj)]
+                hsel = h0 if self.pos_only else None
+                zt = new()
+                self._step_kernel(topo, 2, None, None, draw(), hsel, 0.0, 0.0, 1.0, zt, stream)
+                t_table = torch.arange(timesteps + 1, device=dev, dtype=torch.float32) / timesteps
+                schedule = get_repaint_schedule(resamplings, jump_length, timesteps)
+                s = timesteps - 1
+                for i, n_denoise in enumerate(schedule):
+                    for j in range(n_denoise):
+                        a_s, sig_s = self.schedule.alpha_sigma(s, timesteps)
+                        known = new()
+                        self._step_kernel(topo, 3, xf, None, draw(), hsel, a_s, 0.0, sig_s, known, stream)   # :797-805
+                        co = self.schedule.step(s, timesteps)
+                        eps_hat, _ = dyn(zt, edge_index, t_table[s + 1: s + 2], conditions, n_frag_switch, combined_mask)
+                        unknown = new()
+                        self._step_kernel(topo, 0, zt, eps_hat, draw(), hsel, co.alpha_ts, co.c_eps, co.sigma, unknown, stream)
+                        zt = [known[k] if k in frag_fixed else unknown[k] for k in range(n_obj)]            # :827-830
+                        if j == n_denoise - 1 and i < len(schedule) - 1:                                   # :833-850
+                            t = s + jump_length
+                            a_ts, sig_ts = self.schedule.forward_jump(s, t, timesteps)
+                            jumped = new()
+                            self._step_kernel(topo, 4, zt, None, draw(), None, a_ts, 0.0, sig_ts, jumped, stream)
+                            zt = jumped
+                            s = t
+                        s -= 1
+                fc = self.schedule.final()
+                eps_hat, _ = dyn(zt, edge_index, t_table[0:1], conditions, n_frag_switch, combined_mask)
+                x = new()
+                self._step_kernel(topo, 1, zt, eps_hat, draw(), None, fc.inv_alpha_0, fc.sigma_0, fc.sigma_x, x, stream)
+                self.last_x = x
+                self.last_status = dyn.last_status
+        finally:
+            dyn.nan_check = old_nan
+        nv, nb = self.norm_values, self.norm_biases
+        pos = [x[k][:, :pd] * nv[0] + nb[0] for k in range(n_obj)]
+        if self.pos_only:
+            cat = [h[:, :-1].long() for h in h0]
+            charge = [h[:, -1:].long() for h in h0]
+        else:
+            cat = [torch.nn.functional.one_hot(torch.argmax(x[k][:, pd:-1] * nv[1] + nb[1], dim=1),
+                                               self.node_nfs[k] - 4).long() for k in range(n_obj)]
+            charge = [torch.round(x[k][:, -1:] * nv[2] + nb[2]).long() for k in range(n_obj)]
+        out_samples = [None] * return_frames
+        out_samples[0] = [torch.cat([pos[k], cat[k], charge[k]], dim=1) for k in range(n_obj)]
         return out_samples, masks
 
     def _unnormalize_z(self, z: List[Tensor]) -> List[Tensor]:

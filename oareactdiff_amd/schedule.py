@@ -88,3 +88,38 @@ class Schedule:
         g0 = self.gamma[0]
         return FinalCoefficients(float(1.0 / torch.sqrt(torch.sigmoid(-g0))), float(torch.sqrt(torch.sigmoid(g0))),
                                  float(torch.exp(0.5 * g0)))
+
+    def alpha_sigma(self, step: int, n_steps: int = None):
+        """(alpha, sigma) at time step/n_steps  (DiffSchedule.alpha / .sigma, _schedule.py:149-158)."""
+        n_steps = self.timesteps if n_steps is None else n_steps
+        g = self.gamma[self.index(step, n_steps)]
+        return float(torch.sqrt(torch.sigmoid(-g))), float(torch.sqrt(torch.sigmoid(g)))
+
+    def forward_jump(self, s: int, t: int, n_steps: int = None):
+        """(alpha_t|s, sigma_t|s) of the forward re-noising s -> t > s  (sample_p_zt_given_zs, en_diffusion.py:1050-1074)."""
+        n_steps = self.timesteps if n_steps is None else n_steps
+        g_s, g_t = self.gamma[self.index(s, n_steps)], self.gamma[self.index(t, n_steps)]
+        sigma2 = -torch.expm1(F.softplus(g_s) - F.softplus(g_t))
+        alpha = torch.exp(0.5 * (F.logsigmoid(-g_t) - F.logsigmoid(-g_s)))
+        return float(alpha), float(torch.sqrt(sigma2))
+
+
+def get_repaint_schedule(resamplings: int, jump_length: int, timesteps: int):
+    """Number of denoising steps before each jump back (_schedule.py:206-232)."""
+    out, cur = [], 0
+    while cur < timesteps:
+        if cur + jump_length < timesteps:
+            if out:
+                out[-1] += jump_length
+                out.extend([jump_length] * (resamplings - 1))
+            else:
+                out.extend([jump_length] * resamplings)
+            cur += jump_length
+        else:
+            residual = timesteps - cur
+            if out:
+                out[-1] += residual
+            else:
+                out.append(residual)
+            cur += residual
+    return list(reversed(out))

@@ -119,3 +119,87 @@ def sample(dynamics: Callable, table: Tensor, timesteps: int, masks: List[Tensor
     mu_x = [1.0 / alpha_0[masks[k]] * (zt[k] - sigma_0[masks[k]] * eps_hat[k]) for k in range(len(masks))]
     eps = combined_noise(noise(call), masks, pos_only, pos_dim)
     return [mu_x[k] + sigma_x[masks[k]] * eps[k] for k in range(len(masks))]
+
+
+def get_repaint_schedule(resamplings, jump_length, timesteps):            # _schedule.py:206-232
+    out, cur = [], 0
+    while cur < timesteps:
+        if cur + jump_length < timesteps:
+            if len(out) > 0:
+                out[-1] += jump_length
+                out.extend([jump_length] * (resamplings - 1))
+            else:
+                out.extend([jump_length] * resamplings)
+            cur += jump_length
+        else:
+            residual = timesteps - cur
+            if len(out) > 0:
+                out[-1] += residual
+            else:
+                out.append(residual)
+            cur += residual
+    return list(reversed(out))
+
+
+def inpaint(dynamics: Callable, table: Tensor, timesteps: int, masks: List[Tensor], n_samples: int,
+            noise: Callable[[int], List[Tensor]], conditions: Optional[Tensor], pos_only: bool,
+            xh_fixed: List[Tensor], frag_fixed: Sequence[int], resamplings: int, jump_length: int, pos_dim: int = 3):
+    """en_diffusion.py:722-883 with identity normaliser; `noise(i)` = i-th set of raw draws in call order."""
+    K = len(masks)
+    xf = [x.clone() for x in xh_fixed]
+    h0 = [x[:, pos_dim:].long() for x in xf]
+    for k in range(K):
+        xf[k][:, :pos_dim] = remove_mean_batch(xf[k][:, :pos_dim], masks[k])
+    cnt = [0]
+
+    def draw():
+        i = cnt[0]
+        cnt[0] += 1
+        return combined_noise(noise(i), masks, pos_only, pos_dim)
+
+    def with_h0(z):
+        return [torch.cat([z[k][:, :pos_dim], h0[k].to(z[k].dtype)], dim=1) for k in range(K)] if pos_only else z
+
+    zt = with_h0(draw())
+    s = timesteps - 1
+    sched = get_repaint_schedule(resamplings, jump_length, timesteps)
+    for i, nd in enumerate(sched):
+        for j in range(nd):
+            s_arr = torch.full((n_samples, 1), float(s)) / timesteps
+            t_arr = torch.full((n_samples, 1), float(s + 1)) / timesteps
+            g_s, g_t = gamma_at(table, s_arr, timesteps), gamma_at(table, t_arr, timesteps)
+            alpha_s, sigma_sv = torch.sqrt(torch.sigmoid(-g_s)), torch.sqrt(torch.sigmoid(g_s))
+            eps = draw()
+            known = [alpha_s[masks[k]] * xf[k] + sigma_sv[masks[k]] * eps[k] for k in range(K)]        # :269-287
+            sigma2_ts = -torch.expm1(F.softplus(g_s) - F.softplus(g_t))
+            alpha_ts = torch.exp(0.5 * (F.logsigmoid(-g_t) - F.logsigmoid(-g_s)))
+            sigma_ts = torch.sqrt(sigma2_ts)
+            sigma_t = torch.sqrt(torch.sigmoid(g_t))
+            eps_hat = dynamics(zt, t_arr)
+            mu = [zt[k] / alpha_ts[masks[k]] - eps_hat[k] * (sigma2_ts / alpha_ts / sigma_t)[masks[k]] for k in range(K)]
+            sigma = sigma_ts * sigma_sv / sigma_t
+            eps = draw()
+            unknown = [mu[k] + sigma[masks[k]] * eps[k] for k in range(K)]
+            unknown = [torch.cat([remove_mean_batch(u[:, :pos_dim], masks[k]), u[:, pos_dim:]], dim=1)
+                       for k, u in enumerate(unknown)]
+            known, unknown = with_h0(known), with_h0(unknown)
+            zt = [known[k] if k in frag_fixed else unknown[k] for k in range(K)]
+            if j == nd - 1 and i < len(sched) - 1:
+                t = s + jump_length
+                tj = torch.full((n_samples, 1), float(t)) / timesteps
+                g_tj = gamma_at(table, tj, timesteps)
+                sigma2 = -torch.expm1(F.softplus(g_s) - F.softplus(g_tj))
+                alpha = torch.exp(0.5 * (F.logsigmoid(-g_tj) - F.logsigmoid(-g_s)))
+                eps = draw()
+                zt = [alpha[masks[k]] * zt[k] + torch.sqrt(sigma2)[masks[k]] * eps[k] for k in range(K)]
+                zt = [torch.cat([remove_mean_batch(z[:, :pos_dim], masks[k]), z[:, pos_dim:]], dim=1) for k, z in enumerate(zt)]
+                s = t
+            s -= 1
+    t0 = torch.zeros(n_samples, 1)
+    g0 = gamma_at(table, t0, timesteps)
+    sigma_x = torch.exp(0.5 * g0)
+    eps_hat = dynamics(zt, t0)
+    sigma_0, alpha_0 = torch.sqrt(torch.sigmoid(g0)), torch.sqrt(torch.sigmoid(-g0))
+    mu_x = [1.0 / alpha_0[masks[k]] * (zt[k] - sigma_0[masks[k]] * eps_hat[k]) for k in range(K)]
+    eps = draw()
+    return [mu_x[k] + sigma_x[masks[k]] * eps[k] for k in range(K)]

@@ -37,7 +37,7 @@ class SCase:
         self.nfs = get_n_frag_switch(self.frag)
         self.B = len(self.sizes)
         self.cond = torch.zeros(self.B, 1)
-        self.h0 = [torch.from_numpy(z[f"h0_{k}"]) for k in range(3)] if self.pos_only else None
+        self.h0 = [torch.from_numpy(z[f"h0_{k}"]) for k in range(3)] if (self.pos_only and "h0_0" in z.files) else None
         self.noise = lambda i: [torch.from_numpy(z[f"noise{i}_{k}"]) for k in range(3)]
         self.table = torch.from_numpy(z["table"])
 
@@ -104,3 +104,61 @@ def test_device_sampler_tracks_f64_replay(name):
     # returned structure as en_diffusion.py:554-560
     assert len(out) == 1 and len(out[0]) == 3 and out[0][0].shape == (sum(c.sizes), 9)
     assert all(torch.equal(m.cpu(), mm) for m, mm in zip(masks, c.masks))
+
+
+class ICase(SCase):
+    def __init__(self, name="g5_inpaint"):
+        super().__init__(name)
+        self.xh_fixed = [torch.from_numpy(self.z[f"xh_fixed{k}"]) for k in range(3)]
+        self.frag_fixed = self.meta["frag_fixed"]
+        self.res, self.jump = self.meta["resamplings"], self.meta["jump_length"]
+
+
+def test_oracle_inpaint_replays_reference_bitwise():
+    from oareactdiff_amd.schedule import get_repaint_schedule
+    c = ICase()
+
+    def dyn(zt, t):
+        return oracle.dynamics_forward(c.sd, c.cfg, zt, c.ei, t, c.cond, c.nfs, c.cm, 1, nodeframe="literal",
+                                       direct_vel=False)
+
+    x = so.inpaint(dyn, c.table, c.T, c.masks, c.B, c.noise, c.cond, True, c.xh_fixed, c.frag_fixed, c.res, c.jump)
+    for k in range(3):
+        assert torch.equal(x[k][:, :3], torch.from_numpy(c.z[f"ref_pos{k}"]))       # reference inpaint output
+    assert get_repaint_schedule(c.res, c.jump, c.T) == so.get_repaint_schedule(c.res, c.jump, c.T)
+    # sum(out) - (len(out) - 1) * jump_length == timesteps   (_schedule.py:210)
+    for r, j, t in ((2, 3, 12), (5, 5, 150), (10, 10, 250), (1, 1, 7)):
+        sch = get_repaint_schedule(r, j, t)
+        n_jumps = len(sch) - 1
+        assert sum(sch) - n_jumps * j == t
+
+
+@pytest.mark.gpu
+def test_device_inpaint_tracks_f64_replay():
+    from oareactdiff_amd import DiffusionSampler, EGNNDynamics
+    dev = torch.device("cuda:0")
+    c = ICase()
+    dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
+                       condition_nf=1, device=dev)
+    dyn.load_state_dict(c.sd, strict=True)
+    smp = DiffusionSampler(dyn, "polynomial_2", c.T, c.meta["precision"], pos_only=True)
+    out, masks = smp.inpaint(c.B, c.frag, conditions=c.cond, resamplings=c.res, jump_length=c.jump,
+                             xh_fixed=[x.clone() for x in c.xh_fixed], frag_fixed=c.frag_fixed, noise_fn=c.noise)
+    assert int(smp.last_status[0].item()) == 0
+    sd64 = {k: v.double() for k, v in c.sd.items()}
+
+    def dyn64(zt, t):
+        return oracle.dynamics_forward(sd64, c.cfg, zt, c.ei, t, c.cond.double(), c.nfs, c.cm, 1, nodeframe="exact")
+
+    torch.set_default_dtype(torch.float64)
+    try:
+        x64 = so.inpaint(dyn64, c.table.double(), c.T, c.masks, c.B, lambda i: [n.double() for n in c.noise(i)],
+                         c.cond.double(), True, [x.double() for x in c.xh_fixed], c.frag_fixed, c.res, c.jump)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    got = torch.cat([smp.last_x[k][:, :3].cpu().double().reshape(-1) for k in range(3)])
+    want = torch.cat([x64[k][:, :3].reshape(-1) for k in range(3)])
+    e = rel(got, want)
+    print(f"g5_inpaint: device inpaint vs float64 replay, positions rel = {e:.2e} ({c.meta['ncalls']} noise draws)")
+    assert e <= 5e-5
+    assert out[0][1].shape == (sum(c.sizes), 9)
