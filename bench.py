@@ -218,7 +218,7 @@ def main():
             "roofline": roof,
             "sampler_loop": sampler_leg,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(nf, os.cpu_count() or 1)
         print(json.dumps(out))
     if dist is not None:

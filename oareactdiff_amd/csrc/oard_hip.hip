@@ -49,12 +49,12 @@ struct Timing {
 int g_stop_after = 0;
 int g_gcl_variant = 3;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
 int g_equi_variant = 2;
+int g_parts = 0;            // sub-batches per topology (0 = auto: 4 for B >= 32, 2 for B >= 16, else 1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
 int g_overlap = 0;         // run the GCL node stage on a side stream underneath the Equi edge kernel
 hipStream_t g_side = nullptr;
 hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
-size_t g_vec_final = 0;    // workspace offset of the vec buffer holding the final state (taps)
 
 struct ScopedLaunch {
     hipStream_t st; hipEvent_t a; int fam; bool on;
@@ -201,9 +201,9 @@ struct Packer {
         hipLaunchKernelGGL(k_copy_raw, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, p[src], blob + dst, n);
     }
 };
-static WsOff make_ws(const oard_config* c, const oard_topology* tp) {
+static WsOff make_ws(const oard_config* c, const TopoDev& td) {
     const RDims d(c->hidden, c->num_radial);
-    const size_t N = tp->d.N, E = tp->d.E + 1, A = tp->d.A + 1;   // + the spare row of the padding columns
+    const size_t N = td.N, E = td.E + 1, A = td.A + 1;   // + the spare row of the padding columns
     WsOff w;
     size_t cur = 0;
     auto take = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
@@ -277,12 +277,12 @@ int launch_equi_v1(int variant, const TopoDev& tp, const float* stream, const fl
 }
 
 template <class D>
-static int forward_impl(const oard_config* c, const oard_topology* topo, const float* wb, const float* const* xh,
+static int forward_impl(const oard_config* c, const TopoPart* topo, const float* wb, const float* const* xh,
                         const float* t, int t_scalar, const float* cond, float* const* out, char* ws, int* status,
                         hipStream_t st) {
     const TopoDev& tp = topo->d;
     const PackOff po = make_layout(c);
-    const WsOff w = make_ws(c, topo);
+    const WsOff w = make_ws(c, tp);
     const int emb = embed_dim(c);
     float* pos = (float*)(ws + w.pos); double* pf64 = (double*)(ws + w.pf64); float* pf32 = (float*)(ws + w.pf32);
     float* x1 = (float*)(ws + w.x1); float* pp0 = (float*)(ws + w.pp0); int* labels = (int*)(ws + w.labels);
@@ -304,7 +304,6 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
     const unsigned gN = (unsigned)cdiv(N, 64), gE = (unsigned)cdiv(E, 64), gA = (unsigned)cdiv(A, 64);
     const double cutoff = (double)c->cutoff;
 
-    HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), st));
     LAUNCH(F_OTHER, k_prep, cdiv(N, 128), 128, st, tp, op, wb, pos, hin, t, t_scalar, cond,
            c->condition_nf > 0 ? c->condition_nf : 0, c->condition_time, emb);
     LAUNCH(F_INIT, k_geom, tp.n_groups, 64, st, tp, (const float*)pos, cutoff, pf64, pf32, x1, pp0, labels);
@@ -361,7 +360,7 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
         if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, 8>), gN16, 512, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
         else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
         if (fork) HIP_TRY(hipEventRecord(g_ev_join, g_side));
-        if (g_stop_after == 100 + 10 * l + 1) { g_vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
+        if (g_stop_after == 100 + 10 * l + 1) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
         if (g_equi_variant == 0) {
             if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew, (const float*)rbuf,
                               (const float*)geo, (const float*)xq, (const float*)vcur, xmsg, vmsg);
@@ -384,9 +383,9 @@ static int forward_impl(const oard_config* c, const oard_topology* topo, const f
         }
         if (!nv1) LAUNCH(F_NODE, (k_equi_upd<D>), gN, 256, st, tp, wb, lo, (const float*)scal, (const float*)vdot,
                          (const float*)v2buf, s, vcur);
-        if (g_stop_after == 100 + 10 * l + 2) { g_vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
+        if (g_stop_after == 100 + 10 * l + 2) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
     }
-    g_vec_final = (size_t)((char*)vcur - ws);
+    topo->vec_final = (size_t)((char*)vcur - ws);
     LAUNCH(F_NODE, (k_out<D>), gN, 256, st, tp, wb, po, (const float*)s, (const float*)vcur, dpos, hout, status);
     LAUNCH(F_OTHER, k_post, cdiv(N, 128), 128, st, tp, op, wb, (const float*)dpos, (const float*)hout, emb);
     HIP_TRY(hipGetLastError());
@@ -513,43 +512,33 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
 // ------------------------------------------------------------------------------------------------
 // topology
 // ------------------------------------------------------------------------------------------------
-int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t* nfs, int64_t n_nodes,
-                         oard_topology** out) {
-    if (!config_ok(c) || !cm || !nfs || !out || n_nodes < 1 || n_nodes > (1 << 24)) return OARD_EINVAL;
-    const int N = (int)n_nodes, n_obj = c->n_obj;
-    std::vector<int> obj_start(n_obj + 1, 0);
-    for (int i = 0; i < N; ++i) {
-        if (nfs[i] < 0 || nfs[i] >= n_obj) return OARD_EINVAL;
-        if (i > 0 && nfs[i] < nfs[i - 1]) return OARD_EINVAL;           // objects must be contiguous, ascending
-        obj_start[nfs[i] + 1]++;
-    }
-    for (int k = 0; k < n_obj; ++k) obj_start[k + 1] += obj_start[k];
-    std::vector<int64_t> samples(cm, cm + N);
-    std::sort(samples.begin(), samples.end());
-    samples.erase(std::unique(samples.begin(), samples.end()), samples.end());
-    const int B = (int)samples.size();
-    if (samples.front() < 0 || samples.back() > (1 << 30)) return OARD_EINVAL;
-    std::vector<int> dense(N);
-    for (int i = 0; i < N; ++i) dense[i] = (int)(std::lower_bound(samples.begin(), samples.end(), cm[i]) - samples.begin());
-    std::vector<int> order(N);
-    for (int i = 0; i < N; ++i) order[i] = i;
+void oard_topology_destroy(oard_topology* tp);
+
+// builds the device tables of the sub-batch made of the samples with dense index in [lo, hi)
+static int build_part(const oard_config* c, const int64_t* cm, const int64_t* nfs, int N_all, const std::vector<int>& obj_start,
+                      const std::vector<int>& dense, const std::vector<long long>& ref_ptr_ref, int lo, int hi,
+                      TopoPart& part, int& max_group, int& max_ns) {
+    const int n_obj = c->n_obj, B = hi - lo;
+    std::vector<int> order;
+    for (int i = 0; i < N_all; ++i) if (dense[i] >= lo && dense[i] < hi) order.push_back(i);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         if (dense[a] != dense[b]) return dense[a] < dense[b];
         return nfs[a] < nfs[b];
     });
+    const int N = (int)order.size();
+    if (N < 1) return OARD_EINVAL;
     std::vector<int> node_obj(N), node_row(N), node_ref(N), node_tidx(N), node_sample(N), sample_ptr(B + 1, 0),
         grp_ptr((size_t)B * n_obj + 1, 0), edge_ptr(N), act_ptr(N + 1, 0);
     for (int n = 0; n < N; ++n) {
-        const int r = order[n];
+        const int r = order[n], sb = dense[r] - lo;
         node_ref[n] = r; node_obj[n] = (int)nfs[r]; node_row[n] = r - obj_start[nfs[r]];
-        node_tidx[n] = (int)cm[r]; node_sample[n] = dense[r];
-        sample_ptr[dense[r] + 1]++;
-        grp_ptr[(size_t)dense[r] * n_obj + nfs[r] + 1]++;
+        node_tidx[n] = (int)cm[r]; node_sample[n] = sb;
+        sample_ptr[sb + 1]++;
+        grp_ptr[(size_t)sb * n_obj + nfs[r] + 1]++;
     }
     for (int b = 0; b < B; ++b) sample_ptr[b + 1] += sample_ptr[b];
     for (size_t q = 0; q < (size_t)B * n_obj; ++q) grp_ptr[q + 1] += grp_ptr[q];
     long long E = 0, A = 0;
-    int max_group = 0, max_ns = 0;
     for (int b = 0; b < B; ++b) {
         const long long ns = sample_ptr[b + 1] - sample_ptr[b];
         max_ns = std::max(max_ns, (int)ns);
@@ -598,21 +587,9 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
         for (long long e = 0; e < E; ++e)
             if (edge_row[e] < 0) { edge_row[e] = (int)r; row_src[r] = edge_src[e]; row_tgt[r] = edge_tgt[e]; row_eid[r] = (int)e; ++r; }
     }
-    // reference-order edge offsets: prefix of (n_s - 1) over reference node order
-    std::vector<long long> ref_ptr_ref(N), ref_edge_ptr(N);
-    {
-        long long acc = 0;
-        std::vector<int> ref_to_int(N);
-        for (int n = 0; n < N; ++n) ref_to_int[node_ref[n]] = n;
-        for (int r = 0; r < N; ++r) {
-            ref_ptr_ref[r] = acc;
-            const int b = node_sample[ref_to_int[r]];
-            acc += sample_ptr[b + 1] - sample_ptr[b] - 1;
-        }
-        for (int n = 0; n < N; ++n) ref_edge_ptr[n] = ref_ptr_ref[node_ref[n]];
-    }
+    std::vector<long long> ref_edge_ptr(N);
+    for (int n = 0; n < N; ++n) ref_edge_ptr[n] = ref_ptr_ref[node_ref[n]];
 
-    // one device block
     struct Item { const void* src; size_t bytes; size_t off; };
     std::vector<Item> items;
     size_t cur = 0;
@@ -632,9 +609,8 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
         hipError_t e = hipMemcpy(dev + it.off, it.src, it.bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(dev); return OARD_EHIP; }
     }
-    oard_topology* tp = new oard_topology();
-    tp->dev_block = dev; tp->max_group = max_group; tp->max_ns = max_ns;
-    TopoDev& d = tp->d;
+    part.dev_block = dev;
+    TopoDev& d = part.d;
     d.N = N; d.B = B; d.n_obj = n_obj; d.n_groups = B * n_obj; d.E = E; d.A = A;
     d.node_obj = (const int*)(dev + o_obj); d.node_row = (const int*)(dev + o_row); d.node_ref = (const int*)(dev + o_ref);
     d.node_tidx = (const int*)(dev + o_tidx); d.node_sample = (const int*)(dev + o_smp); d.sample_ptr = (const int*)(dev + o_sptr);
@@ -644,31 +620,84 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
     d.ref_edge_ptr = (const long long*)(dev + o_rptr);
     d.edge_row = (const int*)(dev + o_erow); d.row_src = (const int*)(dev + o_rsrc); d.row_tgt = (const int*)(dev + o_rtgt);
     d.row_eid = (const int*)(dev + o_reid);
+    return OARD_OK;
+}
+
+int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t* nfs, int64_t n_nodes,
+                         oard_topology** out) {
+    if (!config_ok(c) || !cm || !nfs || !out || n_nodes < 1 || n_nodes > (1 << 24)) return OARD_EINVAL;
+    const int N = (int)n_nodes, n_obj = c->n_obj;
+    std::vector<int> obj_start(n_obj + 1, 0);
+    for (int i = 0; i < N; ++i) {
+        if (nfs[i] < 0 || nfs[i] >= n_obj) return OARD_EINVAL;
+        if (i > 0 && nfs[i] < nfs[i - 1]) return OARD_EINVAL;           // objects must be contiguous, ascending
+        obj_start[nfs[i] + 1]++;
+    }
+    for (int k = 0; k < n_obj; ++k) obj_start[k + 1] += obj_start[k];
+    std::vector<int64_t> samples(cm, cm + N);
+    std::sort(samples.begin(), samples.end());
+    samples.erase(std::unique(samples.begin(), samples.end()), samples.end());
+    const int B = (int)samples.size();
+    if (samples.front() < 0 || samples.back() > (1 << 30)) return OARD_EINVAL;
+    std::vector<int> dense(N), ns_of(B, 0);
+    for (int i = 0; i < N; ++i) {
+        dense[i] = (int)(std::lower_bound(samples.begin(), samples.end(), cm[i]) - samples.begin());
+        ns_of[dense[i]]++;
+    }
+    // reference-order edge offsets: prefix of (n_s - 1) over the reference node order (whole batch)
+    std::vector<long long> ref_ptr_ref(N);
+    long long E_all = 0;
+    for (int r = 0; r < N; ++r) { ref_ptr_ref[r] = E_all; E_all += ns_of[dense[r]] - 1; }
+
+    int n_parts = g_parts > 0 ? g_parts : (B >= 32 ? 4 : (B >= 16 ? 2 : 1));
+    n_parts = std::max(1, std::min(std::min(n_parts, OARD_MAX_PARTS), B));
+    oard_topology* tp = new oard_topology();
+    tp->n_obj = n_obj; tp->B = B; tp->n_parts = n_parts;
+    for (int p = 0; p < n_parts; ++p) {
+        const int lo = (int)((long long)B * p / n_parts), hi = (int)((long long)B * (p + 1) / n_parts);
+        int rc = build_part(c, cm, nfs, N, obj_start, dense, ref_ptr_ref, lo, hi, tp->parts[p], tp->max_group, tp->max_ns);
+        if (rc != OARD_OK) { oard_topology_destroy(tp); return rc; }
+        tp->N += tp->parts[p].d.N; tp->E += tp->parts[p].d.E; tp->A += tp->parts[p].d.A;
+    }
+    if (n_parts > 1) {
+        HIP_TRY(hipEventCreateWithFlags(&tp->ev_fork, hipEventDisableTiming));
+        for (int p = 1; p < n_parts; ++p) {
+            HIP_TRY(hipStreamCreateWithFlags(&tp->side[p], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&tp->ev_join[p], hipEventDisableTiming));
+        }
+    }
     *out = tp;
     return OARD_OK;
 }
 
 void oard_topology_destroy(oard_topology* tp) {
     if (!tp) return;
-    if (tp->dev_block) (void)hipFree(tp->dev_block);
+    for (int p = 0; p < OARD_MAX_PARTS; ++p) {
+        if (tp->parts[p].dev_block) (void)hipFree(tp->parts[p].dev_block);
+        if (tp->side[p]) (void)hipStreamDestroy(tp->side[p]);
+        if (tp->ev_join[p]) (void)hipEventDestroy(tp->ev_join[p]);
+    }
+    if (tp->ev_fork) (void)hipEventDestroy(tp->ev_fork);
     delete tp;
 }
-int64_t oard_topology_num_nodes(const oard_topology* tp) { return tp ? tp->d.N : 0; }
-int64_t oard_topology_num_edges(const oard_topology* tp) { return tp ? tp->d.E : 0; }
-int64_t oard_topology_num_inner_edges(const oard_topology* tp) { return tp ? tp->d.A : 0; }
-int64_t oard_topology_num_samples(const oard_topology* tp) { return tp ? tp->d.B : 0; }
+int64_t oard_topology_num_nodes(const oard_topology* tp) { return tp ? tp->N : 0; }
+int64_t oard_topology_num_edges(const oard_topology* tp) { return tp ? tp->E : 0; }
+int64_t oard_topology_num_inner_edges(const oard_topology* tp) { return tp ? tp->A : 0; }
+int64_t oard_topology_num_samples(const oard_topology* tp) { return tp ? tp->B : 0; }
 
 int oard_topology_check_edge_index(const oard_topology* tp, const int64_t* ei, int64_t n_edges, int32_t* ok,
                                    oard_stream_t stream) {
     if (!tp || !ok) return OARD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int one = (n_edges == tp->d.E) ? 1 : 0;
+    const int one = (n_edges == tp->E) ? 1 : 0;
     HIP_TRY(hipMemcpyAsync(ok, &one, sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));      // `one` lives on this stack frame
-    if (one && tp->d.E > 0) {
+    if (one && tp->E > 0) {
         if (!ei) return OARD_EINVAL;
-        hipLaunchKernelGGL(k_check_edges, dim3((unsigned)cdiv(tp->d.E, 256)), dim3(256), 0, st, tp->d,
-                           (const long long*)ei, (long long)n_edges, (int*)ok);
+        for (int p = 0; p < tp->n_parts; ++p)
+            if (tp->parts[p].d.E > 0)
+                hipLaunchKernelGGL(k_check_edges, dim3((unsigned)cdiv(tp->parts[p].d.E, 256)), dim3(256), 0, st,
+                                   tp->parts[p].d, (const long long*)ei, (long long)n_edges, (int*)ok);
         HIP_TRY(hipGetLastError());
     }
     return OARD_OK;
@@ -677,9 +706,17 @@ int oard_topology_check_edge_index(const oard_topology* tp, const int64_t* ei, i
 // ------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------
+static size_t ws_total(const oard_config* c, const oard_topology* tp) {
+    size_t cur = 0;
+    for (int p = 0; p < tp->n_parts; ++p) {
+        const_cast<TopoPart&>(tp->parts[p]).ws_off = cur;
+        cur = align_up(cur + make_ws(c, tp->parts[p].d).total, 4096);
+    }
+    return cur;
+}
 size_t oard_workspace_bytes(const oard_config* c, const oard_topology* tp) {
     if (!config_ok(c) || !tp) return 0;
-    return make_ws(c, tp).total;
+    return ws_total(c, tp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -691,12 +728,25 @@ int oard_forward(const oard_config* c, const oard_topology* topo, const void* pa
     if (!config_ok(c) || !topo || !packed || !xh || !out || !ws || !status) return OARD_EINVAL;
     if (c->condition_time && !t) return OARD_EINVAL;
     if (c->condition_nf > 0 && !cond) return OARD_EINVAL;
-    if (c->n_obj != topo->d.n_obj) return OARD_EINVAL;
-    if (ws_bytes < make_ws(c, topo).total) return OARD_ENOMEM;
-    int rc = OARD_EINVAL;
-    DISPATCH_DIMS(c, rc = forward_impl<D>(c, topo, (const float*)packed, xh, t, t_is_scalar, cond, out, (char*)ws,
-                                          (int*)status, (hipStream_t)stream));
-    return rc;
+    if (c->n_obj != topo->n_obj) return OARD_EINVAL;
+    if (ws_bytes < ws_total(c, topo)) return OARD_ENOMEM;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), st));
+    // sub-batches run concurrently on the topology's side streams (sequentially when timing / debugging)
+    const bool concurrent = topo->n_parts > 1 && !g_timing.on && g_stop_after == 0;
+    if (concurrent) HIP_TRY(hipEventRecord(topo->ev_fork, st));
+    for (int p = 0; p < topo->n_parts; ++p) {
+        hipStream_t sp = (concurrent && p > 0) ? topo->side[p] : st;
+        if (concurrent && p > 0) HIP_TRY(hipStreamWaitEvent(sp, topo->ev_fork, 0));
+        int rc = OARD_EINVAL;
+        DISPATCH_DIMS(c, rc = forward_impl<D>(c, &topo->parts[p], (const float*)packed, xh, t, t_is_scalar, cond, out,
+                                              (char*)ws + topo->parts[p].ws_off, (int*)status, sp));
+        if (rc != OARD_OK) return rc;
+        if (concurrent && p > 0) HIP_TRY(hipEventRecord(topo->ev_join[p], sp));
+    }
+    if (concurrent)
+        for (int p = 1; p < topo->n_parts; ++p) HIP_TRY(hipStreamWaitEvent(st, topo->ev_join[p], 0));
+    return OARD_OK;
 }
 
 int oard_sampler_step(const oard_config* c, const oard_topology* topo, int mode, const float* const* z,
@@ -705,7 +755,7 @@ int oard_sampler_step(const oard_config* c, const oard_topology* topo, int mode,
     if (!config_ok(c) || !topo || !noise || !out || mode < 0 || mode > 4) return OARD_EINVAL;
     if (mode != 2 && !z) return OARD_EINVAL;
     if (mode <= 1 && !eh) return OARD_EINVAL;
-    if (c->n_obj != topo->d.n_obj) return OARD_EINVAL;
+    if (c->n_obj != topo->n_obj) return OARD_EINVAL;
     SamplerPtrs sp;
     memset(&sp, 0, sizeof(sp));
     for (int k = 0; k < c->n_obj; ++k) {
@@ -717,7 +767,9 @@ int oard_sampler_step(const oard_config* c, const oard_topology* topo, int mode,
         sp.node_nf[k] = c->node_nf[k];
     }
     hipStream_t st = (hipStream_t)stream;
-    LAUNCH(F_OTHER, k_sampler_step, cdiv(topo->d.N, 128), 128, st, topo->d, sp, mode, a, b, cc, zero_feature_noise);
+    for (int p = 0; p < topo->n_parts; ++p)
+        LAUNCH(F_OTHER, k_sampler_step, cdiv(topo->parts[p].d.N, 128), 128, st, topo->parts[p].d, sp, mode, a, b, cc,
+               zero_feature_noise);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
@@ -726,30 +778,33 @@ int oard_tap(const oard_config* c, const oard_topology* topo, const void* ws_, i
              oard_stream_t stream) {
     if (!config_ok(c) || !topo || !ws_ || !dst || layer != 0) return OARD_EINVAL;
     const RDims d(c->hidden, c->num_radial);
-    const WsOff w = make_ws(c, topo);
-    const char* ws = (const char*)ws_;
-    const TopoDev& tp = topo->d;
+    ws_total(c, topo);
     hipStream_t st = (hipStream_t)stream;
-    auto nodes = [&](const float* src, int ld, int sections, int sect_pad, int sect_len) {
-        const long long tot = (long long)tp.N * sections * sect_len;
-        hipLaunchKernelGGL(k_tap_nodes, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, tp, src, ld, sections, sect_pad, sect_len, dst);
-    };
-    switch (which) {
-        case OARD_TAP_S: nodes((const float*)(ws + w.s), d.HP, 1, d.HP, d.H); break;
-        case OARD_TAP_VEC: nodes((const float*)(ws + g_vec_final), 3 * d.HP, 3, d.HP, d.H); break;
-        case OARD_TAP_NE1: nodes((const float*)(ws + w.ne1), 3 * d.HP, 3, d.HP, d.H); break;
-        case OARD_TAP_POS_FRAME: nodes((const float*)(ws + w.pf32), 3, 1, 3, 3); break;
-        case OARD_TAP_DPOS: nodes((const float*)(ws + w.dpos), 3, 1, 3, 3); break;
-        case OARD_TAP_HOUT: nodes((const float*)(ws + w.hout), 16, 1, 16, c->in_hidden); break;
-        case OARD_TAP_LABELS:
-            hipLaunchKernelGGL(k_tap_labels, dim3((unsigned)cdiv(tp.N, 256)), dim3(256), 0, st, tp, (const int*)(ws + w.labels), dst);
-            break;
-        case OARD_TAP_EDGE:
-            if (tp.E > 0)
-                hipLaunchKernelGGL(k_tap_edges, dim3((unsigned)cdiv(tp.E * d.W, 256)), dim3(256), 0, st, tp,
-                                   (const float*)(ws + w.ew), d.WP, d.W, dst);
-            break;
-        default: return OARD_EINVAL;
+    for (int p = 0; p < topo->n_parts; ++p) {
+        const TopoDev& tp = topo->parts[p].d;
+        const WsOff w = make_ws(c, tp);
+        const char* ws = (const char*)ws_ + topo->parts[p].ws_off;
+        auto nodes = [&](const float* src, int ld, int sections, int sect_pad, int sect_len) {
+            const long long tot = (long long)tp.N * sections * sect_len;
+            hipLaunchKernelGGL(k_tap_nodes, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, st, tp, src, ld, sections, sect_pad, sect_len, dst);
+        };
+        switch (which) {
+            case OARD_TAP_S: nodes((const float*)(ws + w.s), d.HP, 1, d.HP, d.H); break;
+            case OARD_TAP_VEC: nodes((const float*)(ws + topo->parts[p].vec_final), 3 * d.HP, 3, d.HP, d.H); break;
+            case OARD_TAP_NE1: nodes((const float*)(ws + w.ne1), 3 * d.HP, 3, d.HP, d.H); break;
+            case OARD_TAP_POS_FRAME: nodes((const float*)(ws + w.pf32), 3, 1, 3, 3); break;
+            case OARD_TAP_DPOS: nodes((const float*)(ws + w.dpos), 3, 1, 3, 3); break;
+            case OARD_TAP_HOUT: nodes((const float*)(ws + w.hout), 16, 1, 16, c->in_hidden); break;
+            case OARD_TAP_LABELS:
+                hipLaunchKernelGGL(k_tap_labels, dim3((unsigned)cdiv(tp.N, 256)), dim3(256), 0, st, tp, (const int*)(ws + w.labels), dst);
+                break;
+            case OARD_TAP_EDGE:
+                if (tp.E > 0)
+                    hipLaunchKernelGGL(k_tap_edges, dim3((unsigned)cdiv(tp.E * d.W, 256)), dim3(256), 0, st, tp,
+                                       (const float*)(ws + w.ew), d.WP, d.W, dst);
+                break;
+            default: return OARD_EINVAL;
+        }
     }
     HIP_TRY(hipGetLastError());
     return OARD_OK;
@@ -763,6 +818,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
     if (strcmp(name, "overlap") == 0) { g_overlap = value; return OARD_OK; }
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
+    if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
     return OARD_EINVAL;
 }
 int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }

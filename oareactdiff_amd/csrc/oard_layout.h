@@ -72,11 +72,25 @@ struct TopoDev {
     const long long *ref_edge_ptr;            // [N] first reference-order edge of internal node n
 };
 
-struct oard_topology {
+// A topology is split into up to OARD_MAX_PARTS independent sub-batches (contiguous ranges of samples):
+// oard_forward runs them concurrently on internal streams so that the low-occupancy node stages and the
+// tail of one part's edge kernels overlap with the other parts' edge kernels.  Reactions never interact,
+// so the split changes nothing in the results.
+#define OARD_MAX_PARTS 8
+struct TopoPart {
     TopoDev d;
-    void* dev_block;       // one allocation holding every table
-    int max_group;
-    int max_ns;
+    void* dev_block = nullptr;     // one allocation holding every table of this part
+    size_t ws_off = 0;             // byte offset of this part's slice of the workspace
+    mutable size_t vec_final = 0;  // workspace offset (within the slice) of the vec buffer holding the final state
+};
+struct oard_topology {
+    int n_parts = 0;
+    TopoPart parts[OARD_MAX_PARTS];
+    int n_obj = 0, B = 0;
+    long long N = 0, E = 0, A = 0;
+    int max_group = 0, max_ns = 0;
+    hipStream_t side[OARD_MAX_PARTS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[OARD_MAX_PARTS] = {};
 };
 
 // ---- workspace carving (byte offsets) --------------------------------------------------------------

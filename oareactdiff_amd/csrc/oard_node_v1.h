@@ -152,7 +152,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
         lds_st(in, t, nb.lane, ld_blk(xh, nb.n, D::HP, t, nb.lane));
         f4 a0 = f4zero(), a1 = f4zero();
         int k = 0;
+#ifdef OARD_ABL_NOGATHER
+        for (; k + 1 < 0; k += 2) {
+#else
         for (; k + 1 < mx; k += 2) {
+#endif
             if (k < deg) a0 += ld_blk(mbuf, e0 + k, D::HP, t, nb.lane);
             if (k + 1 < deg) a1 += ld_blk(mbuf, e0 + k + 1, D::HP, t, nb.lane);
         }
@@ -214,7 +218,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         f4 dx = f4zero(), v0 = f4zero(), v1 = f4zero(), v2 = f4zero();
         const f4 xn0 = ld_blk(xq, n, 3 * D::HP, t, nb.lane), xn1 = ld_blk(xq, n, 3 * D::HP, HT + t, nb.lane),
                  xn2 = ld_blk(xq, n, 3 * D::HP, 2 * HT + t, nb.lane);
+#ifdef OARD_ABL_NOGATHER
+        for (int k = 0; k < 0; ++k)
+#else
         for (int k = 0; k < mx; ++k)
+#endif
             if (k < cnt) {
                 const size_t a = (size_t)a0 + k;
                 const int m = tp.act_src[a];
@@ -254,10 +262,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
             vdk[i] = (v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2]) * inv_sqrt_h;
             f4 sca;
             const int f0 = 16 * t + 4 * nb.g;
+#ifdef OARD_ABL_NOLIN3U
+            sca = sc;
+#else
             sca.x = f0 + 0 < D::H ? lin3u(l3, sc.x) : 0.f;
             sca.y = f0 + 1 < D::H ? lin3u(l3, sc.y) : 0.f;
             sca.z = f0 + 2 < D::H ? lin3u(l3, sc.z) : 0.f;
             sca.w = f0 + 3 < D::H ? lin3u(l3, sc.w) : 0.f;
+#endif
             lds_st(in, HT + t, nb.lane, sca);
         }
     }

@@ -32,6 +32,23 @@ class DiffusionSampler:
         self.node_nfs = dynamics.node_nfs
         self.norm_values = tuple(norm_values)
         self.norm_biases = tuple(norm_biases)
+        self._layout_cache = {}
+
+    def _layout(self, fragments_nodes: List[Tensor], dev):
+        """Batch-layout tensors (masks, combined_mask, edge_index, n_frag_switch) on the device, cached by the
+        atom counts so that repeated sample()/inpaint() calls reuse the same tensors (and therefore the
+        dynamics' cached index tables)."""
+        key = tuple(tuple(int(v) for v in f.tolist()) for f in fragments_nodes)
+        hit = self._layout_cache.get(key)
+        if hit is None:
+            fn = [f.to(dev) for f in fragments_nodes]
+            masks = [get_mask_for_frag(f) for f in fn]
+            combined_mask = torch.cat(masks)
+            hit = (masks, combined_mask, get_edges_index(combined_mask, remove_self_edge=True), get_n_frag_switch(fn))
+            if len(self._layout_cache) >= 4:
+                self._layout_cache.pop(next(iter(self._layout_cache)))
+            self._layout_cache[key] = hit
+        return hit
 
     # --------------------------------------------------------------------------------------------
     def _step_kernel(self, topo, mode, z, eh, noise, h0, a, b, c, out, stream):
@@ -57,11 +74,7 @@ class DiffusionSampler:
         if dev.type != "cuda":
             raise _capi.OardError("DiffusionSampler needs the dynamics on a ROCm device (no CPU fallback)")
         n_obj = len(self.node_nfs)
-        fragments_nodes = [f.to(dev) for f in fragments_nodes]
-        masks = [get_mask_for_frag(f) for f in fragments_nodes]
-        combined_mask = torch.cat(masks)
-        edge_index = get_edges_index(combined_mask, remove_self_edge=True)
-        n_frag_switch = get_n_frag_switch(fragments_nodes)
+        masks, combined_mask, edge_index, n_frag_switch = self._layout(fragments_nodes, dev)
         if conditions is None:
             conditions = torch.zeros(n_samples, max(dyn.condition_nf, 1), device=dev)
         conditions = conditions.to(dev)
@@ -133,11 +146,7 @@ class DiffusionSampler:
         if dev.type != "cuda":
             raise _capi.OardError("DiffusionSampler needs the dynamics on a ROCm device (no CPU fallback)")
         n_obj = len(self.node_nfs)
-        fragments_nodes = [f.to(dev) for f in fragments_nodes]
-        masks = [get_mask_for_frag(f) for f in fragments_nodes]
-        combined_mask = torch.cat(masks)
-        edge_index = get_edges_index(combined_mask, remove_self_edge=True)
-        n_frag_switch = get_n_frag_switch(fragments_nodes)
+        masks, combined_mask, edge_index, n_frag_switch = self._layout(fragments_nodes, dev)
         if conditions is None:
             conditions = torch.zeros(n_samples, max(dyn.condition_nf, 1), device=dev)
         conditions = conditions.to(dev)

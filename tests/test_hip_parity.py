@@ -182,3 +182,29 @@ def test_condition_and_time_change_the_output():
         o2, _ = dyn(a[0], a[1], a[2], a[3] + 0.5, a[4], a[5])
     k = 1                                              # object 1 has nodes in both samples
     assert (o0[k] - o1[k]).abs().max() > 1e-6 and (o0[k] - o2[k]).abs().max() > 1e-6
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_concurrent_sub_batches_are_bitwise_identical(parts):
+    """oard_forward may split a batch into independent sub-batches that run on internal streams; reactions
+    never interact, so the result must be bit-identical to the single-part run."""
+    from oareactdiff_amd import _capi
+    dev = torch.device("cuda:0")
+    c = Case("g3_cutoff_ragged")                      # three samples of different size
+    L = _capi.lib()
+    outs = []
+    try:
+        for p in (1, parts):
+            L.oard_debug_option(b"parts", p)
+            dyn = _dyn(c, dev)
+            with torch.no_grad():
+                o, _ = dyn(*_args(c, dev))
+            torch.cuda.synchronize()
+            outs.append([x.clone() for x in o])
+    finally:
+        L.oard_debug_option(b"parts", 0)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    v, h = c.split([o.cpu() for o in outs[1]])
+    rv, rh = c.split(c.ref64)
+    assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
