@@ -57,9 +57,10 @@ def cpu_baseline(n_atoms: int, threads: int):
 
 
 def pmc_traffic(kernel: str, batch: int, atoms: int):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/round1_pmc_{fetch,write}.txt,
-    collected at the default workload): FETCH_SIZE (KiB; x2 — it under-reports wide streaming reads by 2x on
-    gfx950, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KiB).  None for any other workload."""
+    """HBM bytes per denoising step of all launches of `kernel`, from the committed PMC passes
+    (profiles/round1_pmc_{fetch,write}.txt, collected at the default workload): FETCH_SIZE (KiB; x2 — it
+    under-reports wide streaming reads by 2x on gfx950, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KiB).
+    None for any other workload."""
     if (batch, atoms) != (64, 23):
         return None
     import re
@@ -72,7 +73,7 @@ def pmc_traffic(kernel: str, batch: int, atoms: int):
         for line in open(path):
             if line.startswith("=="):
                 cur = line
-            m = re.search(key + r"\s+avg/launch = ([0-9.e+]+)", line)
+            m = re.search(key + r"\s+per forward = ([0-9.e+]+)", line)
             if m and cur and kernel in cur:
                 vals[key] = float(m.group(1))
     if len(vals) != 2:
@@ -158,13 +159,22 @@ def main():
     A = B * 3 * nf * (nf - 1)
     roof = None
     if rank == 0:
+        # Kernels are timed in isolation on the WHOLE batch (one sub-batch, nothing overlapping): that is the
+        # figure a roofline fraction is about.  The timed region above runs the default schedule (4 concurrent
+        # sub-batches), which is faster than the sum of the isolated kernels.
         L_ = _capi.lib()
+        L_.oard_debug_option(b"parts", 1)
+        dyn._topo_cache.clear()
+        step(0)
+        torch.cuda.synchronize(dev)
         L_.oard_timing_reset()
         L_.oard_timing_enable(1)
         for i in range(3):
             step(i)
         torch.cuda.synchronize(dev)
         L_.oard_timing_enable(0)
+        L_.oard_debug_option(b"parts", int(os.environ.get("OARD_PARTS", "0")))
+        dyn._topo_cache.clear()
         fam = {}
         for f in ("gcl_edge", "equi_edge", "node", "init", "other"):
             ms, n = _capi.timing_get(f)
@@ -179,6 +189,7 @@ def main():
         ach = flops[dom] / (fam[dom]["ms_per_step"] * 1e-3)
         roof = {"bound": "mfma", "kernel": "k_" + dom, "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                 "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "traffic": pmc_traffic("k_" + dom, B, nf),
+                "traffic_note": "HBM bytes per step over all launches of this kernel (committed PMC passes)",
                 "algorithmic_flops_per_step": flops[dom], "launches_per_step": fam[dom]["launches_per_step"],
                 "kernel_ms_per_step": fam[dom]["ms_per_step"], "avg_launch_ms": fam[dom]["avg_ms"],
                 "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},

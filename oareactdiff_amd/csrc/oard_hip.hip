@@ -47,8 +47,9 @@ struct Timing {
     }
 } g_timing;
 int g_stop_after = 0;
-int g_gcl_variant = 3;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
+int g_gcl_variant = 2;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
 int g_equi_variant = 2;
+int g_sequential = 0;       // 1: run the sub-batches one after the other on the caller stream (profiling)
 int g_parts = 0;            // sub-batches per topology (0 = auto: 4 for B >= 32, 2 for B >= 16, else 1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
@@ -733,7 +734,7 @@ int oard_forward(const oard_config* c, const oard_topology* topo, const void* pa
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), st));
     // sub-batches run concurrently on the topology's side streams (sequentially when timing / debugging)
-    const bool concurrent = topo->n_parts > 1 && !g_timing.on && g_stop_after == 0;
+    const bool concurrent = topo->n_parts > 1 && !g_timing.on && g_stop_after == 0 && !g_sequential;
     if (concurrent) HIP_TRY(hipEventRecord(topo->ev_fork, st));
     for (int p = 0; p < topo->n_parts; ++p) {
         hipStream_t sp = (concurrent && p > 0) ? topo->side[p] : st;
@@ -819,6 +820,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "overlap") == 0) { g_overlap = value; return OARD_OK; }
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
     if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
+    if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }
     return OARD_EINVAL;
 }
 int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }
