@@ -409,6 +409,120 @@ __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(Top
 }
 
 // =====================================================================================================
+// Stage S3 of the GCL edge pass as its own kernel (split schedule): ew += SiLU(W3 m + b3) with m read back
+// from the message buffer.  Without h1 it needs ~half the registers of the fused kernel, so it can run two
+// column blocks per wave (each streamed chunk feeds 8 MFMAs) at 2-3 waves per SIMD.
+// OLD_C0: the rows are inter-object edges of layer 0 whose old state is the constant row (never materialised).
+// =====================================================================================================
+template <class D, int NB, int WAVES, int GP, bool OLD_C0>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_s3_v1(TopoDev tp, const float* __restrict__ stream,
+                                                             const float* __restrict__ c0, long long r0, long long r1,
+                                                             const float* __restrict__ mbuf, float* __restrict__ ew) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using S = GclStream<D, GP>;
+    constexpr int HT = D::HT, WB = D::WB, G2 = S::G2, NP3 = S::NP3;
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int KMAX = (S::SLAB + WAVES - 1) / WAVES;
+    const float* pf_src = stream;
+    float* pf_dst = smem;
+    int pf_n = 0, pf_k = 0, pf_next = 0;
+    auto pf_begin = [&](int q) {                               // q = S3 phase to prefetch
+        int start = S::C1 + S::C2, n = 0;
+        if (q < NP3) { start += q * GP * G2; n = min(GP, WB - q * GP) * G2; }
+        pf_src = stream + (size_t)start * 256 + lane * 4;
+        pf_dst = smem + (size_t)(q & 1) * S::SLAB * 256;
+        pf_n = n; pf_k = 0; pf_next = 1 + (wave >= WAVES / 2 ? 1 : 0);
+    };
+    auto pf_one = [&]() {
+        const int j = wave + pf_k * WAVES;
+        if (j < pf_n) glds16(pf_src + (size_t)j * 256, pf_dst + j * 256);
+        ++pf_k;
+    };
+    auto hook = [&]() { if (--pf_next == 0) { pf_one(); pf_next = 3; } };
+    auto pf_flush = [&]() { while (pf_k < KMAX) pf_one(); };
+    auto SL = [&](int q) -> const float* { return smem + (size_t)(q & 1) * S::SLAB * 256 + lane * 4; };
+
+    const long long colbase = r0 + ((long long)blockIdx.x * WAVES + wave) * (NB * 16) + (lane & 15);
+    float* erow[NB];
+    f4 m[NB][HT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const long long c = colbase + nb * 16;
+        const size_t e = (size_t)(c < r1 ? c : tp.E);
+        erow[nb] = ew + e * D::WP + 4 * g;
+        const size_t mrow = (size_t)tp.row_eid[e];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) m[nb][t] = ld_blk(mbuf, mrow, D::HP, t, lane);
+    }
+    f4 on[GP][NB], pend[GP][NB];
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            on[gg][nb] = gg < WB ? (OLD_C0 ? ld_f4(c0 + 16 * gg + 4 * g) : ld_f4(erow[nb] + 16 * gg)) : f4zero();
+    pf_begin(0);
+    pf_flush();
+    for (int q = 0; q < NP3; ++q) {
+        phase_barrier();
+        if (q > 0) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) st_f4(erow[nb] + 16 * ((q - 1) * GP + gg), pend[gg][nb]);
+        }
+        f4 o[GP][NB];
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) o[gg][nb] = on[gg][nb];
+        pf_begin(q + 1);
+        if (q + 1 < NP3) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) {
+                const int t = (q + 1) * GP + gg;
+                if (t < WB)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        on[gg][nb] = OLD_C0 ? ld_f4(c0 + 16 * t + 4 * g) : ld_f4(erow[nb] + 16 * t);
+            }
+        }
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) {
+            const int t = q * GP + gg;
+            if (t < WB) {
+                const f4 bias = lds_a(SL(q), gg * G2);
+                if (NB >= 2) {
+                    f4 acc[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb] = bias;
+#pragma unroll
+                    for (int b = 0; b < HT; ++b) {
+                        f4 xb[NB];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) xb[nb] = m[nb][b];
+                        mma_shared_a<NB>(lds_a(SL(q), gg * G2 + 1 + b), xb, acc);
+                        if (b & 1) hook();
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) pend[gg][nb] = o[gg][nb] + EPI_SILU4(acc[nb]);
+                } else {
+                    pend[gg][0] = o[gg][0] + EPI_SILU4(chain_tile<HT>(SL(q), gg * G2 + 1, m[0], bias, hook));
+                }
+            }
+        }
+        pf_flush();
+    }
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg) {
+        const int t = (NP3 - 1) * GP + gg;
+        if (t < WB)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) st_f4(erow[nb] + 16 * t, pend[gg][nb]);
+    }
+}
+
+// =====================================================================================================
 // EquiMessage edge part, inner edges sorted by target.  Stream: T1 = WB groups x D1T [dir_proj.0, K-outer];
 // T2 = 3*HT groups (order tt-major, third-minor) x (1 + D1T + RB) [bias dp2b | dir_proj.2 tile | rbf_proj tile].
 // Output: q[a][third][feature] = (dir_proj(ew))[..] * (rbf_proj(rbf))[..]  — the node kernel forms the messages.

@@ -50,12 +50,10 @@ int g_stop_after = 0;
 int g_gcl_variant = 2;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
 int g_equi_variant = 2;
 int g_sequential = 0;       // 1: run the sub-batches one after the other on the caller stream (profiling)
+int g_gcl_split = 0;        // 0: fused S1+S2+S3 kernel; 1..: S1+S2 kernel followed by a separate S3 kernel (variant id)
 int g_parts = 0;            // sub-batches per topology (0 = auto: 4 for B >= 32, 2 for B >= 16, else 1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
-int g_overlap = 0;         // run the GCL node stage on a side stream underneath the Equi edge kernel
-hipStream_t g_side = nullptr;
-hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
 
 struct ScopedLaunch {
     hipStream_t st; hipEvent_t a; int fam; bool on;
@@ -250,14 +248,48 @@ int launch_gcl_v1s(int variant, const TopoDev& tp, const float* stream, const fl
         default: return OARD_EINVAL;
     }
 }
+#define S3_CASE(id, NB_, WV_, GP_) case id: { \
+        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_s3_v1<D, NB_, WV_, GP_, C0>), cdiv(r1 - r0, NB_ * 16 * WV_), WV_ * 64, \
+                   (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, c0, r0, r1, mbuf, ew); return OARD_OK; }
+template <class D, bool C0>
+int launch_gcl_s3(int variant, const TopoDev& tp, const float* stream, const float* c0, long long r0, long long r1,
+                  const float* mbuf, float* ew, hipStream_t st) {
+    if (r1 <= r0) return OARD_OK;
+    switch (variant) {
+        S3_CASE(1, 2, 8, 2)      // 8 waves x 32 edges
+        S3_CASE(2, 2, 4, 1)      // 4 waves x 32 edges, one group per phase (28 KB LDS: several workgroups per CU)
+        S3_CASE(3, 1, 8, 2)      // 8 waves x 16 edges
+        S3_CASE(4, 2, 4, 2)      // 4 waves x 32 edges
+        default: return OARD_EINVAL;
+    }
+}
 // one GCL edge pass of layer l: inner edges always run every stage; inter-object edges skip S1 in the first
 // layer (constant initial state) and S3 in the last (their updated state is never read)
 template <class D>
 int launch_gcl_v1(int variant, const TopoDev& tp, const float* stream, const float* P, const float* Q, const float* u0,
                   const float* c0, bool first, bool last, float* ew, float* mbuf, hipStream_t st) {
     const long long A = tp.A, E = tp.E;
+    int rc;
+    if (g_gcl_split) {
+        // S1 + S2 (writes m), then S3 from m
+        const bool skip = g_gcl_skip != 0;
+        if (skip && first) {
+            rc = launch_gcl_v1s<D, true, false>(variant, tp, stream, P, Q, u0, c0, 0, A, ew, mbuf, st);
+            if (rc == OARD_OK) rc = launch_gcl_v1s<D, false, false>(variant, tp, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
+        } else {
+            rc = launch_gcl_v1s<D, true, false>(variant, tp, stream, P, Q, u0, c0, 0, E, ew, mbuf, st);
+        }
+        if (rc != OARD_OK) return rc;
+        if (skip && first && !last) {
+            rc = launch_gcl_s3<D, false>(g_gcl_split, tp, stream, c0, 0, A, mbuf, ew, st);
+            if (rc == OARD_OK) rc = launch_gcl_s3<D, true>(g_gcl_split, tp, stream, c0, A, E, mbuf, ew, st);
+            return rc;
+        }
+        if (skip && last) return launch_gcl_s3<D, false>(g_gcl_split, tp, stream, c0, 0, A, mbuf, ew, st);
+        return launch_gcl_s3<D, false>(g_gcl_split, tp, stream, c0, 0, E, mbuf, ew, st);
+    }
     if (!g_gcl_skip || (!first && !last)) return launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, c0, 0, E, ew, mbuf, st);
-    int rc = launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, c0, 0, A, ew, mbuf, st);
+    rc = launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, c0, 0, A, ew, mbuf, st);
     if (rc != OARD_OK) return rc;
     if (first && last) return launch_gcl_v1s<D, false, false>(variant, tp, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
     if (first) return launch_gcl_v1s<D, false, true>(variant, tp, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
@@ -344,23 +376,9 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                 if (rc != OARD_OK) return rc;
             }
         }
-        // k_equi_edge_v1 needs only the edge state, not the node update: the GCL node stage (s, xq) runs on a
-        // side stream underneath it and is joined before the Equi node stage
-        const bool fork = nv1 && g_overlap && g_equi_variant != 0 && A > 0 && g_stop_after == 0 && !g_timing.on;
         hipStream_t sn = st;
-        if (fork) {
-            if (!g_side) {
-                HIP_TRY(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming));
-            }
-            HIP_TRY(hipEventRecord(g_ev_fork, st));
-            HIP_TRY(hipStreamWaitEvent(g_side, g_ev_fork, 0));
-            sn = g_side;
-        }
         if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, 8>), gN16, 512, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
         else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
-        if (fork) HIP_TRY(hipEventRecord(g_ev_join, g_side));
         if (g_stop_after == 100 + 10 * l + 1) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
         if (g_equi_variant == 0) {
             if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew, (const float*)rbuf,
@@ -372,7 +390,6 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                 int rc = launch_equi_v1<D>(g_equi_variant, tp, wb + lo.equi_stream, wb + lo.dp0b, ew, rbuf, vmsg, st);
                 if (rc != OARD_OK) return rc;
             }
-            if (fork) HIP_TRY(hipStreamWaitEvent(st, g_ev_join, 0));
             if (nv1) {
                 LAUNCH(F_NODE, (k_equi_node_v1<D, 8>), gN16, 512, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
                        (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext);
@@ -817,9 +834,9 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "gcl_variant") == 0) { g_gcl_variant = value; return OARD_OK; }
     if (strcmp(name, "equi_variant") == 0) { g_equi_variant = value; return OARD_OK; }
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
-    if (strcmp(name, "overlap") == 0) { g_overlap = value; return OARD_OK; }
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
     if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
+    if (strcmp(name, "gcl_split") == 0) { g_gcl_split = value; return OARD_OK; }
     if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }
     return OARD_EINVAL;
 }

@@ -129,10 +129,12 @@ def _random_case(sizes, pos_scale, seed, cfg):
     return xh, ei, torch.rand(B, 1, generator=g), torch.rand(B, 1, generator=g), nfs, cm
 
 
-@pytest.mark.parametrize("sizes,pos_scale", [([7, 23, 12, 1, 16], 1.0), ([9, 30, 5], 2.5), ([40, 3], 1.5)])
+@pytest.mark.parametrize("sizes,pos_scale", [([7, 23, 12, 1, 16], 1.0), ([9, 30, 5], 2.5), ([40, 3], 1.5),
+                                             ([1, 1], 1.0), ([2], 1.0)])
 def test_ragged_production_dims_vs_oracle(sizes, pos_scale):
     """Ragged reactions (incl. a single-atom-per-object sample and groups > 32 atoms), with and without the
-    cutoff biting, production dims, against the float64 oracle evaluated here on the same inputs."""
+    cutoff biting, production dims, against the float64 oracle evaluated here on the same inputs; the last two
+    cases have no same-object edge at all (A = 0) / a single reaction of two-atom objects."""
     from oareactdiff_amd.dynamics import EGNNDynamics
     from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
     dev = torch.device("cuda:0")
@@ -208,3 +210,32 @@ def test_concurrent_sub_batches_are_bitwise_identical(parts):
     v, h = c.split([o.cpu() for o in outs[1]])
     rv, rh = c.split(c.ref64)
     assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
+
+
+@pytest.mark.parametrize("opts", [
+    dict(gcl_variant=0, equi_variant=0, node_variant=0),       # v0: weights straight from L2, one wave per 16 nodes
+    dict(gcl_variant=1, equi_variant=1),
+    dict(gcl_variant=3, equi_variant=3),
+    dict(gcl_variant=4, equi_variant=2, gcl_skip=0),
+    dict(gcl_split=1), dict(gcl_split=2), dict(gcl_split=3), dict(gcl_split=4),
+])
+def test_every_kernel_variant_is_parity_green(opts):
+    """The A/B variants kept in the library (oard_debug_option) all compute the same thing."""
+    from oareactdiff_amd import _capi
+    dev = torch.device("cuda:0")
+    L = _capi.lib()
+    defaults = dict(gcl_variant=2, equi_variant=2, node_variant=1, gcl_skip=1, gcl_split=0)
+    try:
+        for k, v in opts.items():
+            assert L.oard_debug_option(k.encode(), v) == 0
+        for name in ("g2s_prod_b1_n5", "g3_cutoff_ragged"):
+            c = Case(name)
+            dyn = _dyn(c, dev)
+            with torch.no_grad():
+                out, _ = dyn(*_args(c, dev))
+            v, h = c.split([o.cpu() for o in out])
+            rv, rh = c.split(c.ref64)
+            assert rel(v, rv) <= TOL and rel(h, rh) <= TOL, (opts, name, rel(v, rv), rel(h, rh))
+    finally:
+        for k, v in defaults.items():
+            L.oard_debug_option(k.encode(), v)
