@@ -141,7 +141,8 @@ int oard_tap(const oard_config* cfg, const oard_topology* topo, const void* work
  * layer l's EquiUpdate. */
 int oard_debug_stop_after(int code);
 /* Kernel-variant switches for A/B measurements: "gcl_variant" / "equi_variant" (0 = weights straight
- * from L2, >= 1 = LDS-streamed variants, see oard_hip.hip). */
+ * from L2, >= 1 = LDS-streamed variants, see oard_hip.hip); "poison" = 1 fills the workspace with NaN
+ * bit patterns before every forward (tests use it to prove that nothing depends on workspace contents). */
 int oard_debug_option(const char* name, int value);
 
 /* Average duration (ms) and launch count per kernel family since the last reset, measured with

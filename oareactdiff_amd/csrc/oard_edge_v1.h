@@ -140,7 +140,7 @@ struct GclStream {
 //   (EquiMessage only touches inner edges): the residual stage and its edge-state traffic are skipped.
 // Columns are the physical rows [r0, r1).
 template <class D, int NB, int WAVES, int GP, int PRIO, bool DO_S1, bool DO_S3>
-__global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
+__global__ __launch_bounds__(WAVES * 64, NB == 1 ? (PRIO == 3 ? 3 : 2) : 1) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                             const float* __restrict__ P, const float* __restrict__ Q,
                                                             const float* __restrict__ u0, const float* __restrict__ c0,
                                                             long long r0, long long r1,
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WAVES * 64, NB == 1 ? 2 : 1) void k_gcl_edge_v1(Top
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
     // static priority for the younger half: the two waves sharing a SIMD then take the matrix pipe in
     // turns (one runs its MFMA chain while the other does its VALU epilogue) instead of in lockstep
-    if (PRIO && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
+    if (PRIO == 1 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);      // PRIO == 3: no priority, but 3 waves per SIMD (<= 168 registers)
 
     // DMA prefetch of the next phase, spread over the current phase: one global_load_lds costs the
     // issuing wave ~100-180 cycles, so the pieces are issued one at a time between MFMA pairs (every

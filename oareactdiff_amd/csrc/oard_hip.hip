@@ -51,6 +51,7 @@ int g_gcl_variant = 2;     // 0: v0 (weights straight from L2), 1..: LDS-streame
 int g_equi_variant = 2;
 int g_sequential = 0;       // 1: run the sub-batches one after the other on the caller stream (profiling)
 int g_gcl_split = 0;        // 0: fused S1+S2+S3 kernel; 1..: S1+S2 kernel followed by a separate S3 kernel (variant id)
+int g_poison = 0;           // 1: fill the workspace with NaN bit patterns before every forward (tests: nothing may depend on its contents)
 int g_parts = 0;            // sub-batches per topology (0 = auto: 4 for B >= 32, 2 for B >= 16, else 1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
@@ -245,6 +246,7 @@ int launch_gcl_v1s(int variant, const TopoDev& tp, const float* stream, const fl
         GCL_CASE(2, 1, 8, 2, 0)      // 8 waves x 16 edges, two waves per SIMD
         GCL_CASE(3, 1, 4, 2, 0)      // 4 waves x 16 edges (two workgroups per CU)
         GCL_CASE(4, 1, 8, 2, 1)      // as 2, static priority for waves 4-7
+        GCL_CASE(5, 1, 4, 1, 3)      // 4 waves x 16 edges, one group per phase, held to 168 registers: 3 workgroups per CU
         default: return OARD_EINVAL;
     }
 }
@@ -750,6 +752,7 @@ int oard_forward(const oard_config* c, const oard_topology* topo, const void* pa
     if (ws_bytes < ws_total(c, topo)) return OARD_ENOMEM;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), st));
+    if (g_poison) HIP_TRY(hipMemsetAsync(ws, 0xFF, ws_total(c, topo), st));
     // sub-batches run concurrently on the topology's side streams (sequentially when timing / debugging)
     const bool concurrent = topo->n_parts > 1 && !g_timing.on && g_stop_after == 0 && !g_sequential;
     if (concurrent) HIP_TRY(hipEventRecord(topo->ev_fork, st));
@@ -838,6 +841,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
     if (strcmp(name, "gcl_split") == 0) { g_gcl_split = value; return OARD_OK; }
     if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }
+    if (strcmp(name, "poison") == 0) { g_poison = value; return OARD_OK; }
     return OARD_EINVAL;
 }
 int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }

@@ -364,6 +364,8 @@ __global__ void k_rbf(TopoDev tp, const double* __restrict__ d64, const float* _
         const double q = exp(-d) - (double)means[k];
         v = (float)(rb * exp(-(double)betas[k] * q * q) * m);
         ew[(size_t)a * WP + 3 * H + k] = v;
+        if (k == 0)                                  // the row's padding features: consumers multiply them by zero weights,
+            for (int c = 3 * H + R; c < WP; ++c) ew[(size_t)a * WP + c] = 0.f;   // so they must be finite
     }
     rbuf[i] = v;
 }

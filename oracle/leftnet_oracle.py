@@ -278,7 +278,12 @@ def leftnet_forward(
         sc2 = torch.cat((sc2[:, :1], sc2[:, 1:2].abs(), sc2[:, 2:]), dim=1)
 
     def lin3(x: Tensor) -> Tensor:  # x [E,H,3]
-        return _linear(_silu(_linear(x, sd, p + "lin3.0")), sd, p + "lin3.2")
+        def f(y: Tensor) -> Tensor:
+            return _linear(_silu(_linear(y, sd, p + "lin3.0")), sd, p + "lin3.2")
+        rows = max(1, (1 << 27) // max(1, x.shape[1] * (H // 4)))      # bound the [rows,H,H/4] intermediate (~1 GiB)
+        if x.shape[0] <= rows:
+            return f(x)
+        return torch.cat([f(x[k:k + rows]) for k in range(0, x.shape[0], rows)], dim=0)
 
     sc1p = sc1.permute(0, 2, 1)
     sc2p = sc2.permute(0, 2, 1)

@@ -156,6 +156,45 @@ def test_ragged_production_dims_vs_oracle(sizes, pos_scale):
     assert rel(v, rv) <= TOL and rel(h, rh) <= TOL, (rel(v, rv), rel(h, rh))
 
 
+@pytest.mark.parametrize("pos_scale", [1.0, 3.0])
+def test_config5_large_reactions(pos_scale):
+    """BASELINE.json configs[4] (SURVEY.md section 8d "config 5"): 128 atoms per object = 384-node reactions with
+    147,072 edges each, B=4; positions ~N(0,1) (everything inside the cutoff) and x3 (the cutoff bites: ragged
+    active set, one-hop labels).  The first reaction alone is checked against the float64 oracle (3 layers, to
+    bound the oracle's memory and time), and the B=4 launch must reproduce it for that reaction."""
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.graph_tools import get_edges_index, get_mask_for_frag, get_n_frag_switch
+    from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    cfg = dict(PRODUCTION_LEFTNET_CONFIG, num_layers=3)
+    sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg, seed=7)
+    nf, B = 128, 4
+    xh, ei, t, cond, nfs, cm = _random_case([nf] * B, pos_scale, 23, cfg)
+    dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
+                       condition_nf=1, device=dev)
+    dyn.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        out4, _ = dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+    assert all(bool(torch.isfinite(o).all()) for o in out4)
+    # the first reaction on its own
+    xh1 = [x[:nf].clone() for x in xh]
+    natm = [torch.tensor([nf]) for _ in range(3)]
+    cm1 = torch.cat([get_mask_for_frag(n) for n in natm])
+    nfs1 = get_n_frag_switch(natm)
+    ei1 = get_edges_index(cm1, remove_self_edge=True)
+    with torch.no_grad():
+        out1, _ = dyn([x.to(dev) for x in xh1], ei1.to(dev), t[:1].to(dev), cond[:1].to(dev), nfs1.to(dev), cm1.to(dev))
+    for a, b in zip(out1, out4):
+        assert rel(b[:nf, :3].cpu(), a[:, :3].cpu()) <= 1e-6 and rel(b[:nf, 3:].cpu(), a[:, 3:].cpu()) <= 1e-6
+    ref = oracle.dynamics_forward({k: v.double() for k, v in sd.items()}, cfg, [x.double() for x in xh1], ei1,
+                                  t[:1].double(), cond[:1].double(), nfs1, cm1, 1, nodeframe="exact")
+    v = torch.cat([o[:, :3].cpu().double().reshape(-1) for o in out1])
+    h = torch.cat([o[:, 3:].cpu().double().reshape(-1) for o in out1])
+    rv = torch.cat([o[:, :3].reshape(-1) for o in ref])
+    rh = torch.cat([o[:, 3:].reshape(-1) for o in ref])
+    assert rel(v, rv) <= TOL and rel(h, rh) <= TOL, (rel(v, rv), rel(h, rh))
+
+
 def test_scalar_t_equals_per_sample_t_and_input_is_not_mutated():
     dev = torch.device("cuda:0")
     c = Case("g3_cutoff_ragged")
