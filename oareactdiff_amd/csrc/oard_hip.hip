@@ -11,6 +11,7 @@
 #include "oard_kernels.h"
 #include "oard_edge_v1.h"
 #include "oard_node_v1.h"
+#include "oard_edge_small.h"
 
 #define OARD_VERSION 1001
 
@@ -51,6 +52,10 @@ int g_gcl_variant = 2;     // 0: v0 (weights straight from L2), 1..: LDS-streame
 int g_equi_variant = 2;
 int g_sequential = 0;       // 1: run the sub-batches one after the other on the caller stream (profiling)
 int g_gcl_split = 0;        // 0: fused S1+S2+S3 kernel; 1..: S1+S2 kernel followed by a separate S3 kernel (variant id)
+int g_auto_tiny = 2;        // launches of <= 512 * g_auto_tiny edge tiles (all concurrent sub-batches together) use the
+                            //    latency kernels of oard_edge_small.h (8 waves share 16 edges); 0 = never
+int g_auto_small = 4;       // 1: small launches use the 4-wave workgroups (one wave per SIMD instead of two): a launch that cannot
+                            //    fill the chip anyway finishes sooner when its waves do not share a SIMD (B <= 8 reactions: -25 %)
 int g_poison = 0;           // 1: fill the workspace with NaN bit patterns before every forward (tests: nothing may depend on its contents)
 int g_parts = 0;            // sub-batches per topology (0 = auto: 4 for B >= 32, 2 for B >= 16, else 1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
@@ -238,9 +243,16 @@ int set_lds(K kernel, size_t bytes) {
         LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB_, WV_, GP_, PR_, S1, S3>), cdiv(r1 - r0, NB_ * 16 * WV_), WV_ * 64, \
                    (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew, mbuf); return OARD_OK; }
 template <class D, bool S1, bool S3>
-int launch_gcl_v1s(int variant, const TopoDev& tp, const float* stream, const float* P, const float* Q, const float* u0,
+int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
                    const float* c0, long long r0, long long r1, float* ew, float* mbuf, hipStream_t st) {
     if (r1 <= r0) return OARD_OK;
+    if (variant == 2 && cdiv(r1 - r0, 16) * conc <= 1024LL * g_auto_small) variant = 3;
+    if ((variant == 2 || variant == 3) && cdiv(r1 - r0, 16) * conc <= 512LL * g_auto_tiny) variant = 6;
+    if (variant == 6) {          // latency kernel: 8 waves share 16 edges
+        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_small<D, 8, S1, S3>), cdiv(r1 - r0, 16), 512, (GclSmall<D>::LDS_BYTES), st,
+                   tp, wb, lo, P, Q, u0, c0, r0, r1, ew, mbuf);
+        return OARD_OK;
+    }
     switch (variant) {
         GCL_CASE(1, 2, 4, 2, 0)      // 4 waves x 32 edges, one wave per SIMD
         GCL_CASE(2, 1, 8, 2, 0)      // 8 waves x 16 edges, two waves per SIMD
@@ -268,7 +280,7 @@ int launch_gcl_s3(int variant, const TopoDev& tp, const float* stream, const flo
 // one GCL edge pass of layer l: inner edges always run every stage; inter-object edges skip S1 in the first
 // layer (constant initial state) and S3 in the last (their updated state is never read)
 template <class D>
-int launch_gcl_v1(int variant, const TopoDev& tp, const float* stream, const float* P, const float* Q, const float* u0,
+int launch_gcl_v1(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
                   const float* c0, bool first, bool last, float* ew, float* mbuf, hipStream_t st) {
     const long long A = tp.A, E = tp.E;
     int rc;
@@ -276,10 +288,10 @@ int launch_gcl_v1(int variant, const TopoDev& tp, const float* stream, const flo
         // S1 + S2 (writes m), then S3 from m
         const bool skip = g_gcl_skip != 0;
         if (skip && first) {
-            rc = launch_gcl_v1s<D, true, false>(variant, tp, stream, P, Q, u0, c0, 0, A, ew, mbuf, st);
-            if (rc == OARD_OK) rc = launch_gcl_v1s<D, false, false>(variant, tp, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
+            rc = launch_gcl_v1s<D, true, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, A, ew, mbuf, st);
+            if (rc == OARD_OK) rc = launch_gcl_v1s<D, false, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
         } else {
-            rc = launch_gcl_v1s<D, true, false>(variant, tp, stream, P, Q, u0, c0, 0, E, ew, mbuf, st);
+            rc = launch_gcl_v1s<D, true, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, E, ew, mbuf, st);
         }
         if (rc != OARD_OK) return rc;
         if (skip && first && !last) {
@@ -290,19 +302,26 @@ int launch_gcl_v1(int variant, const TopoDev& tp, const float* stream, const flo
         if (skip && last) return launch_gcl_s3<D, false>(g_gcl_split, tp, stream, c0, 0, A, mbuf, ew, st);
         return launch_gcl_s3<D, false>(g_gcl_split, tp, stream, c0, 0, E, mbuf, ew, st);
     }
-    if (!g_gcl_skip || (!first && !last)) return launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, c0, 0, E, ew, mbuf, st);
-    rc = launch_gcl_v1s<D, true, true>(variant, tp, stream, P, Q, u0, c0, 0, A, ew, mbuf, st);
+    if (!g_gcl_skip || (!first && !last)) return launch_gcl_v1s<D, true, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, E, ew, mbuf, st);
+    rc = launch_gcl_v1s<D, true, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, A, ew, mbuf, st);
     if (rc != OARD_OK) return rc;
-    if (first && last) return launch_gcl_v1s<D, false, false>(variant, tp, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
-    if (first) return launch_gcl_v1s<D, false, true>(variant, tp, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
-    return launch_gcl_v1s<D, true, false>(variant, tp, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
+    if (first && last) return launch_gcl_v1s<D, false, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
+    if (first) return launch_gcl_v1s<D, false, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
+    return launch_gcl_v1s<D, true, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
 }
 #define EQUI_CASE(id, WV_, PR_) case id: { \
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV_, PR_>), cdiv(tp.A, 16 * WV_), WV_ * 64, (EquiStream<D>::LDS_BYTES), st, \
                    tp, stream, dp0b, ew, rbuf, qbuf); return OARD_OK; }
 template <class D>
-int launch_equi_v1(int variant, const TopoDev& tp, const float* stream, const float* dp0b, const float* ew,
+int launch_equi_v1(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* dp0b, const float* ew,
                    const float* rbuf, float* qbuf, hipStream_t st) {
+    if (variant == 2 && cdiv(tp.A, 16) * conc <= 512LL * g_auto_small) variant = 1;
+    if ((variant == 2 || variant == 1) && cdiv(tp.A, 16) * conc <= 512LL * g_auto_tiny) variant = 4;
+    if (variant == 4) {          // latency kernel: 8 waves share 16 edges
+        LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_small<D, 8>), cdiv(tp.A, 16), 512, (EquiSmall<D>::LDS_BYTES), st,
+                   tp, wb, lo, ew, rbuf, qbuf);
+        return OARD_OK;
+    }
     switch (variant) {
         EQUI_CASE(1, 4, 0)
         EQUI_CASE(2, 8, 0)
@@ -373,7 +392,7 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
             if (g_gcl_variant == 0) {
                 LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew, mbuf);
             } else {
-                int rc = launch_gcl_v1<D>(g_gcl_variant, tp, wb + lo.gcl_stream, P, Q, wb + po.u0, wb + po.c0row, l == 0,
+                int rc = launch_gcl_v1<D>(g_gcl_variant, topo->conc, tp, wb, lo, wb + lo.gcl_stream, P, Q, wb + po.u0, wb + po.c0row, l == 0,
                                           l == c->num_layers - 1, ew, mbuf, st);
                 if (rc != OARD_OK) return rc;
             }
@@ -389,7 +408,7 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                    s, vcur, v2buf, scal, vdot);
         } else {
             if (A > 0) {
-                int rc = launch_equi_v1<D>(g_equi_variant, tp, wb + lo.equi_stream, wb + lo.dp0b, ew, rbuf, vmsg, st);
+                int rc = launch_equi_v1<D>(g_equi_variant, topo->conc, tp, wb, lo, wb + lo.equi_stream, wb + lo.dp0b, ew, rbuf, vmsg, st);
                 if (rc != OARD_OK) return rc;
             }
             if (nv1) {
@@ -678,6 +697,7 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
         int rc = build_part(c, cm, nfs, N, obj_start, dense, ref_ptr_ref, lo, hi, tp->parts[p], tp->max_group, tp->max_ns);
         if (rc != OARD_OK) { oard_topology_destroy(tp); return rc; }
         tp->N += tp->parts[p].d.N; tp->E += tp->parts[p].d.E; tp->A += tp->parts[p].d.A;
+        tp->parts[p].conc = n_parts;
     }
     if (n_parts > 1) {
         HIP_TRY(hipEventCreateWithFlags(&tp->ev_fork, hipEventDisableTiming));
@@ -842,6 +862,8 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "gcl_split") == 0) { g_gcl_split = value; return OARD_OK; }
     if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }
     if (strcmp(name, "poison") == 0) { g_poison = value; return OARD_OK; }
+    if (strcmp(name, "auto_small") == 0) { g_auto_small = value; return OARD_OK; }
+    if (strcmp(name, "auto_tiny") == 0) { g_auto_tiny = value; return OARD_OK; }
     return OARD_EINVAL;
 }
 int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }

@@ -81,6 +81,7 @@ struct TopoPart {
     TopoDev d;
     void* dev_block = nullptr;     // one allocation holding every table of this part
     size_t ws_off = 0;             // byte offset of this part's slice of the workspace
+    int conc = 1;                  // sub-batches of this topology that run concurrently (launch-shape heuristics)
     mutable size_t vec_final = 0;  // workspace offset (within the slice) of the vec buffer holding the final state
 };
 struct oard_topology {

@@ -13,25 +13,33 @@
 OARD_DEV f4 lds_blk(const float* v, int b, int lane) { return *reinterpret_cast<const f4*>(v + b * 256 + lane * 4); }
 OARD_DEV void lds_st(float* v, int t, int lane, f4 x) { *reinterpret_cast<f4*>(v + t * 256 + lane * 4) = x; }
 
-// one output tile from an LDS-resident input vector; even / odd K blocks on two accumulators
+// one output tile from an LDS-resident input vector; even / odd K blocks on two accumulators.
+// The weight chunks come straight from L2 (latency ~1 us): they are requested a whole group (<= 13 chunks,
+// 52 VGPRs) at a time BEFORE the first MFMA of the group - left to itself the compiler keeps only two
+// loads in flight and the tile costs one L2 round trip per chunk pair (measured: 5-6 us per tile instead of ~2).
+#ifndef OARD_NODE_PF
+#define OARD_NODE_PF 13
+#endif
 template <int KB>
 OARD_DEV f4 dense_tile_lds(const float* __restrict__ wp, int t, const float* in, int lane, f4 init) {
     const float* base = wp + ((size_t)t * KB * 64 + lane) * 4;
     f4 c0 = init, c1 = f4zero();
+    constexpr int G = OARD_NODE_PF;
 #pragma unroll
-    for (int b = 0; b + 1 < KB; b += 2) {
-        const f4 a0 = ld_f4(base + (size_t)b * 256), a1 = ld_f4(base + (size_t)(b + 1) * 256);
-        const f4 x0 = lds_blk(in, b, lane), x1 = lds_blk(in, b + 1, lane);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, x0.x, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, x1.x, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, x0.y, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, x1.y, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, x0.z, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, x1.z, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, x0.w, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, x1.w, c1, 0, 0, 0);
+    for (int b0 = 0; b0 < KB; b0 += G) {
+        f4 a[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (b0 + i < KB) a[i] = ld_f4(base + (size_t)(b0 + i) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (b0 + i < KB) {
+                const f4 x = lds_blk(in, b0 + i, lane);
+                if (i & 1) c1 = mma_chunk(a[i], x, c1);
+                else c0 = mma_chunk(a[i], x, c0);
+            }
     }
-    if (KB & 1) c0 = mma_chunk(ld_f4(base + (size_t)(KB - 1) * 256), lds_blk(in, KB - 1, lane), c0);
     return c0 + c1;
 }
 
@@ -151,16 +159,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
     for (int t = nb.wave; t < D::HT; t += WAVES) {
         lds_st(in, t, nb.lane, ld_blk(xh, nb.n, D::HP, t, nb.lane));
         f4 a0 = f4zero(), a1 = f4zero();
-        int k = 0;
+        // 8 message rows in flight per step (branch-free: out-of-range slots re-read the last row with weight 0)
+        const int last = max(deg - 1, 0);
 #ifdef OARD_ABL_NOGATHER
-        for (; k + 1 < 0; k += 2) {
+        for (int k = 0; k < 0; k += 8) {
 #else
-        for (; k + 1 < mx; k += 2) {
+        for (int k = 0; k < mx; k += 8) {
 #endif
-            if (k < deg) a0 += ld_blk(mbuf, e0 + k, D::HP, t, nb.lane);
-            if (k + 1 < deg) a1 += ld_blk(mbuf, e0 + k + 1, D::HP, t, nb.lane);
+            f4 r[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = ld_blk(mbuf, e0 + min(k + i, last), D::HP, t, nb.lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f4 v = k + i < deg ? r[i] : f4zero();
+                if (i & 1) a1 += v; else a0 += v;
+            }
         }
-        if (k < deg) a0 += ld_blk(mbuf, e0 + k, D::HP, t, nb.lane);
         lds_st(in, D::HT + t, nb.lane, (a0 + a1) * inv);
     }
     __syncthreads();
@@ -218,24 +232,40 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         f4 dx = f4zero(), v0 = f4zero(), v1 = f4zero(), v2 = f4zero();
         const f4 xn0 = ld_blk(xq, n, 3 * D::HP, t, nb.lane), xn1 = ld_blk(xq, n, 3 * D::HP, HT + t, nb.lane),
                  xn2 = ld_blk(xq, n, 3 * D::HP, 2 * HT + t, nb.lane);
+        // two edges in flight per step, branch-free (out-of-range slots re-read a valid edge and are discarded)
+        const long long a_hi = max(tp.A - 1, 0LL);
 #ifdef OARD_ABL_NOGATHER
-        for (int k = 0; k < 0; ++k)
+        for (int k = 0; k < 0; k += 2) {
 #else
-        for (int k = 0; k < mx; ++k)
+        for (int k = 0; k < mx; k += 2) {
 #endif
-            if (k < cnt) {
-                const size_t a = (size_t)a0 + k;
+            f4 q0[2], q1[2], q2[2], y0[2], y1[2], y2[2], w0[2], w1[2], w2[2];
+            float gx[2], gy[2], gz[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const size_t a = (size_t)min((long long)a0 + min(k + i, max(cnt - 1, 0)), a_hi);
                 const int m = tp.act_src[a];
                 const float* g = geo + a * GEO_STRIDE;
-                const f4 q0 = ld_blk(qbuf, a, 3 * D::HP, t, nb.lane), q1 = ld_blk(qbuf, a, 3 * D::HP, HT + t, nb.lane),
-                         q2 = ld_blk(qbuf, a, 3 * D::HP, 2 * HT + t, nb.lane);
-                dx += (ld_blk(xq, m, 3 * D::HP, t, nb.lane) + xn0) * q0;
-                const f4 a2 = (ld_blk(xq, m, 3 * D::HP, HT + t, nb.lane) + xn1) * q1 * inv_sqrt3;
-                const f4 a3 = (ld_blk(xq, m, 3 * D::HP, 2 * HT + t, nb.lane) + xn2) * q2;
-                v0 += (ld_blk(vec_in, (size_t)m * 3 + 0, D::HP, t, nb.lane) * a2 + a3 * g[2]) * inv_sqrt_h;
-                v1 += (ld_blk(vec_in, (size_t)m * 3 + 1, D::HP, t, nb.lane) * a2 + a3 * g[3]) * inv_sqrt_h;
-                v2 += (ld_blk(vec_in, (size_t)m * 3 + 2, D::HP, t, nb.lane) * a2 + a3 * g[4]) * inv_sqrt_h;
+                gx[i] = g[2]; gy[i] = g[3]; gz[i] = g[4];
+                q0[i] = ld_blk(qbuf, a, 3 * D::HP, t, nb.lane); q1[i] = ld_blk(qbuf, a, 3 * D::HP, HT + t, nb.lane);
+                q2[i] = ld_blk(qbuf, a, 3 * D::HP, 2 * HT + t, nb.lane);
+                y0[i] = ld_blk(xq, m, 3 * D::HP, t, nb.lane); y1[i] = ld_blk(xq, m, 3 * D::HP, HT + t, nb.lane);
+                y2[i] = ld_blk(xq, m, 3 * D::HP, 2 * HT + t, nb.lane);
+                w0[i] = ld_blk(vec_in, (size_t)m * 3 + 0, D::HP, t, nb.lane);
+                w1[i] = ld_blk(vec_in, (size_t)m * 3 + 1, D::HP, t, nb.lane);
+                w2[i] = ld_blk(vec_in, (size_t)m * 3 + 2, D::HP, t, nb.lane);
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (k + i < cnt) {
+                    dx += (y0[i] + xn0) * q0[i];
+                    const f4 a2 = (y1[i] + xn1) * q1[i] * inv_sqrt3;
+                    const f4 a3 = (y2[i] + xn2) * q2[i];
+                    v0 += (w0[i] * a2 + a3 * gx[i]) * inv_sqrt_h;
+                    v1 += (w1[i] * a2 + a3 * gy[i]) * inv_sqrt_h;
+                    v2 += (w2[i] * a2 + a3 * gz[i]) * inv_sqrt_h;
+                }
+        }
         lds_st(in, t, nb.lane, (ld_blk(s, n, D::HP, t, nb.lane) + dx) * inv_sqrt2);
         lds_st(vx + 0 * HT * 256, t, nb.lane, v0 + ld_blk(vec_in, (size_t)n * 3 + 0, D::HP, t, nb.lane));
         lds_st(vx + 1 * HT * 256, t, nb.lane, v1 + ld_blk(vec_in, (size_t)n * 3 + 1, D::HP, t, nb.lane));

@@ -1,4 +1,5 @@
 """Shared helpers for the parity tests: load a golden fixture, rebuild its weights."""
+import contextlib
 import json
 import os
 
@@ -50,3 +51,21 @@ class Case:
         vel = torch.cat([torch.as_tensor(outs[k])[:, :pos_dim].double().reshape(-1) for k in nz])
         h = torch.cat([torch.as_tensor(outs[k])[:, pos_dim:].double().reshape(-1) for k in nz])
         return vel, h
+
+
+LIB_AUTO = dict(auto_small=4, auto_tiny=2)     # the library's default launch-shape heuristics (conftest turns them off)
+
+
+@contextlib.contextmanager
+def debug_options(**kw):
+    """Set oard_debug_option values for the duration of a block, then restore the suite's options."""
+    from conftest import SUITE_OPTIONS
+    from oareactdiff_amd import _capi
+    lib = _capi.lib()
+    try:
+        for k, v in kw.items():
+            assert lib.oard_debug_option(k.encode(), v) == 0, k
+        yield lib
+    finally:
+        for k in kw:
+            lib.oard_debug_option(k.encode(), SUITE_OPTIONS[k])

@@ -13,8 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# debug options every GPU test starts from: NaN-poisoned workspace, and the launch-shape heuristics OFF so
+# that the small golden cases exercise the throughput kernels (the ones bench.py measures); the tests of the
+# heuristics / latency kernels switch them on explicitly (tests/_cases.py: debug_options(**LIB_AUTO))
+SUITE_OPTIONS = dict(gcl_variant=2, equi_variant=2, node_variant=1, gcl_skip=1, gcl_split=0, parts=0,
+                     auto_small=0, auto_tiny=0, poison=1)
+LIB_DEFAULTS = dict(SUITE_OPTIONS, auto_small=4, auto_tiny=2, poison=0)
+
+
 @pytest.fixture(autouse=True)
-def _poisoned_workspace(request):
+def _suite_options(request):
     """Every GPU test runs with the workspace filled with NaN bit patterns before each forward: the
     C ABI says the caller owns the workspace and its contents are arbitrary, so no kernel may depend on
     them (a padding feature read before it is written would turn the result into NaN)."""
@@ -23,6 +31,8 @@ def _poisoned_workspace(request):
         return
     from oareactdiff_amd import _capi
     lib = _capi.lib()
-    lib.oard_debug_option(b"poison", 1)
+    for k, v in SUITE_OPTIONS.items():
+        assert lib.oard_debug_option(k.encode(), v) == 0
     yield
-    lib.oard_debug_option(b"poison", 0)
+    for k, v in LIB_DEFAULTS.items():
+        lib.oard_debug_option(k.encode(), v)

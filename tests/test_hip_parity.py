@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import leftnet_oracle as oracle
-from _cases import ALL_CASES, Case, rel
+from _cases import ALL_CASES, LIB_AUTO, Case, debug_options, rel
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -25,12 +25,15 @@ def _args(c, dev):
             c.n_frag_switch.to(dev), c.combined_mask.to(dev))
 
 
+@pytest.mark.parametrize("shapes", ["throughput", "auto"])
 @pytest.mark.parametrize("name", ALL_CASES)
-def test_forward_matches_reference_f64(name):
+def test_forward_matches_reference_f64(name, shapes):
+    """shapes = "throughput": the kernels bench.py measures, whatever the size of the case; "auto": the library's
+    default launch-shape heuristics, which send these small cases to the latency kernels (oard_edge_small.h)."""
     dev = torch.device("cuda:0")
     c = Case(name)
     dyn = _dyn(c, dev)
-    with torch.no_grad():
+    with debug_options(**(LIB_AUTO if shapes == "auto" else {})), torch.no_grad():
         out, edge_attr = dyn(*_args(c, dev))
     assert edge_attr is None and len(out) == c.n_obj
     for k in range(c.n_obj):
@@ -131,7 +134,8 @@ def _random_case(sizes, pos_scale, seed, cfg):
 
 @pytest.mark.parametrize("sizes,pos_scale", [([7, 23, 12, 1, 16], 1.0), ([9, 30, 5], 2.5), ([40, 3], 1.5),
                                              ([1, 1], 1.0), ([2], 1.0)])
-def test_ragged_production_dims_vs_oracle(sizes, pos_scale):
+@pytest.mark.parametrize("shapes", ["throughput", "auto"])
+def test_ragged_production_dims_vs_oracle(sizes, pos_scale, shapes):
     """Ragged reactions (incl. a single-atom-per-object sample and groups > 32 atoms), with and without the
     cutoff biting, production dims, against the float64 oracle evaluated here on the same inputs; the last two
     cases have no same-object edge at all (A = 0) / a single reaction of two-atom objects."""
@@ -145,7 +149,7 @@ def test_ragged_production_dims_vs_oracle(sizes, pos_scale):
     dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
                        condition_nf=1, device=dev)
     dyn.load_state_dict(sd, strict=True)
-    with torch.no_grad():
+    with debug_options(**(LIB_AUTO if shapes == "auto" else {})), torch.no_grad():
         out, _ = dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
     ref = oracle.dynamics_forward({k: v.double() for k, v in sd.items()}, cfg, [x.double() for x in xh], ei,
                                   t.double(), cond.double(), nfs, cm, 1, nodeframe="exact")
@@ -193,6 +197,39 @@ def test_config5_large_reactions(pos_scale):
     rv = torch.cat([o[:, :3].reshape(-1) for o in ref])
     rh = torch.cat([o[:, 3:].reshape(-1) for o in ref])
     assert rel(v, rv) <= TOL and rel(h, rh) <= TOL, (rel(v, rv), rel(h, rh))
+
+
+@pytest.mark.parametrize("parts", [1, 0])
+def test_large_batch_needs_64bit_offsets(parts):
+    """B = 800 reactions on one GPU: 3.75 M edge rows x 688 floats = 2.58e9 elements (10.3 GB), beyond what a
+    32-bit element offset can address - as ONE launch (parts=1) and under the default sub-batch schedule.
+    Reactions are independent, so the first 64 must reproduce a B=64 launch of the same inputs."""
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
+    from oareactdiff_amd.synthetic import make_inputs, make_topology
+    dev = torch.device("cuda:0")
+    cfg = dict(PRODUCTION_LEFTNET_CONFIG, num_layers=2)
+    sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg, seed=7)
+    dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
+                       condition_nf=1, device=dev)
+    dyn.load_state_dict(sd, strict=True)
+    nf, B, b = 23, 800, 64
+    g = torch.Generator().manual_seed(3)
+    with debug_options(parts=parts):
+        cm, nfs, ei, masks = make_topology(B, nf)
+        assert ei.shape[1] * 688 > 2 ** 31
+        xh = make_inputs(B, nf, masks, 5, dev)
+        t, cond = torch.rand(B, 1, generator=g).to(dev), torch.rand(B, 1, generator=g).to(dev)
+        with torch.no_grad():
+            big, _ = dyn(xh, ei.to(dev), t, cond, nfs.to(dev), cm.to(dev))
+        cm2, nfs2, ei2, _ = make_topology(b, nf)
+        with torch.no_grad():
+            small, _ = dyn([x[:b * nf].clone() for x in xh], ei2.to(dev), t[:b], cond[:b], nfs2.to(dev), cm2.to(dev))
+    for x, y in zip(big, small):
+        assert bool(torch.isfinite(x).all())
+        assert rel(x[:b * nf, :3].cpu(), y[:, :3].cpu()) <= 1e-6 and rel(x[:b * nf, 3:].cpu(), y[:, 3:].cpu()) <= 1e-6
+    # and the tail of the batch is computed too (not left as the NaN poison / zeros)
+    assert float(big[1][-nf:, :3].abs().max()) > 0
 
 
 def test_scalar_t_equals_per_sample_t_and_input_is_not_mutated():
@@ -256,18 +293,16 @@ def test_concurrent_sub_batches_are_bitwise_identical(parts):
     dict(gcl_variant=1, equi_variant=1),
     dict(gcl_variant=3, equi_variant=3),
     dict(gcl_variant=4, equi_variant=2, gcl_skip=0),
+    dict(gcl_variant=5, equi_variant=4),                        # 3-waves-per-SIMD GCL; latency EquiMessage kernel
+    dict(gcl_variant=6, equi_variant=2),                        # latency GCL kernel
+    dict(gcl_variant=6, equi_variant=4, gcl_skip=0),
     dict(gcl_split=1), dict(gcl_split=2), dict(gcl_split=3), dict(gcl_split=4),
 ])
 def test_every_kernel_variant_is_parity_green(opts):
     """The A/B variants kept in the library (oard_debug_option) all compute the same thing."""
-    from oareactdiff_amd import _capi
     dev = torch.device("cuda:0")
-    L = _capi.lib()
-    defaults = dict(gcl_variant=2, equi_variant=2, node_variant=1, gcl_skip=1, gcl_split=0)
-    try:
-        for k, v in opts.items():
-            assert L.oard_debug_option(k.encode(), v) == 0
-        for name in ("g2s_prod_b1_n5", "g3_cutoff_ragged"):
+    with debug_options(**opts):
+        for name in ("g2s_prod_b1_n5", "g3_cutoff_ragged", "g2_prod_b2_n23"):
             c = Case(name)
             dyn = _dyn(c, dev)
             with torch.no_grad():
@@ -275,6 +310,3 @@ def test_every_kernel_variant_is_parity_green(opts):
             v, h = c.split([o.cpu() for o in out])
             rv, rh = c.split(c.ref64)
             assert rel(v, rv) <= TOL and rel(h, rh) <= TOL, (opts, name, rel(v, rv), rel(h, rh))
-    finally:
-        for k, v in defaults.items():
-            L.oard_debug_option(k.encode(), v)
