@@ -56,6 +56,7 @@ int g_auto_tiny = 2;        // launches of <= 512 * g_auto_tiny edge tiles (all 
                             //    latency kernels of oard_edge_small.h (8 waves share 16 edges); 0 = never
 int g_auto_small = 4;       // 1: small launches use the 4-wave workgroups (one wave per SIMD instead of two): a launch that cannot
                             //    fill the chip anyway finishes sooner when its waves do not share a SIMD (B <= 8 reactions: -25 %)
+int g_npb = 0;              // nodes per workgroup of the node stages (0 = auto, see oard_topology_create)
 int g_poison = 0;           // 1: fill the workspace with NaN bit patterns before every forward (tests: nothing may depend on its contents)
 int g_parts = 0;            // sub-batches per topology (0 = auto: 4 for B >= 32, 2 for B >= 16, else 1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
@@ -72,6 +73,8 @@ struct ScopedLaunch {
 };
 #define LAUNCH(fam, kern, grid, block, stream, ...) do { ScopedLaunch sl_(fam, stream); \
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), 0, stream, __VA_ARGS__); } while (0)
+#define LAUNCH2(fam, kern, gx, gy, block, stream, ...) do { ScopedLaunch sl_(fam, stream); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy)), dim3(block), 0, stream, __VA_ARGS__); } while (0)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -373,9 +376,23 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     }
     LAUNCH(F_INIT, (k_node_embed<D>), gN, 256, st, tp, wb, po, (const float*)hin, zemb, nb);
     if (A > 0) LAUNCH(F_INIT, (k_radial_lin<D>), gA, 256, st, tp, wb, po, (const float*)rbuf, (const float*)geo, ew);
-    LAUNCH(F_INIT, (k_neighbor<D>), gN, 256, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s, s1);
-    LAUNCH(F_INIT, (k_s2v_agg<D>), gN, 256, st, tp, (const float*)s1, (const float*)ew, (const float*)geo, ne1);
-    if (A > 0) LAUNCH(F_INIT, (k_scalarize<D>), gA, 256, st, tp, wb, po, (const float*)ne1, (const float*)geo, ew);
+    // waves per workgroup of the v1 node stages: one per hidden tile (13 at H = 196), so that every wave owns
+    // exactly one tile of each H-wide layer
+#ifndef OARD_NODE_WAVES
+    constexpr int NW = D::HT <= 16 ? D::HT : 8;
+#else
+    constexpr int NW = OARD_NODE_WAVES;
+#endif
+    const unsigned gNb = (unsigned)cdiv(N, tp.npb);
+    if (g_node_variant >= 1) {
+        LAUNCH(F_INIT, (k_neighbor_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s, s1);
+        LAUNCH(F_INIT, (k_s2v_agg_v1<D, NW>), gNb, NW * 64, st, tp, (const float*)s1, (const float*)ew, (const float*)geo, ne1);
+    } else {
+        LAUNCH(F_INIT, (k_neighbor<D>), gN, 256, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s, s1);
+        LAUNCH(F_INIT, (k_s2v_agg<D>), gN, 256, st, tp, (const float*)s1, (const float*)ew, (const float*)geo, ne1);
+    }
+    // small launches: one workgroup per (64 edges, hidden tile) instead of per 64 edges
+    if (A > 0) LAUNCH2(F_INIT, (k_scalarize<D>), gA, (gA * topo->conc <= 2048 ? D::HT : 1), 256, st, tp, wb, po, (const float*)ne1, (const float*)geo, ew);
     HIP_TRY(hipMemsetAsync(vec, 0, (size_t)N * 3 * D::HP * sizeof(float), st));
     if (g_stop_after == 1) return OARD_OK;
 
@@ -385,8 +402,9 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     for (int l = 0; l < c->num_layers; ++l) {
         const LayerOff lo = po.layer[l];
         const bool nv1 = g_node_variant == 1 && g_equi_variant != 0;
-        const unsigned gN16 = (unsigned)cdiv(N, OARD_NPB);
-        if (nv1) LAUNCH(F_NODE, (k_node_pre_v1<D, 8>), gN16, 512, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
+        const unsigned gN16 = (unsigned)cdiv(N, tp.npb);
+
+        if (nv1) LAUNCH(F_NODE, (k_node_pre_v1<D, NW>), gN16, NW * 64, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
         else LAUNCH(F_NODE, (k_node_pre<D>), gN, 256, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
         if (E > 0) {
             if (g_gcl_variant == 0) {
@@ -398,7 +416,7 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
             }
         }
         hipStream_t sn = st;
-        if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, 8>), gN16, 512, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
+        if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW>), gN16, NW * 64, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
         else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
         if (g_stop_after == 100 + 10 * l + 1) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
         if (g_equi_variant == 0) {
@@ -412,7 +430,7 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                 if (rc != OARD_OK) return rc;
             }
             if (nv1) {
-                LAUNCH(F_NODE, (k_equi_node_v1<D, 8>), gN16, 512, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
+                LAUNCH(F_NODE, (k_equi_node_v1<D, NW>), gN16, NW * 64, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
                        (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext);
             } else {
                 LAUNCH(F_NODE, (k_equi_agg_v1<D>), gN, 256, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
@@ -425,7 +443,10 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
         if (g_stop_after == 100 + 10 * l + 2) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
     }
     topo->vec_final = (size_t)((char*)vcur - ws);
-    LAUNCH(F_NODE, (k_out<D>), gN, 256, st, tp, wb, po, (const float*)s, (const float*)vcur, dpos, hout, status);
+    if (g_node_variant >= 1)
+        LAUNCH(F_NODE, (k_out_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)s, (const float*)vcur, dpos, hout, status);
+    else
+        LAUNCH(F_NODE, (k_out<D>), gN, 256, st, tp, wb, po, (const float*)s, (const float*)vcur, dpos, hout, status);
     LAUNCH(F_OTHER, k_post, cdiv(N, 128), 128, st, tp, op, wb, (const float*)dpos, (const float*)hout, emb);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
@@ -699,6 +720,10 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
         tp->N += tp->parts[p].d.N; tp->E += tp->parts[p].d.E; tp->A += tp->parts[p].d.A;
         tp->parts[p].conc = n_parts;
     }
+    {   // node-stage workgroup shape: about one workgroup per CU over all concurrent sub-batches, at most 16 nodes each
+        const int npb = g_npb > 0 ? g_npb : (int)std::max<long long>(1, std::min<long long>(16, cdiv(tp->N, 256)));
+        for (int p = 0; p < n_parts; ++p) tp->parts[p].d.npb = npb;
+    }
     if (n_parts > 1) {
         HIP_TRY(hipEventCreateWithFlags(&tp->ev_fork, hipEventDisableTiming));
         for (int p = 1; p < n_parts; ++p) {
@@ -864,6 +889,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "poison") == 0) { g_poison = value; return OARD_OK; }
     if (strcmp(name, "auto_small") == 0) { g_auto_small = value; return OARD_OK; }
     if (strcmp(name, "auto_tiny") == 0) { g_auto_tiny = value; return OARD_OK; }
+    if (strcmp(name, "npb") == 0) { g_npb = value; return OARD_OK; }
     return OARD_EINVAL;
 }
 int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }

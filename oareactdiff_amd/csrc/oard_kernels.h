@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256) void k_scalarize(TopoDev tp, const float* __re
     const float* w2 = b0 + D::H4;
     const float b2 = w2[D::H4];
     const size_t row = (size_t)a * D::WP;
-    for (int t = 0; t < D::HT; ++t) {
+    // gridDim.y > 1 spreads the hidden tiles of an edge block over several workgroups (small launches)
+    for (int t = blockIdx.y; t < D::HT; t += gridDim.y) {
         if (16 * t + 4 * id.g >= D::H) continue;
 #pragma unroll
         for (int side = 0; side < 2; ++side) {

@@ -58,6 +58,7 @@ struct PackOff {
 // ---- topology tables (device pointers) -----------------------------------------------------------
 struct TopoDev {
     int N, B, n_obj, n_groups;
+    int npb;       // real nodes per 16-column workgroup of the node stages (< 16 on small batches: more workgroups)
     long long E, A;
     const int *node_obj, *node_row, *node_ref, *node_tidx, *node_sample, *sample_ptr;
     const int *edge_ptr, *edge_src, *edge_tgt;   // implicit ("logical") edge ids: node n owns ids edge_ptr[n] + rank

@@ -43,6 +43,50 @@ OARD_DEV f4 dense_tile_lds(const float* __restrict__ wp, int t, const float* in,
     return c0 + c1;
 }
 
+// A sequence of N output tiles, software-pipelined: the weight chunks of step s+1 (a step = up to 13 chunks of
+// one tile) are requested before the MFMAs of step s are issued, so the L2 round trip of every step but the
+// first hides behind the previous step's MFMAs.  job[j].w = first chunk of the tile (lane offset included by
+// the callee), job[j].in = LDS input vector; acc[j] carries the initial value in and the result out.
+struct TileJob {
+    const float* w;
+    const float* in;
+};
+template <int KB>
+OARD_DEV TileJob tile_job(const float* __restrict__ wp, int t, const float* in) {
+    return TileJob{wp + (size_t)t * KB * 256, in};
+}
+#ifndef OARD_NODE_SEQ_G
+#define OARD_NODE_SEQ_G 7       // chunks per pipeline step (2 x 7 x 4 VGPRs of weights in flight)
+#endif
+template <int KB, int N>
+OARD_DEV void dense_seq(const TileJob (&job)[N], int lane, f4 (&acc)[N]) {
+    constexpr int G = OARD_NODE_SEQ_G, NG = (KB + G - 1) / G, S = N * NG;
+    f4 a[2][G];
+    f4 c1 = f4zero();
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+        if (i < KB) a[0][i] = ld_f4(job[0].w + (size_t)i * 256 + lane * 4);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+        const int j = st / NG, q = st % NG;
+        if (st + 1 < S) {
+            const int j1 = (st + 1) / NG, q1 = (st + 1) % NG;
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                if (q1 * G + i < KB) a[(st + 1) & 1][i] = ld_f4(job[j1].w + (size_t)(q1 * G + i) * 256 + lane * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (q * G + i < KB) {
+                const f4 x = lds_blk(job[j].in, q * G + i, lane);
+                if (i & 1) c1 = mma_chunk(a[st & 1][i], x, c1);
+                else acc[j] = mma_chunk(a[st & 1][i], x, acc[j]);
+            }
+        if (q == NG - 1) { acc[j] += c1; c1 = f4zero(); }
+    }
+}
+
 // LayerNorm statistics of an LDS vector (every wave computes them redundantly)
 template <int HT, int H>
 OARD_DEV void ln_stats_lds(const float* v, int lane, float& mean, float& rstd) {
@@ -78,16 +122,14 @@ struct NodeBlk {
     int lane, wave, g, n;
     bool valid;
 };
-// NPB = real nodes per workgroup (<= 16): fewer than 16 leaves MFMA columns empty but doubles the
-// number of workgroups, which is what these latency-bound stages need at N = 4416
-#ifndef OARD_NPB
-#define OARD_NPB 16
-#endif
-OARD_DEV NodeBlk node_blk(int N) {
+// npb = real nodes per workgroup (<= 16; TopoDev::npb, chosen by the host): fewer than 16 leaves MFMA columns
+// empty but multiplies the number of workgroups, which is what these latency-bound stages need on small
+// batches (at B = 1 sixteen nodes per workgroup would put the whole layer on 5 CUs)
+OARD_DEV NodeBlk node_blk(int N, int npb) {
     NodeBlk b;
     b.lane = threadIdx.x & 63; b.wave = threadIdx.x >> 6; b.g = b.lane >> 4;
-    const int c = blockIdx.x * OARD_NPB + (b.lane & 15);
-    b.valid = (b.lane & 15) < OARD_NPB && c < N;
+    const int c = blockIdx.x * npb + (b.lane & 15);
+    b.valid = (b.lane & 15) < npb && c < N;
     b.n = b.valid ? c : N - 1;
     return b;
 }
@@ -104,7 +146,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_node_pre_v1(TopoDev tp, const fl
     float* hid = sm;                      // [PB]
     float* sv = sm + D::PB * 256;         // [HT]
     float* xv = sv + D::HT * 256;         // [HT]
-    const NodeBlk nb = node_blk(tp.N);
+    const NodeBlk nb = node_blk(tp.N, tp.npb);
     const float pp = pp0[nb.n];
     for (int b = nb.wave; b < D::PB; b += WAVES) {
         const int k0 = 16 * b + 4 * nb.g;
@@ -117,8 +159,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_node_pre_v1(TopoDev tp, const fl
         lds_st(hid, b, nb.lane, h);
     }
     __syncthreads();
-    for (int t = nb.wave; t < D::HT; t += WAVES)
-        lds_st(sv, t, nb.lane, dense_tile_lds<D::PB>(wb + po.pe1, t, hid, nb.lane, ld_blk(s, nb.n, D::HP, t, nb.lane)));
+    constexpr int TPW = (D::HT + WAVES - 1) / WAVES, TPW2 = (2 * D::HT + WAVES - 1) / WAVES;
+    {
+        TileJob job[TPW];
+        f4 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = min(nb.wave + i * WAVES, D::HT - 1);
+            job[i] = tile_job<D::PB>(wb + po.pe1, t, hid);
+            acc[i] = ld_blk(s, nb.n, D::HP, t, nb.lane);
+        }
+        dense_seq<D::PB, TPW>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (nb.wave + i * WAVES < D::HT) lds_st(sv, nb.wave + i * WAVES, nb.lane, acc[i]);
+    }
     __syncthreads();
     float mean, rstd;
     ln_stats_lds<D::HT, D::H>(sv, nb.lane, mean, rstd);
@@ -128,13 +183,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_node_pre_v1(TopoDev tp, const fl
         if (nb.valid) st_blk(xh, nb.n, D::HP, t, nb.lane, y);
     }
     __syncthreads();
-    for (int t = nb.wave; t < 2 * D::HT; t += WAVES) {
-        if (t < D::HT) {
-            const f4 p = dense_tile_lds<D::HT>(wb + lo.W1a, t, xv, nb.lane, ld_vec(wb + lo.b1, t, nb.lane));
-            if (nb.valid) st_blk(P, nb.n, D::HP, t, nb.lane, p);
-        } else {
-            const f4 q = dense_tile_lds<D::HT>(wb + lo.W1b, t - D::HT, xv, nb.lane, f4zero());
-            if (nb.valid) st_blk(Q, nb.n, D::HP, t - D::HT, nb.lane, q);
+    {
+        TileJob job[TPW2];
+        f4 acc[TPW2];
+#pragma unroll
+        for (int i = 0; i < TPW2; ++i) {
+            const int t = min(nb.wave + i * WAVES, 2 * D::HT - 1);
+            job[i] = t < D::HT ? tile_job<D::HT>(wb + lo.W1a, t, xv) : tile_job<D::HT>(wb + lo.W1b, t - D::HT, xv);
+            acc[i] = t < D::HT ? ld_vec(wb + lo.b1, t, nb.lane) : f4zero();
+        }
+        dense_seq<D::HT, TPW2>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW2; ++i) {
+            const int t = nb.wave + i * WAVES;
+            if (t < 2 * D::HT && nb.valid) {
+                if (t < D::HT) st_blk(P, nb.n, D::HP, t, nb.lane, acc[i]);
+                else st_blk(Q, nb.n, D::HP, t - D::HT, nb.lane, acc[i]);
+            }
         }
     }
 }
@@ -150,9 +215,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
     float* in = sm;                        // [2 HT]: xh | agg      (later: xln | hq)
     float* hm = sm + 2 * D::HT * 256;      // [HT]
     float* sv = sm + 3 * D::HT * 256;      // [HT]
-    const NodeBlk nb = node_blk(tp.N);
+    const NodeBlk nb = node_blk(tp.N, tp.npb);
     const int smp = tp.node_sample[nb.n];
-    const int deg = tp.sample_ptr[smp + 1] - tp.sample_ptr[smp] - 1;
+    const int deg = nb.valid ? tp.sample_ptr[smp + 1] - tp.sample_ptr[smp] - 1 : 0;
     const size_t e0 = (size_t)tp.edge_ptr[nb.n];
     const int mx = wave_max(deg);
     const float inv = 1.0f / (float)max(deg, 1);
@@ -178,14 +243,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
         lds_st(in, D::HT + t, nb.lane, (a0 + a1) * inv);
     }
     __syncthreads();
-    for (int t = nb.wave; t < D::HT; t += WAVES)
-        lds_st(hm, t, nb.lane, silu4(dense_tile_lds<2 * D::HT>(wb + lo.nm0, t, in, nb.lane, ld_vec(wb + lo.nm0b, t, nb.lane))));
+    constexpr int TPW = (D::HT + WAVES - 1) / WAVES, TPW3 = (3 * D::HT + WAVES - 1) / WAVES;
+    int tw[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) tw[i] = min(nb.wave + i * WAVES, D::HT - 1);
+    {
+        TileJob job[TPW];
+        f4 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { job[i] = tile_job<2 * D::HT>(wb + lo.nm0, tw[i], in); acc[i] = ld_vec(wb + lo.nm0b, tw[i], nb.lane); }
+        dense_seq<2 * D::HT, TPW>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (nb.wave + i * WAVES < D::HT) lds_st(hm, tw[i], nb.lane, silu4(acc[i]));
+    }
     __syncthreads();
-    for (int t = nb.wave; t < D::HT; t += WAVES) {
-        const f4 v = lds_blk(in, t, nb.lane) +
-                     dense_tile_lds<D::HT>(wb + lo.nm1, t, hm, nb.lane, ld_vec(wb + lo.nm1b, t, nb.lane));
-        lds_st(sv, t, nb.lane, v);
-        if (nb.valid) st_blk(s, nb.n, D::HP, t, nb.lane, v);
+    {
+        TileJob job[TPW];
+        f4 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { job[i] = tile_job<D::HT>(wb + lo.nm1, tw[i], hm); acc[i] = ld_vec(wb + lo.nm1b, tw[i], nb.lane); }
+        dense_seq<D::HT, TPW>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (nb.wave + i * WAVES < D::HT) {
+                const f4 v = lds_blk(in, tw[i], nb.lane) + acc[i];
+                lds_st(sv, tw[i], nb.lane, v);
+                if (nb.valid) st_blk(s, nb.n, D::HP, tw[i], nb.lane, v);
+            }
     }
     __syncthreads();
     float mean, rstd;
@@ -195,13 +280,61 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
     for (int t = nb.wave; t < D::HT; t += WAVES)
         lds_st(xln, t, nb.lane, ln_apply<D::H>(lds_blk(sv, t, nb.lane), mean, rstd, wb + lo.ln_q_w, wb + lo.ln_q_b, t, nb.lane));
     __syncthreads();
-    for (int t = nb.wave; t < D::HT; t += WAVES)
-        lds_st(hq, t, nb.lane, silu4(dense_tile_lds<D::HT>(wb + lo.xp0, t, xln, nb.lane, f4zero())));
-    __syncthreads();
-    for (int t = nb.wave; t < 3 * D::HT; t += WAVES) {
-        const f4 o = dense_tile_lds<D::HT>(wb + lo.xp2, t, hq, nb.lane, f4zero());
-        if (nb.valid) st_blk(xq, nb.n, 3 * D::HP, t, nb.lane, o);
+    {
+        TileJob job[TPW];
+        f4 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { job[i] = tile_job<D::HT>(wb + lo.xp0, tw[i], xln); acc[i] = f4zero(); }
+        dense_seq<D::HT, TPW>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (nb.wave + i * WAVES < D::HT) lds_st(hq, tw[i], nb.lane, silu4(acc[i]));
     }
+    __syncthreads();
+    {
+        TileJob job[TPW3];
+        f4 acc[TPW3];
+#pragma unroll
+        for (int i = 0; i < TPW3; ++i) {
+            job[i] = tile_job<D::HT>(wb + lo.xp2, min(nb.wave + i * WAVES, 3 * D::HT - 1), hq);
+            acc[i] = f4zero();
+        }
+        dense_seq<D::HT, TPW3>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW3; ++i)
+            if (nb.wave + i * WAVES < 3 * D::HT && nb.valid) st_blk(xq, nb.n, 3 * D::HP, nb.wave + i * WAVES, nb.lane, acc[i]);
+    }
+}
+
+// EquiUpdate's frame-scalar MLP (Linear(3,48) SiLU Linear(48,8) SiLU Linear(8,1) on (x, 0, 0), see lin3u) for the
+// four features of a lane at once, first two layers from an LDS copy laid out per hidden unit k as
+// [w2[0..7][k], w0[k][0], b0[k], -, -] (12 floats): three broadcast LDS reads per k instead of ten dependent
+// scalar loads per k and per value
+OARD_DEV void lin3u_stage(const float* __restrict__ p, float* l3s, int tid, int nthreads) {
+    for (int i = tid; i < 48 * 12; i += nthreads) {
+        const int k = i / 12, j = i % 12;
+        l3s[i] = j < 8 ? p[192 + j * 48 + k] : (j == 8 ? p[3 * k] : (j == 9 ? p[144 + k] : 0.f));
+    }
+}
+OARD_DEV f4 lin3u4(const float* l3s, const float* __restrict__ p, f4 x) {
+    const float* b2 = p + 576;
+    const float* w4 = p + 584;
+    f4 h2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h2[j] = (f4){b2[j], b2[j], b2[j], b2[j]};
+#pragma unroll 4
+    for (int k = 0; k < 48; ++k) {
+        const f4 wa = *reinterpret_cast<const f4*>(l3s + 12 * k), wc = *reinterpret_cast<const f4*>(l3s + 12 * k + 4);
+        const float w0 = l3s[12 * k + 8], b0 = l3s[12 * k + 9];
+        const f4 h = silu4(x * w0 + b0);
+        h2[0] += h * wa.x; h2[1] += h * wa.y; h2[2] += h * wa.z; h2[3] += h * wa.w;
+        h2[4] += h * wc.x; h2[5] += h * wc.y; h2[6] += h * wc.z; h2[7] += h * wc.w;
+    }
+    const float b4 = p[592];
+    f4 o = (f4){b4, b4, b4, b4};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o += silu4(h2[j]) * w4[j];
+    return o;
 }
 
 // =====================================================================================================
@@ -217,12 +350,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                                                              float* __restrict__ vec_out) {
     constexpr int HT = D::HT;
     constexpr int TPW = (HT + WAVES - 1) / WAVES;            // tiles owned per wave (upper bound)
-    __shared__ __attribute__((aligned(16))) float sm[6 * HT * 256];
+    __shared__ __attribute__((aligned(16))) float sm[6 * HT * 256 + 48 * 12];
+    float* l3s = sm + 6 * HT * 256;        // frame-scalar MLP weights (lin3u_stage)
+    lin3u_stage(wb + lo.l3u, l3s, threadIdx.x, WAVES * 64);        // visible after the first barrier below
     float* vx = sm;                        // [3][HT] updated vec
     float* in = sm + 3 * HT * 256;         // [2 HT]: s_mid | scal
     float* hx = sm + 5 * HT * 256;         // [HT]
-    const NodeBlk nb = node_blk(tp.N);
-    const int n = nb.n, a0 = tp.act_ptr[n], cnt = tp.act_ptr[n + 1] - a0;
+    const NodeBlk nb = node_blk(tp.N, tp.npb);
+    const int n = nb.n, a0 = tp.act_ptr[n], cnt = nb.valid ? tp.act_ptr[n + 1] - a0 : 0;
     const int mx = wave_max(cnt);
     const float inv_sqrt2 = 0.70710678118654752f, inv_sqrt3 = 0.57735026918962576f,
                 inv_sqrt_h = 1.0f / sqrtf((float)D::H);
@@ -234,6 +369,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                  xn2 = ld_blk(xq, n, 3 * D::HP, 2 * HT + t, nb.lane);
         // two edges in flight per step, branch-free (out-of-range slots re-read a valid edge and are discarded)
         const long long a_hi = max(tp.A - 1, 0LL);
+        int mnext[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mnext[i] = tp.act_src[(size_t)min((long long)a0 + min(i, max(cnt - 1, 0)), a_hi)];
 #ifdef OARD_ABL_NOGATHER
         for (int k = 0; k < 0; k += 2) {
 #else
@@ -241,10 +379,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
 #endif
             f4 q0[2], q1[2], q2[2], y0[2], y1[2], y2[2], w0[2], w1[2], w2[2];
             float gx[2], gy[2], gz[2];
+            const int mc[2] = {mnext[0], mnext[1]};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)          // source nodes of the NEXT step: their latency hides behind this step's gathers
+                mnext[i] = tp.act_src[(size_t)min((long long)a0 + min(k + 2 + i, max(cnt - 1, 0)), a_hi)];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const size_t a = (size_t)min((long long)a0 + min(k + i, max(cnt - 1, 0)), a_hi);
-                const int m = tp.act_src[a];
+                const int m = mc[i];
                 const float* g = geo + a * GEO_STRIDE;
                 gx[i] = g[2]; gy[i] = g[3]; gz[i] = g[4];
                 q0[i] = ld_blk(qbuf, a, 3 * D::HP, t, nb.lane); q1[i] = ld_blk(qbuf, a, 3 * D::HP, HT + t, nb.lane);
@@ -280,14 +422,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int t = nb.wave + i * WAVES;
-        if (t < HT) {
-            f4 v1[3], v2[3];
+        if (t < HT) {                                    // wave-uniform
+            TileJob job[6];
+            f4 acc[6];
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
-                v1[x] = dense_tile_lds<HT>(wb + lo.vp, t, vx + x * HT * 256, nb.lane, f4zero());
-                v2[x] = dense_tile_lds<HT>(wb + lo.vp, HT + t, vx + x * HT * 256, nb.lane, f4zero());
-                v2k[i][x] = v2[x];
+                job[2 * x] = tile_job<HT>(wb + lo.vp, t, vx + x * HT * 256);
+                job[2 * x + 1] = tile_job<HT>(wb + lo.vp, HT + t, vx + x * HT * 256);
+                acc[2 * x] = f4zero(); acc[2 * x + 1] = f4zero();
             }
+            dense_seq<HT, 6>(job, nb.lane, acc);
+            const f4 v1[3] = {acc[0], acc[2], acc[4]}, v2[3] = {acc[1], acc[3], acc[5]};
+#pragma unroll
+            for (int x = 0; x < 3; ++x) v2k[i][x] = v2[x];
             const f4 sc = v1[0] * fx + v1[1] * fy + v1[2] * fz;
             vdk[i] = (v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2]) * inv_sqrt_h;
             f4 sca;
@@ -295,10 +442,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
 #ifdef OARD_ABL_NOLIN3U
             sca = sc;
 #else
-            sca.x = f0 + 0 < D::H ? lin3u(l3, sc.x) : 0.f;
-            sca.y = f0 + 1 < D::H ? lin3u(l3, sc.y) : 0.f;
-            sca.z = f0 + 2 < D::H ? lin3u(l3, sc.z) : 0.f;
-            sca.w = f0 + 3 < D::H ? lin3u(l3, sc.w) : 0.f;
+            sca = lin3u4(l3s, l3, sc);
+            sca.x = f0 + 0 < D::H ? sca.x : 0.f; sca.y = f0 + 1 < D::H ? sca.y : 0.f;
+            sca.z = f0 + 2 < D::H ? sca.z : 0.f; sca.w = f0 + 3 < D::H ? sca.w : 0.f;
 #endif
             lds_st(in, HT + t, nb.lane, sca);
         }
@@ -306,19 +452,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
     __syncthreads();
 
     // 3. xvec_proj hidden
-    for (int t = nb.wave; t < HT; t += WAVES)
-        lds_st(hx, t, nb.lane, silu4(dense_tile_lds<2 * HT>(wb + lo.xv0, t, in, nb.lane, f4zero())));
+    {
+        TileJob job[TPW];
+        f4 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { job[i] = tile_job<2 * HT>(wb + lo.xv0, min(nb.wave + i * WAVES, HT - 1), in); acc[i] = f4zero(); }
+        dense_seq<2 * HT, TPW>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (nb.wave + i * WAVES < HT) lds_st(hx, nb.wave + i * WAVES, nb.lane, silu4(acc[i]));
+    }
     __syncthreads();
 
     // 4. outputs for owned tiles
+    {
+        TileJob job[3 * TPW];
+        f4 acc[3 * TPW];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int t = nb.wave + i * WAVES;
-        if (t < HT) {
-            const f4 a = dense_tile_lds<HT>(wb + lo.xv2, t, hx, nb.lane, f4zero());
-            const f4 b = dense_tile_lds<HT>(wb + lo.xv2, HT + t, hx, nb.lane, f4zero());
-            const f4 c = dense_tile_lds<HT>(wb + lo.xv2, 2 * HT + t, hx, nb.lane, f4zero());
-            if (nb.valid) {
+        for (int i = 0; i < TPW; ++i) {
+            const int t = min(nb.wave + i * WAVES, HT - 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { job[3 * i + k] = tile_job<HT>(wb + lo.xv2, k * HT + t, hx); acc[3 * i + k] = f4zero(); }
+        }
+        dense_seq<HT, 3 * TPW>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = nb.wave + i * WAVES;
+            if (t < HT && nb.valid) {
+                const f4 a = acc[3 * i], b = acc[3 * i + 1], c = acc[3 * i + 2];
                 st_blk(s, n, D::HP, t, nb.lane, lds_blk(in, t, nb.lane) + (a + b + vdk[i]) * inv_sqrt2);
 #pragma unroll
                 for (int x = 0; x < 3; ++x)
@@ -326,5 +487,206 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                            lds_blk(vx + x * HT * 256, t, nb.lane) + c * v2k[i][x]);
             }
         }
+    }
+}
+
+// =====================================================================================================
+// init / output node stages in the same shape (WAVES waves share tp.npb nodes, one hidden tile per wave)
+// =====================================================================================================
+// NeighborEmb aggregation + s2v.lin1 (see k_neighbor):  s = z_emb + sum_m f(m->n) * nb[m];  s1 = SiLU(LN0(Linear(s)))
+template <class D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_neighbor_v1(TopoDev tp, const float* __restrict__ wb, PackOff po,
+                                                            const float* __restrict__ zemb, const float* __restrict__ nbe,
+                                                            const float* __restrict__ ew, float* __restrict__ s,
+                                                            float* __restrict__ s1) {
+    constexpr int HT = D::HT, TPW = (HT + WAVES - 1) / WAVES;
+    __shared__ __attribute__((aligned(16))) float sm[2 * HT * 256];
+    float* sv = sm;
+    float* yv = sm + HT * 256;
+    const NodeBlk nb = node_blk(tp.N, tp.npb);
+    const int n = nb.n, smp = tp.node_sample[n], s0 = tp.sample_ptr[smp];
+    const int ns = nb.valid ? tp.sample_ptr[smp + 1] - s0 : 0;
+    const int mx = wave_max(ns);
+    const int self = n - s0;
+    const float* c0f = wb + po.c0row + 2 * D::H;
+    for (int t = nb.wave; t < HT; t += WAVES) {
+        f4 acc = ld_blk(zemb, n, D::HP, t, nb.lane);
+        const bool fok = 16 * t + 4 * nb.g < D::H;                 // the f section is H wide, not HP
+        const int fo = 16 * t + 4 * nb.g;
+        // four neighbours in flight per step; slot k of the sample is node s0 + k, the own slot is skipped
+        for (int k = 0; k < mx; k += 4) {
+            int r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = min(k + i, max(ns - 1, 0)), m = s0 + kk;
+                r[i] = kk == self ? -1 : tp.edge_row[tp.edge_ptr[m] + self - (self > kk ? 1 : 0)];
+            }
+            f4 f[4], x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = min(k + i, max(ns - 1, 0));
+                const float* frow = (r[i] >= 0 && r[i] < tp.A) ? ew + (size_t)r[i] * D::WP + 2 * D::H : c0f;
+                f[i] = fok ? ld_f4(frow + fo) : f4zero();
+                x[i] = ld_blk(nbe, s0 + kk, D::HP, t, nb.lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (k + i < ns && r[i] >= 0) acc += f[i] * x[i];
+        }
+        lds_st(sv, t, nb.lane, acc);
+        if (nb.valid) st_blk(s, n, D::HP, t, nb.lane, acc);
+    }
+    __syncthreads();
+    {
+        TileJob job[TPW];
+        f4 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = min(nb.wave + i * WAVES, HT - 1);
+            job[i] = tile_job<HT>(wb + po.s2v, t, sv);
+            acc[i] = ld_vec(wb + po.s2v_b, t, nb.lane);
+        }
+        dense_seq<HT, TPW>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (nb.wave + i * WAVES < HT) lds_st(yv, nb.wave + i * WAVES, nb.lane, acc[i]);
+    }
+    __syncthreads();
+    float mean, rstd;
+    ln_stats_lds<HT, D::H>(yv, nb.lane, mean, rstd);
+    for (int t = nb.wave; t < HT; t += WAVES) {
+        const int f0 = 16 * t + 4 * nb.g;
+        f4 y = (lds_blk(yv, t, nb.lane) - mean) * rstd;
+        y.x = f0 + 0 < D::H ? y.x : 0.f; y.y = f0 + 1 < D::H ? y.y : 0.f;
+        y.z = f0 + 2 < D::H ? y.z : 0.f; y.w = f0 + 3 < D::H ? y.w : 0.f;
+        if (nb.valid) st_blk(s1, n, D::HP, t, nb.lane, silu4(y));
+    }
+}
+
+// CFConvS2V aggregation (see k_s2v_agg):  NE1[n][x][:] = sum_{m active->n} f(m->n) * s1[m] * coord_diff(m->n)[x]
+template <class D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_s2v_agg_v1(TopoDev tp, const float* __restrict__ s1,
+                                                           const float* __restrict__ ew, const float* __restrict__ geo,
+                                                           float* __restrict__ ne1) {
+    constexpr int HT = D::HT;
+    const NodeBlk nb = node_blk(tp.N, tp.npb);
+    const int n = nb.n, a0 = tp.act_ptr[n], cnt = nb.valid ? tp.act_ptr[n + 1] - a0 : 0;
+    const int mx = wave_max(cnt);
+    const long long a_hi = max(tp.A - 1, 0LL);
+    for (int t = nb.wave; t < HT; t += WAVES) {
+        f4 ax = f4zero(), ay = f4zero(), az = f4zero();
+        const bool fok = 16 * t + 4 * nb.g < D::H;
+        for (int k = 0; k < mx; k += 4) {
+            f4 f[4], x[4];
+            float gx[4], gy[4], gz[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const size_t a = (size_t)min((long long)a0 + min(k + i, max(cnt - 1, 0)), a_hi);
+                const int m = tp.act_src[a];
+                const float* g = geo + a * GEO_STRIDE;
+                gx[i] = g[2]; gy[i] = g[3]; gz[i] = g[4];
+                f[i] = fok ? ld_f4(ew + a * D::WP + 2 * D::H + 16 * t + 4 * nb.g) : f4zero();
+                x[i] = ld_blk(s1, m, D::HP, t, nb.lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (k + i < cnt) {
+                    const f4 p = f[i] * x[i];
+                    ax += p * gx[i]; ay += p * gy[i]; az += p * gz[i];
+                }
+        }
+        if (nb.valid) {
+            st_blk(ne1, (size_t)n * 3 + 0, D::HP, t, nb.lane, ax);
+            st_blk(ne1, (size_t)n * 3 + 1, D::HP, t, nb.lane, ay);
+            st_blk(ne1, (size_t)n * 3 + 2, D::HP, t, nb.lane, az);
+        }
+    }
+}
+
+// output block (see k_out): dpos = gate * vec2_proj(vec), gate from update_net([s, |vec1_proj(vec)|]); h_out = embedding_out(s)
+template <class D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_out_v1(TopoDev tp, const float* __restrict__ wb, PackOff po,
+                                                       const float* __restrict__ s, const float* __restrict__ vec,
+                                                       float* __restrict__ dpos, float* __restrict__ hout,
+                                                       int* __restrict__ status) {
+    constexpr int HT = D::HT, TPW = (HT + WAVES - 1) / WAVES;
+    __shared__ __attribute__((aligned(16))) float sm[6 * HT * 256 + 3 * 16 * 16];
+    float* vx = sm;                        // [3][HT]
+    float* in = sm + 3 * HT * 256;         // [2 HT]: s | |vec1_proj(vec)|
+    float* hu = sm + 5 * HT * 256;         // [HT]
+    float* red = sm + 6 * HT * 256;        // [3][16 waves][16 columns] partial vec2_proj sums
+    const NodeBlk nb = node_blk(tp.N, tp.npb);
+    const int n = nb.n;
+    float part[3] = {0.f, 0.f, 0.f};
+    for (int t = nb.wave; t < HT; t += WAVES) {
+        const f4 w = ld_vec(wb + po.v2p, t, nb.lane);
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            const f4 v = ld_blk(vec, (size_t)n * 3 + x, D::HP, t, nb.lane);
+            lds_st(vx + x * HT * 256, t, nb.lane, v);
+            part[x] += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+        }
+        lds_st(in, t, nb.lane, ld_blk(s, n, D::HP, t, nb.lane));
+    }
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        const float p = col_reduce(part[x]);
+        if (nb.g == 0 && nb.wave < 16) red[(x * 16 + nb.wave) * 16 + (nb.lane & 15)] = p;
+    }
+    __syncthreads();
+    {
+        TileJob job[3 * TPW];
+        f4 acc[3 * TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                job[3 * i + x] = tile_job<HT>(wb + po.v1p, min(nb.wave + i * WAVES, HT - 1), vx + x * HT * 256);
+                acc[3 * i + x] = f4zero();
+            }
+        dense_seq<HT, 3 * TPW>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (nb.wave + i * WAVES < HT) {
+                const f4 q = acc[3 * i] * acc[3 * i] + acc[3 * i + 1] * acc[3 * i + 1] + acc[3 * i + 2] * acc[3 * i + 2];
+                lds_st(in, HT + nb.wave + i * WAVES, nb.lane, (f4){sqrtf(q.x), sqrtf(q.y), sqrtf(q.z), sqrtf(q.w)});
+            }
+    }
+    __syncthreads();
+    {
+        TileJob job[TPW];
+        f4 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = min(nb.wave + i * WAVES, HT - 1);
+            job[i] = tile_job<2 * HT>(wb + po.un0, t, in);
+            acc[i] = ld_vec(wb + po.un0_b, t, nb.lane);
+        }
+        dense_seq<2 * HT, TPW>(job, nb.lane, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (nb.wave + i * WAVES < HT) lds_st(hu, nb.wave + i * WAVES, nb.lane, silu4(acc[i]));
+    }
+    __syncthreads();
+    if (nb.wave == 0) {
+        const f4 xg = dense_tile_lds<HT>(wb + po.un2, 0, hu, nb.lane, ld_vec(wb + po.un2_b, 0, nb.lane));
+        // rows 0,1 of tile 0 live in lane group 0: xg.x = scalar output (unused), xg.y = gate
+        if (nb.valid && nb.g == 0) {
+            float v2s[3];
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                float a = 0.f;
+                for (int w = 0; w < WAVES; ++w) a += red[(x * 16 + w) * 16 + (nb.lane & 15)];
+                v2s[x] = a;
+            }
+            const float gate = xg.y;
+            const float d0 = gate * v2s[0], d1 = gate * v2s[1], d2 = gate * v2s[2];
+            dpos[n * 3] = d0; dpos[n * 3 + 1] = d1; dpos[n * 3 + 2] = d2;
+            if (isnan(d0) || isnan(d1) || isnan(d2)) atomicOr(status, 1);
+        }
+    }
+    if (nb.wave == (WAVES > 1 ? 1 : 0)) {
+        const f4 ho = dense_tile_lds<HT>(wb + po.embout, 0, in, nb.lane, ld_vec(wb + po.embout_b, 0, nb.lane));
+        if (nb.valid) st_blk(hout, n, 16, 0, nb.lane, ho);
     }
 }

@@ -13,7 +13,7 @@ for flags in "$@"; do
   i=$((i+1))
   echo "##### build $i: $flags"
   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-  OARD_LIB=/tmp/liboard_$i.so rocprofv3 --kernel-trace -d gpurun_out/abl_$i -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  OARD_LIB=/tmp/liboard_$i.so rocprofv3 --kernel-trace -d gpurun_out/abl_$i -o t -- python bench.py --batch ${ABL_BATCH:-64} --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   python tools/prof_summary.py gpurun_out/abl_$i/t_results.db | grep -E "k_equi_node|k_gcl_node|k_node_pre"
   rm -rf gpurun_out/abl_$i
 done
