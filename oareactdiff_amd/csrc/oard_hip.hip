@@ -52,7 +52,7 @@ int g_gcl_variant = 2;     // 0: v0 (weights straight from L2), 1..: LDS-streame
 int g_equi_variant = 2;
 int g_sequential = 0;       // 1: run the sub-batches one after the other on the caller stream (profiling)
 int g_gcl_split = 0;        // 0: fused S1+S2+S3 kernel; 1..: S1+S2 kernel followed by a separate S3 kernel (variant id)
-int g_auto_tiny = 2;        // launches of <= 512 * g_auto_tiny edge tiles (all concurrent sub-batches together) use the
+int g_auto_tiny = 8;        // launches of <= 512 * g_auto_tiny edge tiles (all concurrent sub-batches together) use the
                             //    latency kernels of oard_edge_small.h (8 waves share 16 edges); 0 = never
 int g_auto_small = 4;       // 1: small launches use the 4-wave workgroups (one wave per SIMD instead of two): a launch that cannot
                             //    fill the chip anyway finishes sooner when its waves do not share a SIMD (B <= 8 reactions: -25 %)

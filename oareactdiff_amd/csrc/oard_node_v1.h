@@ -337,6 +337,27 @@ OARD_DEV f4 lin3u4(const float* l3s, const float* __restrict__ p, f4 x) {
     return o;
 }
 
+// the same MLP for one value per lane (small batches: with <= 4 real nodes per workgroup a 16 x 16 tile holds at
+// most 64 real values, one per lane, instead of four per lane of which most belong to padding columns)
+OARD_DEV float lin3u1(const float* l3s, const float* __restrict__ p, float x) {
+    const float* b2 = p + 576;
+    const float* w4 = p + 584;
+    float h2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h2[j] = b2[j];
+#pragma unroll 4
+    for (int k = 0; k < 48; ++k) {
+        const f4 wa = *reinterpret_cast<const f4*>(l3s + 12 * k), wc = *reinterpret_cast<const f4*>(l3s + 12 * k + 4);
+        const float h = silu1(x * l3s[12 * k + 8] + l3s[12 * k + 9]);
+        h2[0] += h * wa.x; h2[1] += h * wa.y; h2[2] += h * wa.z; h2[3] += h * wa.w;
+        h2[4] += h * wc.x; h2[5] += h * wc.y; h2[6] += h * wc.z; h2[7] += h * wc.w;
+    }
+    float o = p[592];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o += silu1(h2[j]) * w4[j];
+    return o;
+}
+
 // =====================================================================================================
 // EquiMessage node side + EquiUpdate, fused (see k_equi_agg_v1 / k_equi_upd):
 //   messages from q, aggregation, s = (s + dx)/sqrt2, vec += dvec, vec_proj, frame scalar MLP,
@@ -442,11 +463,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
 #ifdef OARD_ABL_NOLIN3U
             sca = sc;
 #else
-            sca = lin3u4(l3s, l3, sc);
-            sca.x = f0 + 0 < D::H ? sca.x : 0.f; sca.y = f0 + 1 < D::H ? sca.y : 0.f;
-            sca.z = f0 + 2 < D::H ? sca.z : 0.f; sca.w = f0 + 3 < D::H ? sca.w : 0.f;
+            if (tp.npb <= 4) {
+                // one value per lane: lane -> (feature lane >> 2, column lane & 3) of this tile, through the LDS block
+                float* blk = in + (HT + t) * 256;
+                lds_st(in, HT + t, nb.lane, sc);
+                __builtin_amdgcn_wave_barrier();        // same-wave LDS traffic: the queue is in order, keep the compiler in order too
+                const int f = nb.lane >> 2, c = nb.lane & 3;
+                float* cell = blk + (16 * (f >> 2) + c) * 4 + (f & 3);
+                const float y = (c < tp.npb && 16 * t + f < D::H) ? lin3u1(l3s, l3, *cell) : 0.f;
+                *cell = y;                  // columns 4..15 of the block are padding and keep the raw projection
+            } else {
+                sca = lin3u4(l3s, l3, sc);
+                sca.x = f0 + 0 < D::H ? sca.x : 0.f; sca.y = f0 + 1 < D::H ? sca.y : 0.f;
+                sca.z = f0 + 2 < D::H ? sca.z : 0.f; sca.w = f0 + 3 < D::H ? sca.w : 0.f;
+                lds_st(in, HT + t, nb.lane, sca);
+            }
 #endif
+#ifdef OARD_ABL_NOLIN3U
             lds_st(in, HT + t, nb.lane, sca);
+#endif
         }
     }
     __syncthreads();

@@ -53,7 +53,7 @@ class Case:
         return vel, h
 
 
-LIB_AUTO = dict(auto_small=4, auto_tiny=2)     # the library's default launch-shape heuristics (conftest turns them off)
+LIB_AUTO = dict(auto_small=4, auto_tiny=8, npb=0)     # the library's default launch-shape heuristics (conftest turns them off)
 
 
 @contextlib.contextmanager
