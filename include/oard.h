@@ -140,9 +140,23 @@ int oard_tap(const oard_config* cfg, const oard_topology* topo, const void* work
  * initial edgeweight); 100 + 10*l + 1 = after layer l's GCL node update; 100 + 10*l + 2 = after
  * layer l's EquiUpdate. */
 int oard_debug_stop_after(int code);
-/* Kernel-variant switches for A/B measurements: "gcl_variant" / "equi_variant" (0 = weights straight
- * from L2, >= 1 = LDS-streamed variants, see oard_hip.hip); "poison" = 1 fills the workspace with NaN
- * bit patterns before every forward (tests use it to prove that nothing depends on workspace contents). */
+/* Process-wide switches for tests and A/B measurements (defaults in brackets; all variants compute the same
+ * function and have their own parity test):
+ *   "gcl_variant" [2]   GCLMessage edge kernel: 0 = weights straight from L2 (v0), 1-5 = LDS-streamed shapes
+ *                       (oard_edge_v1.h), 6 = latency kernel (oard_edge_small.h)
+ *   "equi_variant" [2]  EquiMessage edge kernel: 0 = v0, 1-3 = LDS-streamed shapes, 4 = latency kernel
+ *   "node_variant" [1]  0 = one wave per 16 nodes (v0), 1 = one wave per hidden tile (oard_node_v1.h)
+ *   "gcl_skip" [1]      skip S1 / S3 of the GCL chain on inter-object rows of the first / last layer
+ *   "gcl_split" [0]     1-4: S3 of the GCL chain as its own launch
+ *   "auto_small" [4], "auto_tiny" [8]  launch-shape heuristics: launches of <= 1024*auto_small (GCL) /
+ *                       512*auto_small (Equi) 16-edge tiles use 4-wave workgroups, launches of <= 512*auto_tiny
+ *                       tiles the latency kernels; 0 = always the throughput shape
+ *   "npb" [0]           real nodes per workgroup of the node stages (0 = ceil(N/256) clamped to 1..16); read by
+ *                       oard_topology_create
+ *   "parts" [0]         sub-batches per topology (0 = 4 for B >= 32, 2 for B >= 16, else 1); read by
+ *                       oard_topology_create;  "sequential" [0] = 1 runs them one after the other
+ *   "poison" [0]        1 fills the workspace with NaN bit patterns before every forward (the tests use it to
+ *                       prove that nothing depends on workspace contents) */
 int oard_debug_option(const char* name, int value);
 
 /* Average duration (ms) and launch count per kernel family since the last reset, measured with
