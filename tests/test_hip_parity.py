@@ -232,6 +232,39 @@ def test_large_batch_needs_64bit_offsets(parts):
     assert float(big[1][-nf:, :3].abs().max()) > 0
 
 
+def test_largest_supported_object_and_the_limit():
+    """One reaction of 3 x 1024-atom objects (the per-object limit OARD_MAX_GROUP; 9.4 M edges, 26 GB of edge
+    state): no oracle runs at that size, so the check is the reference's own property test - a global rotation of
+    the input rotates the velocities and leaves the features unchanged - plus finiteness.  One atom more per
+    object is refused with an error, not a wrong answer."""
+    from oareactdiff_amd._capi import OardError
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    cfg = dict(PRODUCTION_LEFTNET_CONFIG, num_layers=1)
+    sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg, seed=7)
+    dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
+                       condition_nf=1, device=dev)
+    dyn.load_state_dict(sd, strict=True)
+    xh, ei, t, cond, nfs, cm = _random_case([1024], 4.0, 5, cfg)          # x4: the 10 A cutoff bites
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(1)))
+    q = q * torch.sign(torch.linalg.det(q))
+    xr = [torch.cat([x[:, :3] @ q.T, x[:, 3:]], dim=1) for x in xh]
+    args = (ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+    with torch.no_grad():
+        a, _ = dyn([x.to(dev) for x in xh], *args)
+        b, _ = dyn([x.to(dev) for x in xr], *args)
+    for x, y in zip(a, b):
+        x, y = x.cpu().double(), y.cpu().double()
+        assert bool(torch.isfinite(x).all()) and float(x[:, :3].abs().max()) > 0
+        assert rel(y[:, :3], x[:, :3] @ q.double().T) <= 1e-4 and rel(y[:, 3:], x[:, 3:]) <= 1e-4
+    del a, b
+    xh, ei, t, cond, nfs, cm = _random_case([1025], 1.0, 5, cfg)
+    with pytest.raises(OardError):
+        with torch.no_grad():
+            dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+
+
 def test_scalar_t_equals_per_sample_t_and_input_is_not_mutated():
     dev = torch.device("cuda:0")
     c = Case("g3_cutoff_ragged")
