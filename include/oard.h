@@ -142,7 +142,7 @@ int oard_tap(const oard_config* cfg, const oard_topology* topo, const void* work
 int oard_debug_stop_after(int code);
 /* Process-wide switches for tests and A/B measurements (defaults in brackets; all variants compute the same
  * function and have their own parity test):
- *   "gcl_variant" [2]   GCLMessage edge kernel: 0 = weights straight from L2 (v0), 1-5 = LDS-streamed shapes
+ *   "gcl_variant" [2]   GCLMessage edge kernel: 0 = weights straight from L2 (v0), 1-5 and 7 = LDS-streamed shapes
  *                       (oard_edge_v1.h), 6 = latency kernel (oard_edge_small.h)
  *   "equi_variant" [2]  EquiMessage edge kernel: 0 = v0, 1-3 = LDS-streamed shapes, 4 = latency kernel
  *   "node_variant" [1]  0 = one wave per 16 nodes (v0), 1 = one wave per hidden tile (oard_node_v1.h)

@@ -262,6 +262,7 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
         GCL_CASE(3, 1, 4, 2, 0)      // 4 waves x 16 edges (two workgroups per CU)
         GCL_CASE(4, 1, 8, 2, 1)      // as 2, static priority for waves 4-7
         GCL_CASE(5, 1, 4, 1, 3)      // 4 waves x 16 edges, one group per phase, held to 168 registers: 3 workgroups per CU
+        GCL_CASE(7, 2, 8, 2, 0)      // 8 waves x 32 edges, two waves per SIMD (256 registers): half the DMA pieces per edge
         default: return OARD_EINVAL;
     }
 }

@@ -329,6 +329,7 @@ def test_concurrent_sub_batches_are_bitwise_identical(parts):
     dict(gcl_variant=5, equi_variant=4),                        # 3-waves-per-SIMD GCL; latency EquiMessage kernel
     dict(gcl_variant=6, equi_variant=2),                        # latency GCL kernel
     dict(gcl_variant=6, equi_variant=4, gcl_skip=0),
+    dict(gcl_variant=7, equi_variant=2),                        # 8 waves x 32 edges
     dict(gcl_split=1), dict(gcl_split=2), dict(gcl_split=3), dict(gcl_split=4),
 ])
 def test_every_kernel_variant_is_parity_green(opts):
