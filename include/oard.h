@@ -78,6 +78,10 @@ typedef struct oard_topology oard_topology;
 
 int oard_topology_create(const oard_config* cfg, const int64_t* combined_mask_host,
                          const int64_t* n_frag_switch_host, int64_t n_nodes, oard_topology** out);
+/* As oard_topology_create with an explicit number of concurrent sub-batches (0 = the library's choice, see
+ * "parts" below).  Training needs 1: the tape and the backward kernels work on one sub-batch. */
+int oard_topology_create_parts(const oard_config* cfg, const int64_t* combined_mask_host,
+                               const int64_t* n_frag_switch_host, int64_t n_nodes, int parts, oard_topology** out);
 void oard_topology_destroy(oard_topology* topo);
 int64_t oard_topology_num_nodes(const oard_topology* topo);
 int64_t oard_topology_num_edges(const oard_topology* topo);        /* sum n_s (n_s - 1)         */
@@ -142,12 +146,12 @@ int oard_tap(const oard_config* cfg, const oard_topology* topo, const void* work
 int oard_debug_stop_after(int code);
 /* Process-wide switches for tests and A/B measurements (defaults in brackets; all variants compute the same
  * function and have their own parity test):
- *   "gcl_variant" [2]   GCLMessage edge kernel: 0 = weights straight from L2 (v0), 1-5 and 7 = LDS-streamed shapes
+ *   "gcl_variant" [2]   GCLMessage edge kernel: 0 = weights straight from L2 (v0, the simple cross-check kernel),
+ *                       2 = LDS-streamed, 8 waves x 16 edges, 3 = the same with 4 waves (small launches)
  *                       (oard_edge_v1.h), 6 = latency kernel (oard_edge_small.h)
- *   "equi_variant" [2]  EquiMessage edge kernel: 0 = v0, 1-3 = LDS-streamed shapes, 4 = latency kernel
+ *   "equi_variant" [2]  EquiMessage edge kernel: 0 = v0, 2 / 1 = LDS-streamed with 8 / 4 waves, 4 = latency kernel
  *   "node_variant" [1]  0 = one wave per 16 nodes (v0), 1 = one wave per hidden tile (oard_node_v1.h)
  *   "gcl_skip" [1]      skip S1 / S3 of the GCL chain on inter-object rows of the first / last layer
- *   "gcl_split" [0]     1-4: S3 of the GCL chain as its own launch
  *   "auto_small" [4], "auto_tiny" [8]  launch-shape heuristics: launches of <= 1024*auto_small (GCL) /
  *                       512*auto_small (Equi) 16-edge tiles use 4-wave workgroups, launches of <= 512*auto_tiny
  *                       tiles the latency kernels; 0 = always the throughput shape
@@ -165,6 +169,96 @@ int oard_debug_option(const char* name, int value);
 int oard_timing_enable(int on);
 int oard_timing_reset(void);
 int oard_timing_get(const char* family, double* total_ms, int64_t* launches);
+
+/* ---- training (next row N2): tape, backward of the edge stages ---------------------------------------
+ * Replaces: torch autograd through GCLMessage / EquiMessage when DDPMModule.training_step
+ * (oa_reactdiff/trainer/pl_trainer.py:327-347) back-propagates the loss of EnVariationalDiffusion.forward
+ * (oa_reactdiff/diffusion/en_diffusion.py:56-248).  The reference has no hand-written backward.
+ * All of this works on topologies created with parts == 1.
+ *
+ * oard_forward_train = oard_forward that additionally fills `tape_dev` (oard_tape_bytes) with what the
+ * backward pass needs: the edge state entering every layer, the pre-activations of the edge MLPs, the node
+ * state at the layer boundaries and the geometry constants.  oard_tape_entry locates one tensor in the tape
+ * (byte offset, rows, floats per row); rows are in the library's internal order: nodes sample-major
+ * (oard_topology_export NODE_REF maps them to the reference's rows), edges as physical rows (inner edges
+ * first, target-sorted == INNER_SRC/INNER_TGT, then inter-object edges; ROW_SRC/ROW_TGT), feature widths
+ * padded to multiples of 16 with zero pads (H -> HP, 3H+R -> WP, ...). */
+#define OARD_TOPO_NODE_REF 1     /* [N] internal node -> row in the reference's (object-major) order            */
+#define OARD_TOPO_NODE_OBJ 2     /* [N] object index                                                          */
+#define OARD_TOPO_NODE_ROW 3     /* [N] row inside xh[object]                                                 */
+#define OARD_TOPO_NODE_SAMPLE 4  /* [N] dense sample index                                                    */
+#define OARD_TOPO_NODE_TIDX 5    /* [N] combined_mask value (row of t / conditions)                           */
+#define OARD_TOPO_SAMPLE_PTR 6   /* [B+1] node range of every sample                                          */
+#define OARD_TOPO_GROUP_PTR 7    /* [B*n_obj+1] node range of every (sample, object) group                    */
+#define OARD_TOPO_INNER_SRC 8    /* [A] source node of inner edge a (rows sorted by target)                   */
+#define OARD_TOPO_INNER_TGT 9    /* [A]                                                                       */
+#define OARD_TOPO_ROW_SRC 10     /* [E] source node of physical edge row r                                    */
+#define OARD_TOPO_ROW_TGT 11     /* [E]                                                                       */
+int oard_topology_export(const oard_topology* topo, int which, int32_t* dst_dev, int64_t capacity,
+                         oard_stream_t stream);
+
+#define OARD_TAPE_HIN 1      /* [N][16]      encoder output | t | conditions  (LEFTNet input h)              */
+#define OARD_TAPE_GEO 2      /* [A+1][12]    per inner edge: d, env, u[3], c[3], v[3], mask                   */
+#define OARD_TAPE_RBF 3      /* [A+1][RP]    radial basis                                                     */
+#define OARD_TAPE_PP0 4      /* [N][1]       pos_prjt[:, 0]                                                   */
+#define OARD_TAPE_X1 5       /* [N][3]       node frame axis x1                                               */
+#define OARD_TAPE_S_IN 16    /* [N][HP]      s entering layer l          (l = L: after the last layer)        */
+#define OARD_TAPE_VEC_IN 17  /* [N][3][HP]   vec entering layer l        (l = L: after the last layer)        */
+#define OARD_TAPE_EW 18      /* [E+1][WP]    edge state entering layer l (l = L: final; inter-object rows of l = 0
+                                             are the constant row and are not materialised)                   */
+#define OARD_TAPE_AGG 19     /* [N][HP]      mean gated message per source node                               */
+#define OARD_TAPE_S_MID 20   /* [N][HP]      s after the GCL node update                                      */
+#define OARD_TAPE_Z1 21      /* [E+1][HP]    edge_mlp.0 pre-activation                                        */
+#define OARD_TAPE_Z2 22      /* [E+1][HP]    edge_mlp.1 pre-activation                                        */
+#define OARD_TAPE_ATT 23     /* [E+1][1]     att_mlp pre-activation                                           */
+#define OARD_TAPE_Z3 24      /* [E+1][WP]    edge_out_trans pre-activation                                    */
+#define OARD_TAPE_ZD1 25     /* [A+1][D1P]   dir_proj.0 pre-activation                                        */
+#define OARD_TAPE_CD 26      /* [A+1][3][HP] dir_proj output (before the product with rbf_proj)               */
+size_t oard_tape_bytes(const oard_config* cfg, const oard_topology* topo);
+int oard_tape_entry(const oard_config* cfg, const oard_topology* topo, int which, int layer,
+                    size_t* offset_bytes, int64_t* rows, int64_t* row_floats);
+int oard_forward_train(const oard_config* cfg, const oard_topology* topo, const void* packed_dev,
+                       const float* const* xh_dev, const float* t_dev, int t_is_scalar,
+                       const float* conditions_dev, float* const* out_dev,
+                       void* workspace_dev, size_t workspace_bytes, void* tape_dev, size_t tape_bytes,
+                       int32_t* status_dev, oard_stream_t stream);
+
+/* Transposed weight streams of the two backward edge kernels (same params_dev convention as
+ * oard_pack_weights); call again after any weight update. */
+size_t oard_packed_bwd_bytes(const oard_config* cfg);
+int oard_pack_weights_bwd(const oard_config* cfg, const float* const* params_dev, size_t n_params,
+                          void* packed_bwd_dev, size_t packed_bytes, oard_stream_t stream);
+
+/* Adjoint of layer `layer`'s GCLMessage edge part (leftnet.py:162-170 + the mean aggregation :172-180).
+ *   in : dagg_dev [N][HP]    gradient w.r.t. the per-node mean message (pads zero)
+ *        dew_dev  [E+1][WP]  gradient w.r.t. the edge state LEAVING the layer (pads and spare row finite)
+ *   out: dew_dev             gradient w.r.t. the edge state ENTERING the layer (in place)
+ *        dz3_dev [E+1][WP], dz2_dev / dz1_dev [E+1][HP], da_dev [E+1]: gradients w.r.t. the pre-activations
+ *        of edge_out_trans, edge_mlp.1, edge_mlp.0, att_mlp;  mout_dev [E+1][HP]: the gated message m,
+ *        all in physical row order - the operands of the weight-gradient GEMMs (oard_wgrad).
+ *   Last layer: dz3 is produced for the inner rows [0, A) only (the forward skips edge_out_trans on
+ *   inter-object rows there). */
+int oard_gcl_backward_dx(const oard_config* cfg, const oard_topology* topo, const void* packed_bwd_dev, int layer,
+                         const void* tape_dev, const float* dagg_dev, float* dew_dev, float* dz3_dev,
+                         float* mout_dev, float* dz2_dev, float* da_dev, float* dz1_dev, oard_stream_t stream);
+/* dP[n] / dQ[n] = sum of dz1 over the edges whose source / target is node n (the node halves of edge_mlp.0). */
+int oard_edge_node_sums(const oard_config* cfg, const oard_topology* topo, const float* dz1_dev,
+                        float* dP_dev, float* dQ_dev, oard_stream_t stream);
+/* Adjoint of layer `layer`'s EquiMessage edge part (leftnet.py:247-249, dir_proj):
+ *   in : dcd_dev [A+1][3][HP] gradient w.r.t. dir_proj's output;  out: dew_dev rows [0, A) += dir_proj.0^T ...,
+ *        dzd1_dev [A+1][D1P] gradient w.r.t. dir_proj.0's pre-activation. */
+int oard_equi_backward_dx(const oard_config* cfg, const oard_topology* topo, const void* packed_bwd_dev, int layer,
+                          const void* tape_dev, const float* dcd_dev, float* dew_dev, float* dzd1_dev,
+                          oard_stream_t stream);
+/* Weight gradient of a Linear layer from row-major operands (nn.Linear backward, dW = dY^T X, db = sum dY):
+ *   dW[o][i] = sum_{r < rows} dY[r][op(o)] * act(X[r][ip(i)]),   db[o] = sum_r dY[r][op(o)]   (db may be NULL)
+ * op(o) = (o / o_len) * o_pad + o % o_len undoes section padding (e.g. three 196-wide thirds stored 208 apart);
+ * ncY / ncX = readable floats per row (multiples of 4, <= ld);  x_silu != 0 applies SiLU to X on load.
+ * Deterministic: fixed chunking and summation order for a given shape. */
+size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows);
+int oard_wgrad(const float* dY_dev, int ldY, int ncY, int o_len, int o_pad, int MO,
+               const float* X_dev, int ldX, int ncX, int x_silu, int i_len, int i_pad, int MI, int64_t rows,
+               float* dW_dev, float* db_dev, void* scratch_dev, size_t scratch_bytes, oard_stream_t stream);
 
 #ifdef __cplusplus
 }

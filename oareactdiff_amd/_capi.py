@@ -18,7 +18,16 @@ EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_by
            "oard_topology_create", "oard_topology_destroy", "oard_topology_num_nodes", "oard_topology_num_edges",
            "oard_topology_num_inner_edges", "oard_topology_num_samples", "oard_topology_check_edge_index",
            "oard_workspace_bytes", "oard_forward", "oard_sampler_step", "oard_tap", "oard_debug_stop_after", "oard_debug_option", "oard_timing_enable", "oard_timing_reset",
-           "oard_timing_get"]
+           "oard_timing_get",
+           "oard_topology_create_parts", "oard_topology_export", "oard_tape_bytes", "oard_tape_entry", "oard_forward_train",
+           "oard_packed_bwd_bytes", "oard_pack_weights_bwd", "oard_gcl_backward_dx", "oard_edge_node_sums",
+           "oard_equi_backward_dx", "oard_wgrad_scratch_bytes", "oard_wgrad"]
+
+# oard_topology_export tables / oard_tape_entry tensors (include/oard.h)
+TOPO_NODE_REF, TOPO_NODE_OBJ, TOPO_NODE_ROW, TOPO_NODE_SAMPLE, TOPO_NODE_TIDX, TOPO_SAMPLE_PTR, TOPO_GROUP_PTR, \
+    TOPO_INNER_SRC, TOPO_INNER_TGT, TOPO_ROW_SRC, TOPO_ROW_TGT = range(1, 12)
+TAPE_HIN, TAPE_GEO, TAPE_RBF, TAPE_PP0, TAPE_X1 = 1, 2, 3, 4, 5
+TAPE_S_IN, TAPE_VEC_IN, TAPE_EW, TAPE_AGG, TAPE_S_MID, TAPE_Z1, TAPE_Z2, TAPE_ATT, TAPE_Z3, TAPE_ZD1, TAPE_CD = range(16, 27)
 
 
 class OardConfig(C.Structure):
@@ -72,13 +81,28 @@ def lib() -> C.CDLL:
                                     C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(vp), vp]
     L.oard_sampler_step.restype = C.c_int
     L.oard_tap.argtypes = [cfgp, vp, vp, C.c_int, C.c_int, vp, vp]; L.oard_tap.restype = C.c_int
+    ci = C.c_int
+    L.oard_topology_create_parts.argtypes = [cfgp, C.POINTER(i64), C.POINTER(i64), i64, ci, C.POINTER(vp)]
+    L.oard_topology_create_parts.restype = ci
+    L.oard_topology_export.argtypes = [vp, ci, vp, i64, vp]; L.oard_topology_export.restype = ci
+    L.oard_tape_bytes.argtypes = [cfgp, vp]; L.oard_tape_bytes.restype = sz
+    L.oard_tape_entry.argtypes = [cfgp, vp, ci, ci, C.POINTER(sz), C.POINTER(i64), C.POINTER(i64)]; L.oard_tape_entry.restype = ci
+    L.oard_forward_train.argtypes = [cfgp, vp, vp, C.POINTER(vp), vp, ci, vp, C.POINTER(vp), vp, sz, vp, sz, vp, vp]
+    L.oard_forward_train.restype = ci
+    L.oard_packed_bwd_bytes.argtypes = [cfgp]; L.oard_packed_bwd_bytes.restype = sz
+    L.oard_pack_weights_bwd.argtypes = [cfgp, C.POINTER(vp), sz, vp, sz, vp]; L.oard_pack_weights_bwd.restype = ci
+    L.oard_gcl_backward_dx.argtypes = [cfgp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]; L.oard_gcl_backward_dx.restype = ci
+    L.oard_edge_node_sums.argtypes = [cfgp, vp, vp, vp, vp, vp]; L.oard_edge_node_sums.restype = ci
+    L.oard_equi_backward_dx.argtypes = [cfgp, vp, vp, ci, vp, vp, vp, vp, vp]; L.oard_equi_backward_dx.restype = ci
+    L.oard_wgrad_scratch_bytes.argtypes = [ci, ci, i64]; L.oard_wgrad_scratch_bytes.restype = sz
+    L.oard_wgrad.argtypes = [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, i64, vp, vp, vp, sz, vp]; L.oard_wgrad.restype = ci
     L.oard_debug_stop_after.argtypes = [C.c_int]; L.oard_debug_stop_after.restype = C.c_int
     L.oard_debug_option.argtypes = [C.c_char_p, C.c_int]; L.oard_debug_option.restype = C.c_int
     L.oard_timing_enable.argtypes = [C.c_int]; L.oard_timing_enable.restype = C.c_int
     L.oard_timing_reset.argtypes = []; L.oard_timing_reset.restype = C.c_int
     L.oard_timing_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]; L.oard_timing_get.restype = C.c_int
     for env, opt in (("OARD_GCL_VARIANT", b"gcl_variant"), ("OARD_EQUI_VARIANT", b"equi_variant"),
-                     ("OARD_NODE_VARIANT", b"node_variant"), ("OARD_GCL_SKIP", b"gcl_skip"), ("OARD_PARTS", b"parts"), ("OARD_SEQUENTIAL", b"sequential"), ("OARD_GCL_SPLIT", b"gcl_split"), ("OARD_POISON", b"poison"), ("OARD_AUTO_SMALL", b"auto_small"), ("OARD_AUTO_TINY", b"auto_tiny"), ("OARD_NPB", b"npb")):
+                     ("OARD_NODE_VARIANT", b"node_variant"), ("OARD_GCL_SKIP", b"gcl_skip"), ("OARD_PARTS", b"parts"), ("OARD_SEQUENTIAL", b"sequential"), ("OARD_POISON", b"poison"), ("OARD_AUTO_SMALL", b"auto_small"), ("OARD_AUTO_TINY", b"auto_tiny"), ("OARD_NPB", b"npb")):
         if os.environ.get(env):
             check(L.oard_debug_option(opt, int(os.environ[env])), f"oard_debug_option({opt.decode()})")
     _lib = L

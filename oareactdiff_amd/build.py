@@ -8,14 +8,18 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.environ.get("OARD_LIB") or os.path.join(CSRC, "liboard_hip.so")
 SOURCES = ["oard_hip.hip"]
-HEADERS = ["oard_engine.h", "oard_kernels.h", "oard_layout.h", "oard_edge_v1.h", "oard_node_v1.h", os.path.join("..", "..", "include", "oard.h")]
+
+
+def _headers():
+    """Every header the translation unit can include: a stale library must never survive an edit."""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "oard.h")]
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + _headers())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -1,0 +1,422 @@
+// oard_edge_bwd.h — backward pass of the two per-layer edge stages (training).
+//
+// Reference: what torch autograd derives for GCLMessage (leftnet.py:157-183) and for the edge half of
+// EquiMessage (leftnet.py:245-249) when the loss of en_diffusion.py:56-248 is back-propagated
+// (pl_trainer.py:327-347).  The reference has no hand-written backward; these kernels are the adjoints of
+// k_gcl_edge_v1 / k_equi_edge_v1 (oard_edge_v1.h) on the same column engine:
+//
+//   * data gradients ("dx" kernels): the Linear layers run transposed, dX = W^T dY.  The transposed weights are
+//     packed once per weight update into per-layer streams in consumption order (oard_pack_weights_bwd) and
+//     streamed through LDS by LDS-DMA exactly like the forward streams; SiLU' is evaluated from the stored
+//     pre-activations of the training-mode forward (GclTape, zd1, cd).
+//   * weight gradients (k_wgrad): dW[o][i] = sum_rows dY[row][o] * X[row][i] is a GEMM whose contraction index is
+//     the edge, i.e. the SLOW index of both row-major operands.  A wave loads 4 rows x 64 features of each operand
+//     as one float4 per lane (fully coalesced 256-byte row segments) and uses component c of dY against component
+//     c' of X in 16 MFMAs on 16 accumulators: accumulator (c, c') holds dW[4i + c][4j + c'], so no transpose is
+//     ever needed.  Row chunks give per-workgroup partial sums, reduced by a second pass in a fixed order
+//     (deterministic, no atomics).
+#pragma once
+#include "oard_edge_v1.h"
+
+OARD_DEV float dsilu1(float x) {           // d/dx [x sigmoid(x)] = s (1 + x (1 - s))
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+OARD_DEV f4 dsilu4(f4 v) { return (f4){dsilu1(v.x), dsilu1(v.y), dsilu1(v.z), dsilu1(v.w)}; }
+
+// =====================================================================================================
+// GCLMessage edge part, backward.  Stream (chunks, all groups HT wide, no bias chunks):
+//   T3 = WB groups x HT [W3^T, K-outer over the blocks of dz3];  T2 = HT groups x HT [W2^T tile t];
+//   T1 = WB groups x HT [W1c^T tile tb].
+// Per column (edge):   dz3 = G * SiLU'(z3);  dm = W3^T dz3 + dagg[src] / deg(src)
+//                      m0 = SiLU(z2), gate = SiLU(a);  da = <dm, m0> SiLU'(a);  dz2 = (dm gate + watt da) SiLU'(z2)
+//                      dz1 = (W2^T dz2) SiLU'(z1);   G_out = G + W1c^T dz1
+// G (the gradient of the NEW edge state) is read from `dew` and the gradient of the OLD state is written back in place.
+// =====================================================================================================
+template <class D, int GP>
+struct GclBwdStream {
+    static constexpr int HT = D::HT, WB = D::WB, G = HT;
+    static constexpr int SLAB = GP * G;
+    static constexpr int NP3 = (WB + GP - 1) / GP, NP2 = (HT + GP - 1) / GP, NP1 = NP3, NPH = NP3 + NP2 + NP1;
+    static constexpr int C3 = WB * G, C2 = HT * G, C1 = WB * G, CHUNKS = C3 + C2 + C1;
+    static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
+};
+
+struct GclBwdArgs {
+    const float *z1, *z2, *att, *z3;   // tape of the training-mode forward (physical rows)
+    const float* dagg;                 // [N][HP]   gradient of the per-node mean message (pads zero)
+    const float* watt;                 // [HP]      attention weight, padded
+    float* dew;                        // [E+1][WP] in: gradient of ew_{l+1}; out: gradient of ew_l
+    float* dz3;                        // [E+1][WP] out
+    float* mout;                       // [E+1][HP] out: gated message m (recomputed), physical row order
+    float* dz2;                        // [E+1][HP] out
+    float* da;                         // [E+1]     out
+    float* dz1;                        // [E+1][HP] out
+};
+
+// HAS_S3 = false: inter-object rows of the last layer - the forward skipped S3 there (nothing reads their new
+// state), so G == 0, z3 was never stored, dz3 is not produced, and the old-state gradient is just W1c^T dz1.
+template <class D, int WAVES, int GP, bool HAS_S3>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, const float* __restrict__ stream,
+                                                                long long r0, long long r1, GclBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using S = GclBwdStream<D, GP>;
+    constexpr int HT = D::HT, WB = D::WB, G = S::G;
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    SlabPrefetch<WAVES, S::SLAB> pf;
+    pf.wave = wave;
+    const float* stream_lane = stream + lane * 4;
+    auto pf_begin = [&](int p) {
+        int start = 0, n = 0;
+        if (p < S::NP3) { start = p * GP * G; n = min(GP, WB - p * GP) * G; }
+        else if (p < S::NP3 + S::NP2) { const int q = p - S::NP3; start = S::C3 + q * GP * G; n = min(GP, HT - q * GP) * G; }
+        else if (p < S::NPH) { const int q = p - S::NP3 - S::NP2; start = S::C3 + S::C2 + q * GP * G; n = min(GP, WB - q * GP) * G; }
+        pf.begin(stream_lane, smem, p, start, n);
+    };
+    auto hook = [&]() { pf.tick(); };
+    auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
+
+    const long long c = r0 + ((long long)blockIdx.x * WAVES + wave) * 16 + (lane & 15);
+    const size_t e = (size_t)(c < r1 ? c : tp.E);              // padding columns work on the spare row
+    float* grow = a.dew + e * D::WP + 4 * g;
+    const float* z3row = a.z3 + e * D::WP + 4 * g;
+    float* dz3row = a.dz3 + e * D::WP + 4 * g;
+
+    f4 dm[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) dm[t] = f4zero();
+    f4 gn[GP], zn[GP];
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg) {
+        gn[gg] = (HAS_S3 && gg < WB) ? ld_f4(grow + 16 * gg) : f4zero();
+        zn[gg] = (HAS_S3 && gg < WB) ? ld_f4(z3row + 16 * gg) : f4zero();
+    }
+    int p = HAS_S3 ? 0 : S::NP3;
+    pf_begin(p);
+    pf.flush();
+
+    // ---- T3: dm += W3^T . dz3   (K-outer); the dz3 blocks are stored one phase late ---------------------
+    f4 xs[GP];
+    for (int p3 = 0; HAS_S3 && p3 < S::NP3; ++p3, ++p) {
+        phase_barrier();
+        if (p3 > 0) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) st_f4(dz3row + 16 * ((p3 - 1) * GP + gg), xs[gg]);
+        }
+        f4 x[GP];
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) x[gg] = gn[gg] * dsilu4(zn[gg]);
+        pf_begin(p + 1);
+        if (p3 + 1 < S::NP3) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) {
+                const int b = (p3 + 1) * GP + gg;
+                if (b < WB) { gn[gg] = ld_f4(grow + 16 * b); zn[gg] = ld_f4(z3row + 16 * b); }
+            }
+        }
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg)
+            if (p3 * GP + gg < WB) chain_kouter<HT>(SL(p), gg * G, x[gg], dm, hook);
+        pf.flush();
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) xs[gg] = x[gg];
+    }
+    if (HAS_S3) {
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) {
+            const int b = (S::NP3 - 1) * GP + gg;
+            if (b < WB) st_f4(dz3row + 16 * b, xs[gg]);
+        }
+    }
+
+    // ---- mean-aggregation adjoint, gate and SiLU of stage 2 (element-wise) --------------------------------
+    f4 dz2[HT];
+    {
+        const int src = tp.row_src[e];
+        const int smp = tp.node_sample[src];
+        const int deg = tp.sample_ptr[smp + 1] - tp.sample_ptr[smp] - 1;
+        const float inv = 1.0f / (float)max(deg, 1);            // util_funcs.py:40-44
+        const float att = a.att[e];
+        const float gate = silu1(att);
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            dm[t] += ld_blk(a.dagg, src, D::HP, t, lane) * inv;
+            dz2[t] = ld_blk(a.z2, e, D::HP, t, lane);              // z2 for now
+            const f4 m0 = silu4(dz2[t]);
+            part += dm[t].x * m0.x + dm[t].y * m0.y + dm[t].z * m0.z + dm[t].w * m0.w;
+            st_blk(a.mout, e, D::HP, t, lane, m0 * gate);
+        }
+        const float dav = col_reduce(part) * dsilu1(att);
+        if (g == 0) a.da[e] = dav;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            const f4 z = dz2[t];
+            dz2[t] = (dm[t] * gate + ld_vec(a.watt, t, lane) * dav) * dsilu4(z);
+            st_blk(a.dz2, e, D::HP, t, lane, dz2[t]);
+        }
+    }
+
+    // ---- T2: dz1 = (W2^T dz2) * SiLU'(z1), one output tile per group ---------------------------------------
+    f4 dz1[HT];
+    f4 z1n[GP], on[GP];
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg) z1n[gg] = gg < HT ? ld_blk(a.z1, e, D::HP, gg, lane) : f4zero();
+#pragma unroll
+    for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
+        phase_barrier();
+        pf_begin(p + 1);
+        f4 zc[GP];
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) zc[gg] = z1n[gg];
+        if (p2 + 1 < S::NP2) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) {
+                const int t = (p2 + 1) * GP + gg;
+                if (t < HT) z1n[gg] = ld_blk(a.z1, e, D::HP, t, lane);
+            }
+        } else {                                       // prefetch the incoming-gradient tiles of T1's first phase
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) on[gg] = (HAS_S3 && gg < WB) ? ld_f4(grow + 16 * gg) : f4zero();
+        }
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) {
+            const int t = p2 * GP + gg;                // compile-time after unrolling
+            if (t < HT) {
+                dz1[t] = chain_tile<HT>(SL(p), gg * G, dz2, f4zero(), hook) * dsilu4(zc[gg]);
+                st_blk(a.dz1, e, D::HP, t, lane, dz1[t]);
+            }
+        }
+        pf.flush();
+    }
+
+    // ---- T1: G_out = G + W1c^T dz1, one output tile per group; stores one phase late --------------------------
+    f4 pend[GP];
+    for (int p1 = 0; p1 < S::NP1; ++p1, ++p) {
+        phase_barrier();
+        if (p1 > 0) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) st_f4(grow + 16 * ((p1 - 1) * GP + gg), pend[gg]);
+        }
+        f4 o[GP];
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) o[gg] = on[gg];
+        pf_begin(p + 1);
+        if (HAS_S3 && p1 + 1 < S::NP1) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) {
+                const int t = (p1 + 1) * GP + gg;
+                if (t < WB) on[gg] = ld_f4(grow + 16 * t);
+            }
+        }
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg) {
+            const int t = p1 * GP + gg;
+            if (t < WB) pend[gg] = chain_tile<HT>(SL(p), gg * G, dz1, o[gg], hook);
+        }
+        pf.flush();
+    }
+#pragma unroll
+    for (int gg = 0; gg < GP; ++gg) {
+        const int t = (S::NP1 - 1) * GP + gg;
+        if (t < WB) st_f4(grow + 16 * t, pend[gg]);
+    }
+}
+
+// =====================================================================================================
+// EquiMessage edge part, backward, inner edges.  Stream: U2 = 3*HT groups x D1T [dir_proj.2^T, K-outer over the
+// blocks of dcd in their stored order (third-major)];  U1 = WB groups x D1T [dir_proj.0^T tile tb].
+//   dd1 = dir_proj.2^T dcd;  dzd1 = dd1 * SiLU'(zd1);  dew[a] += dir_proj.0^T dzd1
+// (dcd = dq * cr, the rbf_proj factor and its gradient are element-wise / a plain [A,R] GEMM on the caller's side)
+// =====================================================================================================
+template <class D>
+struct EquiBwdStream {
+    static constexpr int WB = D::WB, D1T = D::D1T, HT = D::HT, G = D1T, NG2 = 3 * HT;
+    static constexpr int SLAB = G, NPH = NG2 + WB, C2 = NG2 * G, CHUNKS = C2 + WB * G;
+    static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
+};
+
+template <class D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_equi_edge_bwd(TopoDev tp, const float* __restrict__ stream,
+                                                              const float* __restrict__ dcd, const float* __restrict__ zd1,
+                                                              float* dew, float* __restrict__ dzd1) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using S = EquiBwdStream<D>;
+    constexpr int WB = D::WB, D1T = D::D1T, G = S::G;
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    SlabPrefetch<WAVES, S::SLAB> pf;
+    pf.wave = wave;
+    const float* stream_lane = stream + lane * 4;
+    auto pf_begin = [&](int p) { pf.begin(stream_lane, smem, p, p * G, p >= S::NPH ? 0 : G); };
+    auto hook = [&]() { pf.tick(); };
+    auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
+
+    const long long c = ((long long)blockIdx.x * WAVES + wave) * 16 + (lane & 15);
+    const size_t ai = (size_t)(c < tp.A ? c : tp.A);          // padding columns use the spare entry A
+    float* grow = dew + (c < tp.A ? ai : (size_t)tp.E) * D::WP + 4 * g;      // inner entry a == physical row a
+    const float* crow = dcd + ai * (size_t)(3 * D::HP) + 4 * g;
+
+    f4 d1[D1T];
+#pragma unroll
+    for (int t = 0; t < D1T; ++t) d1[t] = f4zero();
+    f4 xn = ld_f4(crow);
+    pf_begin(0);
+    pf.flush();
+    int p = 0;
+    for (int j = 0; j < S::NG2; ++j, ++p) {
+        phase_barrier();
+        const f4 x = xn;
+        pf_begin(p + 1);
+        if (j + 1 < S::NG2) xn = ld_f4(crow + 16 * (j + 1));
+        chain_kouter<D1T>(SL(p), 0, x, d1, hook);
+        pf.flush();
+    }
+#pragma unroll
+    for (int t = 0; t < D1T; ++t) {
+        d1[t] = d1[t] * dsilu4(ld_blk(zd1, ai, D::D1P, t, lane));
+        st_blk(dzd1, ai, D::D1P, t, lane, d1[t]);
+    }
+    f4 on = ld_f4(grow), pend = f4zero();
+    for (int tb = 0; tb < WB; ++tb, ++p) {
+        phase_barrier();
+        if (tb > 0) st_f4(grow + 16 * (tb - 1), pend);
+        const f4 o = on;
+        pf_begin(p + 1);
+        if (tb + 1 < WB) on = ld_f4(grow + 16 * (tb + 1));
+        pend = chain_tile<D1T>(SL(p), 0, d1, o, hook);
+        pf.flush();
+    }
+    st_f4(grow + 16 * (WB - 1), pend);
+}
+
+// =====================================================================================================
+// dP[n] = sum of dz1 over the edges whose SOURCE is n, dQ[n] = over the edges whose TARGET is n (the node terms
+// P[src] + Q[tgt] of edge_mlp.0 were hoisted to the nodes in the forward).  One 64-thread block per node, one
+// float4 of the row per thread, fixed summation order.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_edge_node_sums(TopoDev tp, const float* __restrict__ dz1, int HP,
+                                                       float* __restrict__ dP, float* __restrict__ dQ) {
+    const int n = blockIdx.x, f = threadIdx.x * 4;
+    if (f >= HP) return;
+    const int smp = tp.node_sample[n], s0 = tp.sample_ptr[smp], ns = tp.sample_ptr[smp + 1] - s0, self = n - s0;
+    f4 ap = f4zero(), aq = f4zero();
+    const int e0 = tp.edge_ptr[n];
+    for (int k = 0; k < ns - 1; ++k) ap += ld_f4(dz1 + (size_t)tp.edge_row[e0 + k] * HP + f);
+    for (int k = 0; k < ns; ++k) {
+        if (k == self) continue;
+        const int row = tp.edge_row[tp.edge_ptr[s0 + k] + self - (self > k ? 1 : 0)];
+        aq += ld_f4(dz1 + (size_t)row * HP + f);
+    }
+    st_f4(dP + (size_t)n * HP + f, ap);
+    st_f4(dQ + (size_t)n * HP + f, aq);
+}
+
+// =====================================================================================================
+// weight gradient GEMM:  partial[chunk][o][i] = sum_{rows of the chunk} dY[row][o] * act(X[row][i])
+// block = 4 waves; wave (wo, wi) owns dY block 2*blockIdx.y + wo (64 features) x X blocks 4*blockIdx.z + 2*wi + {0,1}.
+// ncY / ncX = readable columns of a row (multiples of 4); features beyond them contribute zeros.
+// bpartial (optional): per-chunk column sums of dY (the bias gradient).
+// =====================================================================================================
+#define OARD_WG_PD 2                 // prefetch distance in 4-row steps (3 spills at the 256-register bound)
+template <bool XSILU>
+__global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ dY, int ldY, int ncY,
+                                                  const float* __restrict__ X, int ldX, int ncX, long long r0, long long r1,
+                                                  long long rows_per_chunk, float* __restrict__ partial,
+                                                  float* __restrict__ bpartial, int MOp, int MIp) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+    const int wave = threadIdx.x >> 6, wo = wave >> 1, wi = wave & 1;
+    const int ob = blockIdx.y * 2 + wo, ib0 = blockIdx.z * 4 + 2 * wi;
+    const long long rb = r0 + (long long)blockIdx.x * rows_per_chunk;
+    const long long re = rb + rows_per_chunk < r1 ? rb + rows_per_chunk : r1;
+    const int cy = 64 * ob + 4 * i, cx0 = 64 * ib0 + 4 * i, cx1 = cx0 + 64;
+    const bool oky = cy < ncY, okx0 = cx0 < ncX, okx1 = cx1 < ncX;
+    const float* py = dY + cy;
+    const float* px0 = X + cx0;
+    const float* px1 = X + cx1;
+
+    f4 acc[2][4][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc[b][c][d] = f4zero();
+    f4 bs = f4zero();
+    f4 ry[OARD_WG_PD], rx0[OARD_WG_PD], rx1[OARD_WG_PD];
+    auto load = [&](int slot, long long row) {
+        const bool v = row < re;
+        ry[slot] = (v && oky) ? ld_f4(py + (size_t)row * ldY) : f4zero();
+        f4 a = (v && okx0) ? ld_f4(px0 + (size_t)row * ldX) : f4zero();
+        f4 b = (v && okx1) ? ld_f4(px1 + (size_t)row * ldX) : f4zero();
+        rx0[slot] = a; rx1[slot] = b;
+    };
+#pragma unroll
+    for (int u = 0; u < OARD_WG_PD; ++u) load(u, rb + 4 * u + g);
+    for (long long r = rb; r < re; r += 4 * OARD_WG_PD) {
+#pragma unroll
+        for (int u = 0; u < OARD_WG_PD; ++u) {
+            const f4 y = ry[u];
+            f4 x0 = rx0[u], x1 = rx1[u];
+            load(u, r + 4 * (u + OARD_WG_PD) + g);
+            if (XSILU) { x0 = silu4(x0); x1 = silu4(x1); }
+            bs += y;
+            const float yc[4] = {y.x, y.y, y.z, y.w};
+            const float xa[4] = {x0.x, x0.y, x0.z, x0.w};
+            const float xb[4] = {x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    acc[0][c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(yc[c], xa[d], acc[0][c][d], 0, 0, 0);
+                    acc[1][c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(yc[c], xb[d], acc[1][c][d], 0, 0, 0);
+                }
+        }
+    }
+    // accumulator (c, d), component q of lane (g, j):  dW[64 ob + 4 (4g + q) + c][64 ib + 4 j + d]
+    float* out = partial + (size_t)blockIdx.x * MOp * MIp;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = 64 * ob + 4 * (4 * g + q) + c;
+                const int col = 64 * (ib0 + b) + 4 * i;
+                st_f4(out + (size_t)o * MIp + col, (f4){acc[b][c][0][q], acc[b][c][1][q], acc[b][c][2][q], acc[b][c][3][q]});
+            }
+        }
+    if (bpartial != nullptr && blockIdx.z == 0 && wi == 0) {
+        bs.x += __shfl_xor(bs.x, 16, 64); bs.x += __shfl_xor(bs.x, 32, 64);
+        bs.y += __shfl_xor(bs.y, 16, 64); bs.y += __shfl_xor(bs.y, 32, 64);
+        bs.z += __shfl_xor(bs.z, 16, 64); bs.z += __shfl_xor(bs.z, 32, 64);
+        bs.w += __shfl_xor(bs.w, 16, 64); bs.w += __shfl_xor(bs.w, 32, 64);
+        if (g == 0) st_f4(bpartial + (size_t)blockIdx.x * MOp + 64 * ob + 4 * i, bs);
+    }
+}
+
+// second pass: out[o][i] (dense, logical shape) = sum over chunks in ascending order; logical index -> padded
+// index by sections (o = s * len + w  ->  s * pad + w), which undoes the 196 -> 208 padding of split projections
+__global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int MOp, int MIp, int o_len, int o_pad,
+                               int MO, int i_len, int i_pad, int MI, float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)MO * MI) return;
+    const int o = (int)(idx / MI), i = (int)(idx % MI);
+    const int op = (o / o_len) * o_pad + o % o_len, ip = (i / i_len) * i_pad + i % i_len;
+    const float* p = partial + (size_t)op * MIp + ip;
+    float s = 0.f;
+    for (int ch = 0; ch < n_chunks; ++ch) s += p[(size_t)ch * MOp * MIp];
+    out[idx] = s;
+}
+__global__ void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int MOp, int o_len, int o_pad, int MO,
+                               float* __restrict__ out) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= MO) return;
+    const int op = (o / o_len) * o_pad + o % o_len;
+    float s = 0.f;
+    for (int ch = 0; ch < n_chunks; ++ch) s += bpartial[(size_t)ch * MOp + op];
+    out[o] = s;
+}

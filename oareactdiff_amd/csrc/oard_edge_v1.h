@@ -16,9 +16,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // one 1-KiB chunk: per-lane global source, wave-uniform LDS destination (+ lane*16 by hardware)
 OARD_DEV void glds16(const float* gsrc_lane, float* lds_chunk) {
-#ifndef OARD_DBG_NODMA
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc_lane, (lds_ptr_t)lds_chunk, 16, 0, 0);
-#endif
 }
 
 // Phase barrier: every LDS-DMA piece this wave issued must have landed before any wave reads the slab.
@@ -30,20 +28,8 @@ OARD_DEV void phase_barrier() {
     __syncthreads();
 }
 
-// acc[i] += a x b[i] for NA independent accumulators, k-steps outermost so consecutive MFMAs never
-// depend on each other (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency)
-template <int NA>
-OARD_DEV void mma_shared_a(f4 a, const f4 (&b)[NA], f4 (&acc)[NA]) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[i].x, acc[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[i].y, acc[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[i].z, acc[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[i].w, acc[i], 0, 0, 0);
-}
-// two (a, b, acc) triples interleaved
+// two (a, b, acc) triples interleaved: consecutive MFMAs never depend on each other
+// (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency)
 OARD_DEV void mma_pair(f4 a0, f4 b0, f4& c0, f4 a1, f4 b1, f4& c1) {
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, c0, 0, 0, 0);
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, c1, 0, 0, 0);
@@ -58,25 +44,8 @@ OARD_DEV void mma_pair(f4 a0, f4 b0, f4& c0, f4 a1, f4 b1, f4& c1) {
 // ---- software-pipelined LDS -> MFMA chains ---------------------------------------------------------
 // `sl` = this lane's pointer into the current slab (slab base + lane*4); chunk j is at sl + j*256.
 // The A fragments of the NEXT pair of chunks are read from LDS while the current pair's 8 MFMAs issue,
-// so the ds_read latency (~100+ cycles) is covered; sched_group_barrier pins that order.
-#ifdef OARD_DBG_NOLDS
-OARD_DEV f4 lds_a(const float* sl, int j) { return (f4){1.0f + j, 0.5f, 0.25f, 2.0f}; }       // timing experiment only
-#else
+// so the ds_read latency (~100+ cycles) is covered.
 OARD_DEV f4 lds_a(const float* sl, int j) { return *reinterpret_cast<const f4*>(sl + j * 256); }
-#endif
-#ifdef OARD_DBG_NOEPI
-#define EPI_SILU4(x) (x)
-#else
-#define EPI_SILU4(x) silu4(x)
-#endif
-#ifdef OARD_USE_SCHED
-#define OARD_SCHED_PAIR() do { __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); \
-                               __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); } while (0)
-#define OARD_SCHED_OPEN() __builtin_amdgcn_sched_group_barrier(0x100, 2, 0)
-#else
-#define OARD_SCHED_PAIR() do { } while (0)
-#define OARD_SCHED_OPEN() do { } while (0)
-#endif
 
 // M-outer: one output tile = sum over KB chunks (slots j0..j0+KB-1) x in[b]; even/odd accumulators
 struct NoHook { OARD_DEV void operator()() const {} };
@@ -84,14 +53,12 @@ template <int KB, class Hook = NoHook>
 OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hook hook = Hook()) {
     f4 c0 = init, c1 = f4zero();
     f4 a0 = lds_a(sl, j0), a1 = KB > 1 ? lds_a(sl, j0 + 1) : f4zero();
-    OARD_SCHED_OPEN();      // the first pair's reads open the pipeline
 #pragma unroll
     for (int b = 0; b + 1 < KB; b += 2) {
         f4 n0 = a0, n1 = a1;
         if (b + 2 < KB) n0 = lds_a(sl, j0 + b + 2);
         if (b + 3 < KB) n1 = lds_a(sl, j0 + b + 3);
         mma_pair(a0, in[b], c0, a1, in[b + 1], c1);
-        OARD_SCHED_PAIR();
         hook();
         a0 = n0; a1 = n1;
     }
@@ -102,19 +69,40 @@ OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hoo
 template <int MT, class Hook = NoHook>
 OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook hook = Hook()) {
     f4 a0 = lds_a(sl, j0), a1 = MT > 1 ? lds_a(sl, j0 + 1) : f4zero();
-    OARD_SCHED_OPEN();
 #pragma unroll
     for (int t = 0; t + 1 < MT; t += 2) {
         f4 n0 = a0, n1 = a1;
         if (t + 2 < MT) n0 = lds_a(sl, j0 + t + 2);
         if (t + 3 < MT) n1 = lds_a(sl, j0 + t + 3);
         mma_pair(a0, x, acc[t], a1, x, acc[t + 1]);
-        OARD_SCHED_PAIR();
         hook();
         a0 = n0; a1 = n1;
     }
     if (MT & 1) acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]);
 }
+
+// The LDS-DMA prefetcher shared by the streamed kernels: the pieces of the NEXT phase's slab are issued one at
+// a time between MFMA pairs (every third pair), staggered between the two waves that share a SIMD - one
+// global_load_lds costs the issuing wave ~100-180 cycles, a burst after the barrier would stall the chain.
+template <int WAVES, int SLAB>
+struct SlabPrefetch {
+    static constexpr int KMAX = (SLAB + WAVES - 1) / WAVES;    // pieces per wave per phase (upper bound)
+    const float* src;
+    float* dst;
+    int n, k, next, wave;
+    OARD_DEV void begin(const float* stream_lane, float* smem, int phase, int first_chunk, int n_chunks) {
+        src = stream_lane + (size_t)first_chunk * 256;
+        dst = smem + (size_t)(phase & 1) * SLAB * 256;
+        n = n_chunks; k = 0; next = 1 + (wave >= WAVES / 2 ? 1 : 0);
+    }
+    OARD_DEV void one() {
+        const int j = wave + k * WAVES;
+        if (j < n) glds16(src + (size_t)j * 256, dst + j * 256);
+        ++k;
+    }
+    OARD_DEV void tick() { if (--next == 0) { one(); next = 3; } }
+    OARD_DEV void flush() { while (k < KMAX) one(); }
+};
 
 // =====================================================================================================
 // GCLMessage edge part, all edges.  Stream (chunks): S1 = WB groups x HT  [W1c, K-outer];
@@ -130,395 +118,185 @@ struct GclStream {
     static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
 };
 
-// NB == 1 variants are held to <= 256 registers (2 waves per SIMD).  Besides occupancy this keeps the
-// accumulators out of the AGPR half of the file: with the default bound hipcc (ROCm 7.2) put some S1
-// accumulators in AGPRs for the 4-wave variant and the result drifted to 6e-5 of the oracle (a missed
-// MFMA->v_accvgpr_read hazard is the suspect); with the bound every variant is at 2.5e-7.
+// What a training-mode forward keeps per layer for the backward pass (all NULL in inference): the
+// pre-activations of the three Linear layers and of the gate, in physical row order like the edge state.
+struct GclTape {
+    float* z1;     // [E+1][HP]  W1c.ew + P[src] + Q[tgt]
+    float* z2;     // [E+1][HP]  W2.h1 + b2
+    float* att;    // [E+1]      watt.m0 + batt
+    float* z3;     // [E+1][WP]  W3.m + b3
+};
+
+// Held to <= 256 registers (2 waves per SIMD).  Besides occupancy this keeps the accumulators out of the
+// AGPR half of the file: with the default bound hipcc (ROCm 7.2) put some S1 accumulators in AGPRs for the
+// 4-wave shape and the result drifted to 6e-5 of the oracle; with the bound every shape is at 2.5e-7.
 // DO_S1 = false: the columns are inter-object edges of layer 0, whose state is the constant row: stage S1
 //   collapses to the precomputed vector u0 (added to the accumulator init) and its DMA is skipped.
 // DO_S3 = false: the columns are inter-object edges of the last layer, whose updated state nobody reads
 //   (EquiMessage only touches inner edges): the residual stage and its edge-state traffic are skipped.
+// TRAIN: the new state goes to `ew_out` (a different buffer: the backward pass needs every layer's input state)
+//   and the pre-activations are stored (GclTape).  In inference ew_out == ew_in (in-place update).
 // Columns are the physical rows [r0, r1).
-template <class D, int NB, int WAVES, int GP, int PRIO, bool DO_S1, bool DO_S3>
-__global__ __launch_bounds__(WAVES * 64, NB == 1 ? (PRIO == 3 ? 3 : 2) : 1) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
-                                                            const float* __restrict__ P, const float* __restrict__ Q,
-                                                            const float* __restrict__ u0, const float* __restrict__ c0,
-                                                            long long r0, long long r1,
-                                                            float* __restrict__ ew, float* __restrict__ mbuf) {
+template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
+                                                               const float* __restrict__ P, const float* __restrict__ Q,
+                                                               const float* __restrict__ u0, const float* __restrict__ c0,
+                                                               long long r0, long long r1, const float* ew_in, float* ew_out,
+                                                               float* __restrict__ mbuf, GclTape tape) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = GclStream<D, GP>;
     constexpr int HT = D::HT, WB = D::WB, G1 = S::G1, G2 = S::G2;
     const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
-    // static priority for the younger half: the two waves sharing a SIMD then take the matrix pipe in
-    // turns (one runs its MFMA chain while the other does its VALU epilogue) instead of in lockstep
-    if (PRIO == 1 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);      // PRIO == 3: no priority, but 3 waves per SIMD (<= 168 registers)
 
-    // DMA prefetch of the next phase, spread over the current phase: one global_load_lds costs the
-    // issuing wave ~100-180 cycles, so the pieces are issued one at a time between MFMA pairs (every
-    // third pair), staggered between the two waves that share a SIMD, instead of in a burst after the barrier
-    constexpr int KMAX = (S::SLAB + WAVES - 1) / WAVES;        // pieces per wave per phase (upper bound)
-    const float* pf_src = stream;
-    float* pf_dst = smem;
-    int pf_n = 0, pf_k = 0, pf_next = 0;
+    SlabPrefetch<WAVES, S::SLAB> pf;
+    pf.wave = wave;
+    const float* stream_lane = stream + lane * 4;
     auto pf_begin = [&](int p) {                               // p = phase to prefetch
         int start = 0, n = 0;
         if (p < S::NP1) { start = p * GP * G1; n = min(GP, WB - p * GP) * G1; }
         else if (p < S::NP1 + S::NP2) { const int q = p - S::NP1; start = S::C1 + q * GP * G2; n = min(GP, S::NG2 - q * GP) * G2; }
         else if (p < S::NPH && DO_S3) { const int q = p - S::NP1 - S::NP2; start = S::C1 + S::C2 + q * GP * G2; n = min(GP, WB - q * GP) * G2; }
-        pf_src = stream + (size_t)start * 256 + lane * 4;
-        pf_dst = smem + (size_t)(p & 1) * S::SLAB * 256;
-        pf_n = n; pf_k = 0; pf_next = 1 + (wave >= WAVES / 2 ? 1 : 0);
+        pf.begin(stream_lane, smem, p, start, n);
     };
-#ifdef OARD_STAGE_REG_GCL
-    // register-staged alternative: plain 1-KiB loads right after the barrier, ds_write_b128 before the next one
-    f4 stage[KMAX];
-    auto hook = [&]() {};
-    auto pf_flush = [&]() {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int j = wave + k * WAVES;
-            if (j < pf_n) *reinterpret_cast<f4*>(pf_dst + j * 256 + lane * 4) = stage[k];
-        }
-    };
-    auto pf_load = [&]() {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int j = wave + k * WAVES;
-            if (j < pf_n) stage[k] = ld_f4(pf_src + (size_t)j * 256);
-        }
-    };
-    auto issue = [&](int p) { pf_begin(p); pf_load(); pf_flush(); };
-    auto pf_start = [&](int p) { pf_begin(p); pf_load(); };
-#else
-    auto pf_one = [&]() {
-        const int j = wave + pf_k * WAVES;
-        if (j < pf_n) glds16(pf_src + (size_t)j * 256, pf_dst + j * 256);
-        ++pf_k;
-    };
-#ifndef OARD_NO_HOOK
-    auto hook = [&]() { if (--pf_next == 0) { pf_one(); pf_next = 3; } };
-#else
-    auto hook = [&]() { while (pf_k < KMAX) pf_one(); };       // burst at the first hook
-#endif
-    auto pf_flush = [&]() { while (pf_k < KMAX) pf_one(); };
-    auto issue = [&](int p) { pf_begin(p); pf_flush(); };      // burst form (prologue only)
-    auto pf_start = [&](int p) { pf_begin(p); };
-#endif
+    auto hook = [&]() { pf.tick(); };
     auto A = [&](int p, int j) -> f4 {
         return *reinterpret_cast<const f4*>(smem + ((size_t)(p & 1) * S::SLAB + j) * 256 + lane * 4);
     };
     auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
 
-    // columns of this wave; padding columns work on the spare row E of ew / mbuf (allocated for that
+    // column of this lane; padding columns work on the spare row E of every per-edge buffer (allocated for that
     // purpose), so the kernel has no validity branches and every wave stays in the barrier protocol
-    const long long colbase = r0 + ((long long)blockIdx.x * WAVES + wave) * (NB * 16) + (lane & 15);
-    size_t e[NB];
-    float* erow[NB];
-    f4 h1[NB][HT];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const long long c = colbase + nb * 16;
-        e[nb] = (size_t)(c < r1 ? c : tp.E);
-        erow[nb] = ew + e[nb] * D::WP + 4 * g;
-        const int src = tp.row_src[e[nb]], tgt = tp.row_tgt[e[nb]];
+    const long long c = r0 + ((long long)blockIdx.x * WAVES + wave) * 16 + (lane & 15);
+    const size_t e = (size_t)(c < r1 ? c : tp.E);
+    const float* erow = ew_in + e * D::WP + 4 * g;
+    float* orow = ew_out + e * D::WP + 4 * g;
+    f4 h1[HT];
+    {
+        const int src = tp.row_src[e], tgt = tp.row_tgt[e];
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
-            h1[nb][t] = ld_blk(P, src, D::HP, t, lane) + ld_blk(Q, tgt, D::HP, t, lane);
-            if (!DO_S1) h1[nb][t] += ld_vec(u0, t, lane);
+            h1[t] = ld_blk(P, src, D::HP, t, lane) + ld_blk(Q, tgt, D::HP, t, lane);
+            if (!DO_S1) h1[t] += ld_vec(u0, t, lane);
         }
     }
-    f4 xn[GP][NB];
+    f4 xn[GP];
 #pragma unroll
-    for (int gg = 0; gg < GP; ++gg)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) xn[gg][nb] = (DO_S1 && gg < WB) ? ld_f4(erow[nb] + 16 * gg) : f4zero();
+    for (int gg = 0; gg < GP; ++gg) xn[gg] = (DO_S1 && gg < WB) ? ld_f4(erow + 16 * gg) : f4zero();
     int p = DO_S1 ? 0 : S::NP1;
-    issue(p);
+    pf_begin(p);
+    pf.flush();                                                // burst form (prologue only)
 
     // ---- S1: h1 += W1c . ew   (K-outer) -------------------------------------------------------------
     for (int p1 = 0; DO_S1 && p1 < S::NP1; ++p1, ++p) {
         phase_barrier();
-        f4 x[GP][NB];
+        f4 x[GP];
 #pragma unroll
-        for (int gg = 0; gg < GP; ++gg)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) x[gg][nb] = xn[gg][nb];
-        pf_start(p + 1);
+        for (int gg = 0; gg < GP; ++gg) x[gg] = xn[gg];
+        pf_begin(p + 1);
         if (p1 + 1 < S::NP1) {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int b = (p1 + 1) * GP + gg;
-                if (b < WB)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) xn[gg][nb] = ld_f4(erow[nb] + 16 * b);
+                if (b < WB) xn[gg] = ld_f4(erow + 16 * b);
             }
         }
 #pragma unroll
-        for (int gg = 0; gg < GP; ++gg) {
-            if (p1 * GP + gg < WB) {
-                if (NB >= 2) {
+        for (int gg = 0; gg < GP; ++gg)
+            if (p1 * GP + gg < WB) chain_kouter<HT>(SL(p), gg * G1, x[gg], h1, hook);
+        pf.flush();
+    }
+    if (TRAIN) {
 #pragma unroll
-                    for (int t = 0; t < HT; ++t) {
-                        const f4 a = A(p, gg * G1 + t);
-                        f4 acc[NB], xb[NB];
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) { acc[nb] = h1[nb][t]; xb[nb] = x[gg][nb]; }
-                        mma_shared_a<NB>(a, xb, acc);
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) h1[nb][t] = acc[nb];
-                    }
-                } else {
-                    chain_kouter<HT>(SL(p), gg * G1, x[gg][0], h1[0], hook);
-                }
-            }
-        }
-        pf_flush();
+        for (int t = 0; t < HT; ++t) st_blk(tape.z1, e, D::HP, t, lane, h1[t]);
     }
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int t = 0; t < HT; ++t) h1[nb][t] = EPI_SILU4(h1[nb][t]);
+    for (int t = 0; t < HT; ++t) h1[t] = silu4(h1[t]);
 
-    // ---- S2: m = SiLU(W2 h1 + b2); gate = SiLU(watt . m + batt) ---------------------------------------
-    f4 m[NB][HT];
-    f4 on[GP][NB];
-    // note: the gate tile is computed from h1?  no — from m; it is the last group of S2 and uses m as B operand
+    // ---- S2: m = SiLU(W2 h1 + b2); gate = SiLU(watt . m + batt) (the gate is the last group, fed with m) ----
+    f4 m[HT];
+    f4 on[GP];
 #pragma unroll
     for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
         phase_barrier();
-        pf_start(p + 1);
+        pf_begin(p + 1);
         if (DO_S3 && p2 == S::NP2 - 1) {            // prefetch the old edge-state tiles of S3's first phase
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    on[gg][nb] = gg < WB ? (DO_S1 ? ld_f4(erow[nb] + 16 * gg) : ld_f4(c0 + 16 * gg + 4 * g)) : f4zero();
+                on[gg] = gg < WB ? (DO_S1 ? ld_f4(erow + 16 * gg) : ld_f4(c0 + 16 * gg + 4 * g)) : f4zero();
         }
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
             const int tg = p2 * GP + gg;            // compile-time after unrolling
             if (tg < S::NG2) {
                 const f4 bias = A(p, gg * G2);
-                if (NB >= 2) {
-                    f4 acc[NB];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[nb] = bias;
-#pragma unroll
-                    for (int b = 0; b < HT; ++b) {
-                        f4 xb[NB];
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) xb[nb] = tg < HT ? h1[nb][b] : m[nb][b];
-                        mma_shared_a<NB>(A(p, gg * G2 + 1 + b), xb, acc);
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        if (tg < HT) m[nb][tg] = EPI_SILU4(acc[nb]);
-                        else {
-                            const float gate = silu1(__shfl(acc[nb].x, lane & 15, 64));
-#pragma unroll
-                            for (int t = 0; t < HT; ++t) m[nb][t] *= gate;
-                        }
-                    }
+                const f4 acc = tg < HT ? chain_tile<HT>(SL(p), gg * G2 + 1, h1, bias, hook)
+                                       : chain_tile<HT>(SL(p), gg * G2 + 1, m, bias, hook);
+                if (tg < HT) {
+                    if (TRAIN) st_blk(tape.z2, e, D::HP, tg, lane, acc);
+                    m[tg] = silu4(acc);
                 } else {
-                    const f4 acc = tg < HT ? chain_tile<HT>(SL(p), gg * G2 + 1, h1[0], bias, hook)
-                                           : chain_tile<HT>(SL(p), gg * G2 + 1, m[0], bias, hook);
-                    if (tg < HT) m[0][tg] = EPI_SILU4(acc);
-                    else {
-                        const float gate = silu1(__shfl(acc.x, lane & 15, 64));
+                    const float a = __shfl(acc.x, lane & 15, 64);
+                    if (TRAIN && g == 0) tape.att[e] = a;
+                    const float gate = silu1(a);
 #pragma unroll
-                        for (int t = 0; t < HT; ++t) m[0][t] *= gate;
-                    }
+                    for (int t = 0; t < HT; ++t) m[t] *= gate;
                 }
             }
         }
-        pf_flush();
+        pf.flush();
     }
     // ---- S3: ew += SiLU(W3 m + b3), one output tile per group ----------------------------------------
     // stores are issued one phase late (right after the next barrier) so that the barrier's vmcnt(0)
     // never waits for a store that was issued a few cycles earlier
     if (!DO_S3) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e[nb]], D::HP, t, lane, m[nb][t]);
+        for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e], D::HP, t, lane, m[t]);
         return;
     }
-    f4 pend[GP][NB];
+    f4 pend[GP], pendz[TRAIN ? GP : 1];
     for (int p3 = 0; p3 < S::NP3; ++p3, ++p) {
         phase_barrier();
         if (p3 == 0) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e[nb]], D::HP, t, lane, m[nb][t]);
+            for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e], D::HP, t, lane, m[t]);
         } else {
 #pragma unroll
-            for (int gg = 0; gg < GP; ++gg)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) st_f4(erow[nb] + 16 * ((p3 - 1) * GP + gg), pend[gg][nb]);   // (p3-1)*GP+gg < WB always
+            for (int gg = 0; gg < GP; ++gg) {                  // (p3-1)*GP+gg < WB always
+                st_f4(orow + 16 * ((p3 - 1) * GP + gg), pend[gg]);
+                if (TRAIN) st_f4(tape.z3 + e * D::WP + 4 * g + 16 * ((p3 - 1) * GP + gg), pendz[gg]);
+            }
         }
-        f4 o[GP][NB];
+        f4 o[GP];
 #pragma unroll
-        for (int gg = 0; gg < GP; ++gg)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) o[gg][nb] = on[gg][nb];
-        pf_start(p + 1);
+        for (int gg = 0; gg < GP; ++gg) o[gg] = on[gg];
+        pf_begin(p + 1);
         if (p3 + 1 < S::NP3) {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int t = (p3 + 1) * GP + gg;
-                if (t < WB)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)      // !DO_S1: the old state of these rows IS the constant row (never materialised)
-                        on[gg][nb] = DO_S1 ? ld_f4(erow[nb] + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
+                if (t < WB)      // !DO_S1: the old state of these rows IS the constant row (never materialised)
+                    on[gg] = DO_S1 ? ld_f4(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
             }
         }
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
             const int t = p3 * GP + gg;
             if (t < WB) {
-                const f4 bias = A(p, gg * G2);
-                if (NB >= 2) {
-                    f4 acc[NB];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[nb] = bias;
-#pragma unroll
-                    for (int b = 0; b < HT; ++b) {
-                        f4 xb[NB];
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) xb[nb] = m[nb][b];
-                        mma_shared_a<NB>(A(p, gg * G2 + 1 + b), xb, acc);
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) pend[gg][nb] = o[gg][nb] + EPI_SILU4(acc[nb]);
-                } else {
-                    pend[gg][0] = o[gg][0] + EPI_SILU4(chain_tile<HT>(SL(p), gg * G2 + 1, m[0], bias, hook));
-                }
+                const f4 z = chain_tile<HT>(SL(p), gg * G2 + 1, m, A(p, gg * G2), hook);
+                if (TRAIN) pendz[gg] = z;
+                pend[gg] = o[gg] + silu4(z);
             }
         }
-        pf_flush();
+        pf.flush();
     }
 #pragma unroll
     for (int gg = 0; gg < GP; ++gg) {
         const int t = (S::NP3 - 1) * GP + gg;
-        if (t < WB)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) st_f4(erow[nb] + 16 * t, pend[gg][nb]);
-    }
-}
-
-// =====================================================================================================
-// Stage S3 of the GCL edge pass as its own kernel (split schedule): ew += SiLU(W3 m + b3) with m read back
-// from the message buffer.  Without h1 it needs ~half the registers of the fused kernel, so it can run two
-// column blocks per wave (each streamed chunk feeds 8 MFMAs) at 2-3 waves per SIMD.
-// OLD_C0: the rows are inter-object edges of layer 0 whose old state is the constant row (never materialised).
-// =====================================================================================================
-template <class D, int NB, int WAVES, int GP, bool OLD_C0>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_s3_v1(TopoDev tp, const float* __restrict__ stream,
-                                                             const float* __restrict__ c0, long long r0, long long r1,
-                                                             const float* __restrict__ mbuf, float* __restrict__ ew) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    using S = GclStream<D, GP>;
-    constexpr int HT = D::HT, WB = D::WB, G2 = S::G2, NP3 = S::NP3;
-    const int lane = threadIdx.x & 63, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int KMAX = (S::SLAB + WAVES - 1) / WAVES;
-    const float* pf_src = stream;
-    float* pf_dst = smem;
-    int pf_n = 0, pf_k = 0, pf_next = 0;
-    auto pf_begin = [&](int q) {                               // q = S3 phase to prefetch
-        int start = S::C1 + S::C2, n = 0;
-        if (q < NP3) { start += q * GP * G2; n = min(GP, WB - q * GP) * G2; }
-        pf_src = stream + (size_t)start * 256 + lane * 4;
-        pf_dst = smem + (size_t)(q & 1) * S::SLAB * 256;
-        pf_n = n; pf_k = 0; pf_next = 1 + (wave >= WAVES / 2 ? 1 : 0);
-    };
-    auto pf_one = [&]() {
-        const int j = wave + pf_k * WAVES;
-        if (j < pf_n) glds16(pf_src + (size_t)j * 256, pf_dst + j * 256);
-        ++pf_k;
-    };
-    auto hook = [&]() { if (--pf_next == 0) { pf_one(); pf_next = 3; } };
-    auto pf_flush = [&]() { while (pf_k < KMAX) pf_one(); };
-    auto SL = [&](int q) -> const float* { return smem + (size_t)(q & 1) * S::SLAB * 256 + lane * 4; };
-
-    const long long colbase = r0 + ((long long)blockIdx.x * WAVES + wave) * (NB * 16) + (lane & 15);
-    float* erow[NB];
-    f4 m[NB][HT];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const long long c = colbase + nb * 16;
-        const size_t e = (size_t)(c < r1 ? c : tp.E);
-        erow[nb] = ew + e * D::WP + 4 * g;
-        const size_t mrow = (size_t)tp.row_eid[e];
-#pragma unroll
-        for (int t = 0; t < HT; ++t) m[nb][t] = ld_blk(mbuf, mrow, D::HP, t, lane);
-    }
-    f4 on[GP][NB], pend[GP][NB];
-#pragma unroll
-    for (int gg = 0; gg < GP; ++gg)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            on[gg][nb] = gg < WB ? (OLD_C0 ? ld_f4(c0 + 16 * gg + 4 * g) : ld_f4(erow[nb] + 16 * gg)) : f4zero();
-    pf_begin(0);
-    pf_flush();
-    for (int q = 0; q < NP3; ++q) {
-        phase_barrier();
-        if (q > 0) {
-#pragma unroll
-            for (int gg = 0; gg < GP; ++gg)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) st_f4(erow[nb] + 16 * ((q - 1) * GP + gg), pend[gg][nb]);
+        if (t < WB) {
+            st_f4(orow + 16 * t, pend[gg]);
+            if (TRAIN) st_f4(tape.z3 + e * D::WP + 4 * g + 16 * t, pendz[gg]);
         }
-        f4 o[GP][NB];
-#pragma unroll
-        for (int gg = 0; gg < GP; ++gg)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) o[gg][nb] = on[gg][nb];
-        pf_begin(q + 1);
-        if (q + 1 < NP3) {
-#pragma unroll
-            for (int gg = 0; gg < GP; ++gg) {
-                const int t = (q + 1) * GP + gg;
-                if (t < WB)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        on[gg][nb] = OLD_C0 ? ld_f4(c0 + 16 * t + 4 * g) : ld_f4(erow[nb] + 16 * t);
-            }
-        }
-#pragma unroll
-        for (int gg = 0; gg < GP; ++gg) {
-            const int t = q * GP + gg;
-            if (t < WB) {
-                const f4 bias = lds_a(SL(q), gg * G2);
-                if (NB >= 2) {
-                    f4 acc[NB];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[nb] = bias;
-#pragma unroll
-                    for (int b = 0; b < HT; ++b) {
-                        f4 xb[NB];
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) xb[nb] = m[nb][b];
-                        mma_shared_a<NB>(lds_a(SL(q), gg * G2 + 1 + b), xb, acc);
-                        if (b & 1) hook();
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) pend[gg][nb] = o[gg][nb] + EPI_SILU4(acc[nb]);
-                } else {
-                    pend[gg][0] = o[gg][0] + EPI_SILU4(chain_tile<HT>(SL(q), gg * G2 + 1, m[0], bias, hook));
-                }
-            }
-        }
-        pf_flush();
-    }
-#pragma unroll
-    for (int gg = 0; gg < GP; ++gg) {
-        const int t = (NP3 - 1) * GP + gg;
-        if (t < WB)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) st_f4(erow[nb] + 16 * t, pend[gg][nb]);
     }
 }
 
@@ -537,63 +315,28 @@ struct EquiStream {
     static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
 };
 
-template <class D, int WAVES, int PRIO>
+// TRAIN: also stores the pre-activation of dir_proj.0 (zd1 [A+1][D1P]) and dir_proj's output before the product
+// with rbf_proj (cd [A+1][3][HP]) for the backward pass.
+template <class D, int WAVES, bool TRAIN>
 __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                              const float* __restrict__ dp0b,
                                                              const float* __restrict__ ew, const float* __restrict__ rbuf,
-                                                             float* __restrict__ qbuf) {
+                                                             float* __restrict__ qbuf, float* __restrict__ zd1,
+                                                             float* __restrict__ cdbuf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = EquiStream<D>;
     constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT, G1 = S::G1, G2 = S::G2;
     const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (PRIO && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
 
-    constexpr int KMAX = (S::SLAB + WAVES - 1) / WAVES;
-    const float* pf_src = stream;
-    float* pf_dst = smem;
-    int pf_n = 0, pf_k = 0, pf_next = 0;
+    SlabPrefetch<WAVES, S::SLAB> pf;
+    pf.wave = wave;
+    const float* stream_lane = stream + lane * 4;
     auto pf_begin = [&](int p) {
         const int start = p < WB ? p * G1 : S::C1 + (p - WB) * G2;
-        pf_n = p >= S::NPH ? 0 : (p < WB ? G1 : G2);
-        pf_src = stream + (size_t)start * 256 + lane * 4;
-        pf_dst = smem + (size_t)(p & 1) * S::SLAB * 256;
-        pf_k = 0; pf_next = 1 + (wave >= WAVES / 2 ? 1 : 0);
+        pf.begin(stream_lane, smem, p, start, p >= S::NPH ? 0 : (p < WB ? G1 : G2));
     };
-#ifdef OARD_STAGE_REG_EQUI
-    f4 stage[KMAX];
-    auto hook = [&]() {};
-    auto pf_flush = [&]() {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int j = wave + k * WAVES;
-            if (j < pf_n) *reinterpret_cast<f4*>(pf_dst + j * 256 + lane * 4) = stage[k];
-        }
-    };
-    auto pf_load = [&]() {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int j = wave + k * WAVES;
-            if (j < pf_n) stage[k] = ld_f4(pf_src + (size_t)j * 256);
-        }
-    };
-    auto issue = [&](int p) { pf_begin(p); pf_load(); pf_flush(); };
-    auto pf_start = [&](int p) { pf_begin(p); pf_load(); };
-#else
-    auto pf_one = [&]() {
-        const int j = wave + pf_k * WAVES;
-        if (j < pf_n) glds16(pf_src + (size_t)j * 256, pf_dst + j * 256);
-        ++pf_k;
-    };
-#ifndef OARD_NO_HOOK
-    auto hook = [&]() { if (--pf_next == 0) { pf_one(); pf_next = 3; } };
-#else
-    auto hook = [&]() { while (pf_k < KMAX) pf_one(); };
-#endif
-    auto pf_flush = [&]() { while (pf_k < KMAX) pf_one(); };
-    auto issue = [&](int p) { pf_begin(p); pf_flush(); };
-    auto pf_start = [&](int p) { pf_begin(p); };
-#endif
+    auto hook = [&]() { pf.tick(); };
     auto A = [&](int p, int j) -> f4 {
         return *reinterpret_cast<const f4*>(smem + ((size_t)(p & 1) * S::SLAB + j) * 256 + lane * 4);
     };
@@ -609,35 +352,46 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
 #pragma unroll
     for (int b = 0; b < RB; ++b) rb[b] = ld_blk(rbuf, a, D::RP, b, lane);
     f4 xn = ld_f4(erow);
-    issue(0);
+    pf_begin(0);
+    pf.flush();
 
     int p = 0;
     for (int b = 0; b < WB; ++b, ++p) {
         phase_barrier();
         const f4 x = xn;
-        pf_start(p + 1);
+        pf_begin(p + 1);
         if (b + 1 < WB) xn = ld_f4(erow + 16 * (b + 1));
         chain_kouter<D1T>(SL(p), 0, x, d1, hook);
-        pf_flush();
+        pf.flush();
+    }
+    if (TRAIN) {
+#pragma unroll
+        for (int t = 0; t < D1T; ++t) st_blk(zd1, a, D::D1P, t, lane, d1[t]);
     }
 #pragma unroll
-    for (int t = 0; t < D1T; ++t) d1[t] = EPI_SILU4(d1[t]);
+    for (int t = 0; t < D1T; ++t) d1[t] = silu4(d1[t]);
 
     float* qrow = qbuf + a * (size_t)(3 * D::HP) + 4 * g;
-    f4 pend = f4zero();
+    float* cdrow = TRAIN ? cdbuf + a * (size_t)(3 * D::HP) + 4 * g : nullptr;
+    f4 pend = f4zero(), pendc = f4zero();
     int pend_off = 0;
     for (int i = 0; i < S::NG2; ++i, ++p) {
         phase_barrier();
-        if (i > 0) st_f4(qrow + pend_off, pend);               // store of the previous phase, issued one phase late
-        pf_start(p + 1);
+        if (i > 0) {                                           // stores of the previous phase, issued one phase late
+            st_f4(qrow + pend_off, pend);
+            if (TRAIN) st_f4(cdrow + pend_off, pendc);
+        }
+        pf_begin(p + 1);
         const f4 cd = chain_tile<D1T>(SL(p), 1, d1, A(p, 0), hook);
         const f4 cr = chain_tile<RB>(SL(p), 1 + D1T, rb, f4zero(), hook);
-        pf_flush();
+        pf.flush();
         const int tt = i / 3, th = i - 3 * tt;
         pend = cd * cr;
+        if (TRAIN) pendc = cd;
         pend_off = th * D::HP + 16 * tt;
     }
     st_f4(qrow + pend_off, pend);
+    if (TRAIN) st_f4(cdrow + pend_off, pendc);
 }
 
 // =====================================================================================================

@@ -12,8 +12,9 @@
 #include "oard_edge_v1.h"
 #include "oard_node_v1.h"
 #include "oard_edge_small.h"
+#include "oard_edge_bwd.h"
 
-#define OARD_VERSION 1001
+#define OARD_VERSION 2000
 
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "liboard_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
@@ -48,10 +49,9 @@ struct Timing {
     }
 } g_timing;
 int g_stop_after = 0;
-int g_gcl_variant = 2;     // 0: v0 (weights straight from L2), 1..: LDS-streamed variants
-int g_equi_variant = 2;
+int g_gcl_variant = 2;     // 0: v0 (weights straight from L2), 2: LDS-streamed 8-wave shape, 3: 4-wave shape, 6: latency kernel
+int g_equi_variant = 2;    // 0: v0, 2: LDS-streamed 8-wave shape, 1: 4-wave shape, 4: latency kernel
 int g_sequential = 0;       // 1: run the sub-batches one after the other on the caller stream (profiling)
-int g_gcl_split = 0;        // 0: fused S1+S2+S3 kernel; 1..: S1+S2 kernel followed by a separate S3 kernel (variant id)
 int g_auto_tiny = 8;        // launches of <= 512 * g_auto_tiny edge tiles (all concurrent sub-batches together) use the
                             //    latency kernels of oard_edge_small.h (8 waves share 16 edges); 0 = never
 int g_auto_small = 4;       // 1: small launches use the 4-wave workgroups (one wave per SIMD instead of two): a launch that cannot
@@ -186,9 +186,9 @@ struct ParamIdx {
 struct Packer {
     const float* const* p; float* blob; hipStream_t st;
     void matrix(int src, int src_ld, int col_off, int msl, int msp, int ms, int ksl, int ksp, int ks, int MT, int KB,
-                size_t dst, size_t tstride = 0, size_t bstride = 256, int perm_ht = 0) {
+                size_t dst, size_t tstride = 0, size_t bstride = 256, int perm_ht = 0, int transpose = 0) {
         if (tstride == 0) tstride = (size_t)KB * 256;
-        PackJob j{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst, tstride, bstride, perm_ht};
+        PackJob j{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst, tstride, bstride, perm_ht, transpose};
         const size_t total = (size_t)MT * KB * 256;
         hipLaunchKernelGGL(k_pack_matrix, dim3((unsigned)std::min<size_t>(cdiv(total, 256), 4096)), dim3(256), 0, st, j, blob);
     }
@@ -236,48 +236,36 @@ int set_lds(K kernel, size_t bytes) {
     HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return OARD_OK;
 }
+// the dynamic-LDS limit is a per-device function attribute: track it per (call site, device)
 #define LAUNCH_LDS(fam, kern, grid, block, lds, stream, ...) do { \
-    static bool attr_done_ = false; \
-    if (!attr_done_) { int rc_ = set_lds(kern, lds); if (rc_ != OARD_OK) return rc_; attr_done_ = true; } \
+    static bool attr_done_[64] = {}; \
+    int dev_ = 0; (void)hipGetDevice(&dev_); dev_ &= 63; \
+    if (!attr_done_[dev_]) { int rc_ = set_lds(kern, lds); if (rc_ != OARD_OK) return rc_; attr_done_[dev_] = true; } \
     ScopedLaunch sl_(fam, stream); \
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), lds, stream, __VA_ARGS__); } while (0)
 
-#define GCL_CASE(id, NB_, WV_, GP_, PR_) case id: { \
-        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, NB_, WV_, GP_, PR_, S1, S3>), cdiv(r1 - r0, NB_ * 16 * WV_), WV_ * 64, \
-                   (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew, mbuf); return OARD_OK; }
+#define GCL_CASE(id, WV_, GP_) case id: { \
+        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, WV_, GP_, S1, S3, false>), cdiv(r1 - r0, 16 * WV_), WV_ * 64, \
+                   (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
 template <class D, bool S1, bool S3>
 int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
-                   const float* c0, long long r0, long long r1, float* ew, float* mbuf, hipStream_t st) {
+                   const float* c0, long long r0, long long r1, const float* ew_in, float* ew_out, float* mbuf, const GclTape* tape, hipStream_t st) {
     if (r1 <= r0) return OARD_OK;
+    if (tape) {                  // training-mode forward: one shape (8 waves x 16 edges), pre-activations stored
+        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, true>), cdiv(r1 - r0, 16 * 8), 8 * 64,
+                   (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, *tape);
+        return OARD_OK;
+    }
     if (variant == 2 && cdiv(r1 - r0, 16) * conc <= 1024LL * g_auto_small) variant = 3;
     if ((variant == 2 || variant == 3) && cdiv(r1 - r0, 16) * conc <= 512LL * g_auto_tiny) variant = 6;
     if (variant == 6) {          // latency kernel: 8 waves share 16 edges
         LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_small<D, 8, S1, S3>), cdiv(r1 - r0, 16), 512, (GclSmall<D>::LDS_BYTES), st,
-                   tp, wb, lo, P, Q, u0, c0, r0, r1, ew, mbuf);
+                   tp, wb, lo, P, Q, u0, c0, r0, r1, ew_out, mbuf);
         return OARD_OK;
     }
     switch (variant) {
-        GCL_CASE(1, 2, 4, 2, 0)      // 4 waves x 32 edges, one wave per SIMD
-        GCL_CASE(2, 1, 8, 2, 0)      // 8 waves x 16 edges, two waves per SIMD
-        GCL_CASE(3, 1, 4, 2, 0)      // 4 waves x 16 edges (two workgroups per CU)
-        GCL_CASE(4, 1, 8, 2, 1)      // as 2, static priority for waves 4-7
-        GCL_CASE(5, 1, 4, 1, 3)      // 4 waves x 16 edges, one group per phase, held to 168 registers: 3 workgroups per CU
-        GCL_CASE(7, 2, 8, 2, 0)      // 8 waves x 32 edges, two waves per SIMD (256 registers): half the DMA pieces per edge
-        default: return OARD_EINVAL;
-    }
-}
-#define S3_CASE(id, NB_, WV_, GP_) case id: { \
-        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_s3_v1<D, NB_, WV_, GP_, C0>), cdiv(r1 - r0, NB_ * 16 * WV_), WV_ * 64, \
-                   (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, c0, r0, r1, mbuf, ew); return OARD_OK; }
-template <class D, bool C0>
-int launch_gcl_s3(int variant, const TopoDev& tp, const float* stream, const float* c0, long long r0, long long r1,
-                  const float* mbuf, float* ew, hipStream_t st) {
-    if (r1 <= r0) return OARD_OK;
-    switch (variant) {
-        S3_CASE(1, 2, 8, 2)      // 8 waves x 32 edges
-        S3_CASE(2, 2, 4, 1)      // 4 waves x 32 edges, one group per phase (28 KB LDS: several workgroups per CU)
-        S3_CASE(3, 1, 8, 2)      // 8 waves x 16 edges
-        S3_CASE(4, 2, 4, 2)      // 4 waves x 32 edges
+        GCL_CASE(2, 8, 2)      // 8 waves x 16 edges, two waves per SIMD
+        GCL_CASE(3, 4, 2)      // 4 waves x 16 edges (two workgroups per CU): small launches
         default: return OARD_EINVAL;
     }
 }
@@ -285,40 +273,28 @@ int launch_gcl_s3(int variant, const TopoDev& tp, const float* stream, const flo
 // layer (constant initial state) and S3 in the last (their updated state is never read)
 template <class D>
 int launch_gcl_v1(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
-                  const float* c0, bool first, bool last, float* ew, float* mbuf, hipStream_t st) {
+                  const float* c0, bool first, bool last, const float* ew_in, float* ew_out, float* mbuf, const GclTape* tape, hipStream_t st) {
     const long long A = tp.A, E = tp.E;
     int rc;
-    if (g_gcl_split) {
-        // S1 + S2 (writes m), then S3 from m
-        const bool skip = g_gcl_skip != 0;
-        if (skip && first) {
-            rc = launch_gcl_v1s<D, true, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, A, ew, mbuf, st);
-            if (rc == OARD_OK) rc = launch_gcl_v1s<D, false, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
-        } else {
-            rc = launch_gcl_v1s<D, true, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, E, ew, mbuf, st);
-        }
-        if (rc != OARD_OK) return rc;
-        if (skip && first && !last) {
-            rc = launch_gcl_s3<D, false>(g_gcl_split, tp, stream, c0, 0, A, mbuf, ew, st);
-            if (rc == OARD_OK) rc = launch_gcl_s3<D, true>(g_gcl_split, tp, stream, c0, A, E, mbuf, ew, st);
-            return rc;
-        }
-        if (skip && last) return launch_gcl_s3<D, false>(g_gcl_split, tp, stream, c0, 0, A, mbuf, ew, st);
-        return launch_gcl_s3<D, false>(g_gcl_split, tp, stream, c0, 0, E, mbuf, ew, st);
-    }
-    if (!g_gcl_skip || (!first && !last)) return launch_gcl_v1s<D, true, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, E, ew, mbuf, st);
-    rc = launch_gcl_v1s<D, true, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, A, ew, mbuf, st);
+    const bool skip = g_gcl_skip || tape;
+    if (!skip || (!first && !last)) return launch_gcl_v1s<D, true, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, E, ew_in, ew_out, mbuf, tape, st);
+    rc = launch_gcl_v1s<D, true, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, A, ew_in, ew_out, mbuf, tape, st);
     if (rc != OARD_OK) return rc;
-    if (first && last) return launch_gcl_v1s<D, false, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
-    if (first) return launch_gcl_v1s<D, false, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
-    return launch_gcl_v1s<D, true, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew, mbuf, st);
+    if (first && last) return launch_gcl_v1s<D, false, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew_in, ew_out, mbuf, tape, st);
+    if (first) return launch_gcl_v1s<D, false, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew_in, ew_out, mbuf, tape, st);
+    return launch_gcl_v1s<D, true, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew_in, ew_out, mbuf, tape, st);
 }
-#define EQUI_CASE(id, WV_, PR_) case id: { \
-        LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV_, PR_>), cdiv(tp.A, 16 * WV_), WV_ * 64, (EquiStream<D>::LDS_BYTES), st, \
-                   tp, stream, dp0b, ew, rbuf, qbuf); return OARD_OK; }
+#define EQUI_CASE(id, WV_) case id: { \
+        LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV_, false>), cdiv(tp.A, 16 * WV_), WV_ * 64, (EquiStream<D>::LDS_BYTES), st, \
+                   tp, stream, dp0b, ew, rbuf, qbuf, nullptr, nullptr); return OARD_OK; }
 template <class D>
 int launch_equi_v1(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* dp0b, const float* ew,
-                   const float* rbuf, float* qbuf, hipStream_t st) {
+                   const float* rbuf, float* qbuf, float* zd1, float* cd, hipStream_t st) {
+    if (zd1) {                   // training-mode forward
+        LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, 8, true>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiStream<D>::LDS_BYTES), st,
+                   tp, stream, dp0b, ew, rbuf, qbuf, zd1, cd);
+        return OARD_OK;
+    }
     if (variant == 2 && cdiv(tp.A, 16) * conc <= 512LL * g_auto_small) variant = 1;
     if ((variant == 2 || variant == 1) && cdiv(tp.A, 16) * conc <= 512LL * g_auto_tiny) variant = 4;
     if (variant == 4) {          // latency kernel: 8 waves share 16 edges
@@ -327,20 +303,55 @@ int launch_equi_v1(int variant, int conc, const TopoDev& tp, const float* wb, co
         return OARD_OK;
     }
     switch (variant) {
-        EQUI_CASE(1, 4, 0)
-        EQUI_CASE(2, 8, 0)
-        EQUI_CASE(3, 8, 1)
+        EQUI_CASE(1, 4)
+        EQUI_CASE(2, 8)
         default: return OARD_EINVAL;
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// training tape: what a training-mode forward keeps for the backward pass (byte offsets)
+// ------------------------------------------------------------------------------------------------
+struct TapeOff {
+    size_t hin, geo, rbuf, pp0, x1;                                  // init-stage constants
+    size_t s_in[OARD_MAX_LAYERS + 1], vec_in[OARD_MAX_LAYERS + 1];  // node state at the start of layer l (index L: final)
+    size_t agg[OARD_MAX_LAYERS], s_mid[OARD_MAX_LAYERS];           // mean message per node; s after the GCL node update
+    size_t ew[OARD_MAX_LAYERS + 1];                                  // edge state entering layer l (index L: final)
+    size_t z1[OARD_MAX_LAYERS], z2[OARD_MAX_LAYERS], att[OARD_MAX_LAYERS], z3[OARD_MAX_LAYERS];
+    size_t zd1[OARD_MAX_LAYERS], cd[OARD_MAX_LAYERS];
+    size_t total;
+};
+static TapeOff make_tape(const oard_config* c, const TopoDev& td) {
+    const RDims d(c->hidden, c->num_radial);
+    const size_t N = td.N, E = td.E + 1, A = td.A + 1;
+    TapeOff t;
+    memset(&t, 0, sizeof(t));
+    size_t cur = 0;
+    auto take = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; };
+    t.hin = take(N * 16 * 4); t.geo = take(A * GEO_STRIDE * 4); t.rbuf = take(A * d.RP * 4); t.pp0 = take(N * 4); t.x1 = take(N * 3 * 4);
+    for (int l = 0; l <= c->num_layers; ++l) {
+        t.s_in[l] = take(N * d.HP * 4); t.vec_in[l] = take(N * 3 * d.HP * 4); t.ew[l] = take(E * d.WP * 4);
+        if (l == c->num_layers) break;
+        t.agg[l] = take(N * d.HP * 4); t.s_mid[l] = take(N * d.HP * 4);
+        t.z1[l] = take(E * d.HP * 4); t.z2[l] = take(E * d.HP * 4); t.att[l] = take(E * 4); t.z3[l] = take(E * d.WP * 4);
+        t.zd1[l] = take(A * d.D1P * 4); t.cd[l] = take(A * 3 * d.HP * 4);
+    }
+    t.total = cur;
+    return t;
+}
+
+// `tape` != NULL: training-mode forward (TapeOff layout): every layer's input edge state lives in its own tape
+// buffer (the update is out of place), the edge kernels store their pre-activations, and the node state at the
+// layer boundaries is copied out.  One launch shape, layer-0 / last-layer shortcuts always on.
 template <class D>
 static int forward_impl(const oard_config* c, const TopoPart* topo, const float* wb, const float* const* xh,
-                        const float* t, int t_scalar, const float* cond, float* const* out, char* ws, int* status,
-                        hipStream_t st) {
+                        const float* t, int t_scalar, const float* cond, float* const* out, char* ws, char* tape,
+                        int* status, hipStream_t st) {
     const TopoDev& tp = topo->d;
     const PackOff po = make_layout(c);
     const WsOff w = make_ws(c, tp);
+    const bool train = tape != nullptr;
+    const TapeOff to = train ? make_tape(c, tp) : TapeOff{};
     const int emb = embed_dim(c);
     float* pos = (float*)(ws + w.pos); double* pf64 = (double*)(ws + w.pf64); float* pf32 = (float*)(ws + w.pf32);
     float* x1 = (float*)(ws + w.x1); float* pp0 = (float*)(ws + w.pp0); int* labels = (int*)(ws + w.labels);
@@ -350,8 +361,11 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     float* xq = (float*)(ws + w.xq); float* vec = (float*)(ws + w.vec); float* v2buf = (float*)(ws + w.v2buf);
     float* scal = (float*)(ws + w.sc0); float* vdot = (float*)(ws + w.vdot);
     float* geo = (float*)(ws + w.geo); double* d64 = (double*)(ws + w.d64); float* rbuf = (float*)(ws + w.rbuf);
-    float* ew = (float*)(ws + w.ew); float* mbuf = (float*)(ws + w.mbuf); float* xmsg = (float*)(ws + w.xmsg);
+    float* mbuf = (float*)(ws + w.mbuf); float* xmsg = (float*)(ws + w.xmsg);
     float* vmsg = (float*)(ws + w.vmsg); float* dpos = (float*)(ws + w.dpos); float* hout = (float*)(ws + w.hout);
+    // edge state entering layer l (inference: one buffer updated in place)
+    auto ew_at = [&](int l) -> float* { return train ? (float*)(tape + to.ew[l]) : (float*)(ws + w.ew); };
+    float* ew = ew_at(0);
 
     ObjPtrs op;
     memset(&op, 0, sizeof(op));
@@ -361,13 +375,20 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     const long long N = tp.N, E = tp.E, A = tp.A;
     const unsigned gN = (unsigned)cdiv(N, 64), gE = (unsigned)cdiv(E, 64), gA = (unsigned)cdiv(A, 64);
     const double cutoff = (double)c->cutoff;
+    const int gcl_variant = train ? 2 : g_gcl_variant, equi_variant = train ? 2 : g_equi_variant;
+    const int node_variant = train ? 1 : g_node_variant;
+    const bool gcl_skip = train || g_gcl_skip;
+    const int stop_after = train ? 0 : g_stop_after;
+    auto copy = [&](size_t dst_off, const void* src, size_t bytes) {
+        return hipMemcpyAsync(tape + dst_off, src, bytes, hipMemcpyDeviceToDevice, st);
+    };
 
     LAUNCH(F_OTHER, k_prep, cdiv(N, 128), 128, st, tp, op, wb, pos, hin, t, t_scalar, cond,
            c->condition_nf > 0 ? c->condition_nf : 0, c->condition_time, emb);
     LAUNCH(F_INIT, k_geom, tp.n_groups, 64, st, tp, (const float*)pos, cutoff, pf64, pf32, x1, pp0, labels);
     // inter-object rows start as the constant row; with the layer-0 shortcut nobody reads them before layer 0
     // writes them, so they are only materialised for the unspecialised paths and for the debug tap
-    if (!(g_gcl_skip && g_gcl_variant != 0) || g_stop_after == 1)
+    if (!(gcl_skip && gcl_variant != 0) || stop_after == 1)
         LAUNCH(F_INIT, k_fill_edges, std::min<long long>(cdiv((E - A + 1) * (D::WP / 4), 256), 8192), 256, st,
                wb + po.c0row, ew + (size_t)A * D::WP, E - A + 1, D::WP);
     if (A > 0) {
@@ -379,13 +400,9 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     if (A > 0) LAUNCH(F_INIT, (k_radial_lin<D>), gA, 256, st, tp, wb, po, (const float*)rbuf, (const float*)geo, ew);
     // waves per workgroup of the v1 node stages: one per hidden tile (13 at H = 196), so that every wave owns
     // exactly one tile of each H-wide layer
-#ifndef OARD_NODE_WAVES
     constexpr int NW = D::HT <= 16 ? D::HT : 8;
-#else
-    constexpr int NW = OARD_NODE_WAVES;
-#endif
     const unsigned gNb = (unsigned)cdiv(N, tp.npb);
-    if (g_node_variant >= 1) {
+    if (node_variant >= 1) {
         LAUNCH(F_INIT, (k_neighbor_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s, s1);
         LAUNCH(F_INIT, (k_s2v_agg_v1<D, NW>), gNb, NW * 64, st, tp, (const float*)s1, (const float*)ew, (const float*)geo, ne1);
     } else {
@@ -395,39 +412,56 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     // small launches: one workgroup per (64 edges, hidden tile) instead of per 64 edges
     if (A > 0) LAUNCH2(F_INIT, (k_scalarize<D>), gA, (gA * topo->conc <= 2048 ? D::HT : 1), 256, st, tp, wb, po, (const float*)ne1, (const float*)geo, ew);
     HIP_TRY(hipMemsetAsync(vec, 0, (size_t)N * 3 * D::HP * sizeof(float), st));
-    if (g_stop_after == 1) return OARD_OK;
+    if (train) {
+        HIP_TRY(copy(to.hin, hin, (size_t)N * 16 * 4));
+        HIP_TRY(copy(to.geo, geo, (size_t)(A + 1) * GEO_STRIDE * 4));
+        HIP_TRY(copy(to.rbuf, rbuf, (size_t)(A + 1) * D::RP * 4));
+        HIP_TRY(copy(to.pp0, pp0, (size_t)N * 4));
+        HIP_TRY(copy(to.x1, x1, (size_t)N * 3 * 4));
+    }
+    if (stop_after == 1) return OARD_OK;
 
     float* vec2 = (float*)(ws + w.vec2);
     float* vcur = vec;          // holds the current vec; v1 ping-pongs between vec and vec2
     float* vnext = vec2;
     for (int l = 0; l < c->num_layers; ++l) {
         const LayerOff lo = po.layer[l];
-        const bool nv1 = g_node_variant == 1 && g_equi_variant != 0;
+        const bool nv1 = node_variant == 1 && equi_variant != 0;
         const unsigned gN16 = (unsigned)cdiv(N, tp.npb);
+        float* ew_in = ew_at(l);
+        float* ew_out = ew_at(l + 1);
+        if (train) {
+            HIP_TRY(copy(to.s_in[l], s, (size_t)N * D::HP * 4));
+            HIP_TRY(copy(to.vec_in[l], vcur, (size_t)N * 3 * D::HP * 4));
+        }
 
         if (nv1) LAUNCH(F_NODE, (k_node_pre_v1<D, NW>), gN16, NW * 64, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
         else LAUNCH(F_NODE, (k_node_pre<D>), gN, 256, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
         if (E > 0) {
-            if (g_gcl_variant == 0) {
-                LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew, mbuf);
+            if (gcl_variant == 0) {
+                LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew_in, mbuf);
             } else {
-                int rc = launch_gcl_v1<D>(g_gcl_variant, topo->conc, tp, wb, lo, wb + lo.gcl_stream, P, Q, wb + po.u0, wb + po.c0row, l == 0,
-                                          l == c->num_layers - 1, ew, mbuf, st);
+                GclTape gt{};
+                if (train) gt = GclTape{(float*)(tape + to.z1[l]), (float*)(tape + to.z2[l]), (float*)(tape + to.att[l]), (float*)(tape + to.z3[l])};
+                int rc = launch_gcl_v1<D>(gcl_variant, topo->conc, tp, wb, lo, wb + lo.gcl_stream, P, Q, wb + po.u0, wb + po.c0row, l == 0,
+                                          l == c->num_layers - 1, ew_in, ew_out, mbuf, train ? &gt : nullptr, st);
                 if (rc != OARD_OK) return rc;
             }
         }
-        hipStream_t sn = st;
-        if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW>), gN16, NW * 64, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
-        else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, sn, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
-        if (g_stop_after == 100 + 10 * l + 1) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
-        if (g_equi_variant == 0) {
-            if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew, (const float*)rbuf,
+        if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW>), gN16, NW * 64, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq,
+                        train ? (float*)(tape + to.agg[l]) : nullptr);
+        else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
+        if (train) HIP_TRY(copy(to.s_mid[l], s, (size_t)N * D::HP * 4));
+        if (stop_after == 100 + 10 * l + 1) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
+        if (equi_variant == 0) {
+            if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew_out, (const float*)rbuf,
                               (const float*)geo, (const float*)xq, (const float*)vcur, xmsg, vmsg);
             LAUNCH(F_NODE, (k_equi_agg<D>), gN, 256, st, tp, wb, lo, (const float*)xmsg, (const float*)vmsg, (const float*)x1,
                    s, vcur, v2buf, scal, vdot);
         } else {
             if (A > 0) {
-                int rc = launch_equi_v1<D>(g_equi_variant, topo->conc, tp, wb, lo, wb + lo.equi_stream, wb + lo.dp0b, ew, rbuf, vmsg, st);
+                int rc = launch_equi_v1<D>(equi_variant, topo->conc, tp, wb, lo, wb + lo.equi_stream, wb + lo.dp0b, ew_out, rbuf, vmsg,
+                                           train ? (float*)(tape + to.zd1[l]) : nullptr, train ? (float*)(tape + to.cd[l]) : nullptr, st);
                 if (rc != OARD_OK) return rc;
             }
             if (nv1) {
@@ -441,10 +475,14 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
         }
         if (!nv1) LAUNCH(F_NODE, (k_equi_upd<D>), gN, 256, st, tp, wb, lo, (const float*)scal, (const float*)vdot,
                          (const float*)v2buf, s, vcur);
-        if (g_stop_after == 100 + 10 * l + 2) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
+        if (stop_after == 100 + 10 * l + 2) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
     }
     topo->vec_final = (size_t)((char*)vcur - ws);
-    if (g_node_variant >= 1)
+    if (train) {
+        HIP_TRY(copy(to.s_in[c->num_layers], s, (size_t)N * D::HP * 4));
+        HIP_TRY(copy(to.vec_in[c->num_layers], vcur, (size_t)N * 3 * D::HP * 4));
+    }
+    if (node_variant >= 1)
         LAUNCH(F_NODE, (k_out_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)s, (const float*)vcur, dpos, hout, status);
     else
         LAUNCH(F_NODE, (k_out<D>), gN, 256, st, tp, wb, po, (const float*)s, (const float*)vcur, dpos, hout, status);
@@ -461,6 +499,65 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
         else return OARD_EINVAL;                                                           \
     } while (0)
 
+// ---- transposed weight streams of the backward edge kernels -----------------------------------------------------
+struct BwdLayerOff { size_t gcl, equi, watt; };
+struct BwdOff { BwdLayerOff layer[OARD_MAX_LAYERS]; size_t total; };
+static BwdOff make_bwd_layout(const oard_config* c) {
+    const RDims d(c->hidden, c->num_radial);
+    BwdOff b;
+    memset(&b, 0, sizeof(b));
+    size_t cur = 0;
+    auto take = [&](size_t n) { size_t o = cur; cur = align_up(cur + n, 64); return o; };
+    for (int l = 0; l < c->num_layers; ++l) {
+        b.layer[l].gcl = take((size_t)(2 * d.WB * d.HT + d.HT * d.HT) * 256);
+        b.layer[l].equi = take((size_t)(3 * d.HT * d.D1T + d.WB * d.D1T) * 256);
+        b.layer[l].watt = take(d.HP);
+    }
+    b.total = cur;
+    return b;
+}
+template <class D>
+static int gcl_backward_impl(const oard_config* c, const TopoDev& tp, const float* pb, const BwdLayerOff& bl, int layer,
+                             const char* tape, const TapeOff& to, const float* dagg, float* dew, float* dz3, float* mout,
+                             float* dz2, float* da, float* dz1, hipStream_t st) {
+    GclBwdArgs a;
+    a.z1 = (const float*)(tape + to.z1[layer]); a.z2 = (const float*)(tape + to.z2[layer]);
+    a.att = (const float*)(tape + to.att[layer]); a.z3 = (const float*)(tape + to.z3[layer]);
+    a.dagg = dagg; a.watt = pb + bl.watt; a.dew = dew; a.dz3 = dz3; a.mout = mout; a.dz2 = dz2; a.da = da; a.dz1 = dz1;
+    const float* stream = pb + bl.gcl;
+    const bool last = layer == c->num_layers - 1;
+    const long long r_full = last ? tp.A : tp.E;       // rows whose forward ran S3
+    if (r_full > 0)
+        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_bwd<D, 8, 2, true>), cdiv(r_full, 128), 512, (GclBwdStream<D, 2>::LDS_BYTES), st,
+                   tp, stream, 0LL, r_full, a);
+    if (last && tp.E > tp.A)
+        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_bwd<D, 8, 2, false>), cdiv(tp.E - tp.A, 128), 512, (GclBwdStream<D, 2>::LDS_BYTES), st,
+                   tp, stream, tp.A, tp.E, a);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+template <class D>
+static int equi_backward_impl(const TopoDev& tp, const float* stream, const float* dcd, const float* zd1, float* dew,
+                              float* dzd1, hipStream_t st) {
+    LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_bwd<D, 8>), cdiv(tp.A, 128), 512, (EquiBwdStream<D>::LDS_BYTES), st, tp, stream, dcd,
+               zd1, dew, dzd1);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+// chunking of the weight-gradient GEMM: a pure function of the shape, so that the summation order (and with it the
+// result, bit for bit) does not depend on anything else
+struct WgradPlan { int gy, gz, MOp, MIp; long long rpc; int n_chunks; };
+static WgradPlan wgrad_plan(int ncY, int ncX, long long rows) {
+    WgradPlan p;
+    p.gy = (int)cdiv(ncY, 128); p.gz = (int)cdiv(ncX, 256); p.MOp = p.gy * 128; p.MIp = p.gz * 256;
+    long long want = std::max<long long>(1, 1024 / (p.gy * p.gz));
+    want = std::min(want, std::max<long long>(1, cdiv(rows, 64)));
+    p.rpc = align_up((size_t)cdiv(std::max<long long>(rows, 1), want), 16);
+    p.n_chunks = (int)cdiv(std::max<long long>(rows, 1), p.rpc);
+    return p;
+}
 }  // namespace
 
 extern "C" {
@@ -686,6 +783,11 @@ static int build_part(const oard_config* c, const int64_t* cm, const int64_t* nf
 
 int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t* nfs, int64_t n_nodes,
                          oard_topology** out) {
+    return oard_topology_create_parts(c, cm, nfs, n_nodes, g_parts, out);
+}
+
+int oard_topology_create_parts(const oard_config* c, const int64_t* cm, const int64_t* nfs, int64_t n_nodes,
+                               int parts, oard_topology** out) {
     if (!config_ok(c) || !cm || !nfs || !out || n_nodes < 1 || n_nodes > (1 << 24)) return OARD_EINVAL;
     const int N = (int)n_nodes, n_obj = c->n_obj;
     std::vector<int> obj_start(n_obj + 1, 0);
@@ -710,7 +812,7 @@ int oard_topology_create(const oard_config* c, const int64_t* cm, const int64_t*
     long long E_all = 0;
     for (int r = 0; r < N; ++r) { ref_ptr_ref[r] = E_all; E_all += ns_of[dense[r]] - 1; }
 
-    int n_parts = g_parts > 0 ? g_parts : (B >= 32 ? 4 : (B >= 16 ? 2 : 1));
+    int n_parts = parts > 0 ? parts : (B >= 32 ? 4 : (B >= 16 ? 2 : 1));
     n_parts = std::max(1, std::min(std::min(n_parts, OARD_MAX_PARTS), B));
     oard_topology* tp = new oard_topology();
     tp->n_obj = n_obj; tp->B = B; tp->n_parts = n_parts;
@@ -807,7 +909,7 @@ int oard_forward(const oard_config* c, const oard_topology* topo, const void* pa
         if (concurrent && p > 0) HIP_TRY(hipStreamWaitEvent(sp, topo->ev_fork, 0));
         int rc = OARD_EINVAL;
         DISPATCH_DIMS(c, rc = forward_impl<D>(c, &topo->parts[p], (const float*)packed, xh, t, t_is_scalar, cond, out,
-                                              (char*)ws + topo->parts[p].ws_off, (int*)status, sp));
+                                              (char*)ws + topo->parts[p].ws_off, nullptr, (int*)status, sp));
         if (rc != OARD_OK) return rc;
         if (concurrent && p > 0) HIP_TRY(hipEventRecord(topo->ev_join[p], sp));
     }
@@ -837,6 +939,202 @@ int oard_sampler_step(const oard_config* c, const oard_topology* topo, int mode,
     for (int p = 0; p < topo->n_parts; ++p)
         LAUNCH(F_OTHER, k_sampler_step, cdiv(topo->parts[p].d.N, 128), 128, st, topo->parts[p].d, sp, mode, a, b, cc,
                zero_feature_noise);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// training: tape, training-mode forward, backward of the edge stages, weight-gradient GEMM
+// ------------------------------------------------------------------------------------------------
+int oard_topology_export(const oard_topology* topo, int which, int32_t* dst, int64_t capacity, oard_stream_t stream) {
+    if (!topo || !dst || topo->n_parts != 1) return OARD_EINVAL;
+    const TopoDev& d = topo->parts[0].d;
+    const int* src = nullptr;
+    long long n = 0;
+    switch (which) {
+        case OARD_TOPO_NODE_REF: src = d.node_ref; n = d.N; break;
+        case OARD_TOPO_NODE_OBJ: src = d.node_obj; n = d.N; break;
+        case OARD_TOPO_NODE_ROW: src = d.node_row; n = d.N; break;
+        case OARD_TOPO_NODE_SAMPLE: src = d.node_sample; n = d.N; break;
+        case OARD_TOPO_NODE_TIDX: src = d.node_tidx; n = d.N; break;
+        case OARD_TOPO_SAMPLE_PTR: src = d.sample_ptr; n = d.B + 1; break;
+        case OARD_TOPO_GROUP_PTR: src = d.grp_ptr; n = d.n_groups + 1; break;
+        case OARD_TOPO_INNER_SRC: src = d.act_src; n = d.A; break;
+        case OARD_TOPO_INNER_TGT: src = d.act_tgt; n = d.A; break;
+        case OARD_TOPO_ROW_SRC: src = d.row_src; n = d.E; break;
+        case OARD_TOPO_ROW_TGT: src = d.row_tgt; n = d.E; break;
+        default: return OARD_EINVAL;
+    }
+    if (capacity < n) return OARD_ENOMEM;
+    if (n > 0) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return OARD_OK;
+}
+
+size_t oard_tape_bytes(const oard_config* c, const oard_topology* topo) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1) return 0;
+    return make_tape(c, topo->parts[0].d).total;
+}
+
+int oard_tape_entry(const oard_config* c, const oard_topology* topo, int which, int layer, size_t* offset_bytes,
+                    int64_t* rows, int64_t* row_floats) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1 || !offset_bytes || !rows || !row_floats) return OARD_EINVAL;
+    const TopoDev& d = topo->parts[0].d;
+    const TapeOff t = make_tape(c, d);
+    const RDims r(c->hidden, c->num_radial);
+    const int L = c->num_layers;
+    const bool per_layer = which >= OARD_TAPE_S_IN;
+    const bool plus1 = which == OARD_TAPE_S_IN || which == OARD_TAPE_VEC_IN || which == OARD_TAPE_EW;
+    if (per_layer ? (layer < 0 || layer >= L + (plus1 ? 1 : 0)) : layer != 0) return OARD_EINVAL;
+    const int64_t N = d.N, E1 = d.E + 1, A1 = d.A + 1;
+    switch (which) {
+        case OARD_TAPE_HIN: *offset_bytes = t.hin; *rows = N; *row_floats = 16; break;
+        case OARD_TAPE_GEO: *offset_bytes = t.geo; *rows = A1; *row_floats = GEO_STRIDE; break;
+        case OARD_TAPE_RBF: *offset_bytes = t.rbuf; *rows = A1; *row_floats = r.RP; break;
+        case OARD_TAPE_PP0: *offset_bytes = t.pp0; *rows = N; *row_floats = 1; break;
+        case OARD_TAPE_X1: *offset_bytes = t.x1; *rows = N; *row_floats = 3; break;
+        case OARD_TAPE_S_IN: *offset_bytes = t.s_in[layer]; *rows = N; *row_floats = r.HP; break;
+        case OARD_TAPE_VEC_IN: *offset_bytes = t.vec_in[layer]; *rows = N; *row_floats = 3 * r.HP; break;
+        case OARD_TAPE_AGG: *offset_bytes = t.agg[layer]; *rows = N; *row_floats = r.HP; break;
+        case OARD_TAPE_S_MID: *offset_bytes = t.s_mid[layer]; *rows = N; *row_floats = r.HP; break;
+        case OARD_TAPE_EW: *offset_bytes = t.ew[layer]; *rows = E1; *row_floats = r.WP; break;
+        case OARD_TAPE_Z1: *offset_bytes = t.z1[layer]; *rows = E1; *row_floats = r.HP; break;
+        case OARD_TAPE_Z2: *offset_bytes = t.z2[layer]; *rows = E1; *row_floats = r.HP; break;
+        case OARD_TAPE_ATT: *offset_bytes = t.att[layer]; *rows = E1; *row_floats = 1; break;
+        case OARD_TAPE_Z3: *offset_bytes = t.z3[layer]; *rows = E1; *row_floats = r.WP; break;
+        case OARD_TAPE_ZD1: *offset_bytes = t.zd1[layer]; *rows = A1; *row_floats = r.D1P; break;
+        case OARD_TAPE_CD: *offset_bytes = t.cd[layer]; *rows = A1; *row_floats = 3 * r.HP; break;
+        default: return OARD_EINVAL;
+    }
+    return OARD_OK;
+}
+
+int oard_forward_train(const oard_config* c, const oard_topology* topo, const void* packed, const float* const* xh,
+                       const float* t, int t_is_scalar, const float* cond, float* const* out, void* ws, size_t ws_bytes,
+                       void* tape, size_t tape_bytes, int32_t* status, oard_stream_t stream) {
+    if (!config_ok(c) || !topo || !packed || !xh || !out || !ws || !tape || !status) return OARD_EINVAL;
+    if (topo->n_parts != 1 || c->n_obj != topo->n_obj) return OARD_EINVAL;
+    if (c->condition_time && !t) return OARD_EINVAL;
+    if (c->condition_nf > 0 && !cond) return OARD_EINVAL;
+    if (ws_bytes < ws_total(c, topo) || tape_bytes < make_tape(c, topo->parts[0].d).total) return OARD_ENOMEM;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), st));
+    if (g_poison) {
+        HIP_TRY(hipMemsetAsync(ws, 0xFF, ws_total(c, topo), st));
+        HIP_TRY(hipMemsetAsync(tape, 0xFF, make_tape(c, topo->parts[0].d).total, st));
+    }
+    int rc = OARD_EINVAL;
+    DISPATCH_DIMS(c, rc = forward_impl<D>(c, &topo->parts[0], (const float*)packed, xh, t, t_is_scalar, cond, out,
+                                          (char*)ws + topo->parts[0].ws_off, (char*)tape, (int*)status, st));
+    return rc;
+}
+
+size_t oard_packed_bwd_bytes(const oard_config* c) { return config_ok(c) ? make_bwd_layout(c).total * sizeof(float) : 0; }
+
+int oard_pack_weights_bwd(const oard_config* c, const float* const* params, size_t n_params, void* packed,
+                          size_t packed_bytes, oard_stream_t stream) {
+    if (!config_ok(c) || !params || !packed) return OARD_EINVAL;
+    const ParamIdx pi(c);
+    if (n_params != (size_t)pi.count) return OARD_EINVAL;
+    const BwdOff bo = make_bwd_layout(c);
+    if (packed_bytes < bo.total * sizeof(float)) return OARD_ENOMEM;
+    const RDims d(c->hidden, c->num_radial);
+    const int H = d.H, W = d.W;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(packed, 0, bo.total * sizeof(float), st));
+    Packer pk{params, (float*)packed, st};
+    for (int l = 0; l < c->num_layers; ++l) {
+        const int g = pi.gcl0 + 14 * l, m = pi.msg0 + 9 * l;
+        const size_t t3 = bo.layer[l].gcl, t2 = t3 + (size_t)d.WB * d.HT * 256, t1 = t2 + (size_t)d.HT * d.HT * 256;
+        // W3^T, K-outer over the WB blocks of dz3: chunk (t, b) = W3[16b..][16t..]^T
+        pk.matrix(g + 8, H, 0, H, d.HP, 1, W, d.WP, 1, d.HT, d.WB, t3, 256, (size_t)d.HT * 256, 0, 1);
+        // W2^T tiles
+        pk.matrix(g + 2, H, 0, H, d.HP, 1, H, d.HP, 1, d.HT, d.HT, t2, 0, 256, 0, 1);
+        // W1c^T tiles (edge_mlp.0 columns 2H..2H+W)
+        pk.matrix(g + 0, 2 * H + W, 2 * H, W, d.WP, 1, H, d.HP, 1, d.WB, d.HT, t1, 0, 256, 0, 1);
+        pk.vec(g + 10, H, d.HP, 1, d.HP, bo.layer[l].watt);
+        const size_t u2 = bo.layer[l].equi, u1 = u2 + (size_t)3 * d.HT * d.D1T * 256;
+        // dir_proj.2^T, K-outer over the 3*HT blocks of dcd (thirds padded 196 -> 208): rows = dir_proj hidden
+        pk.matrix(m + 2, 3 * H, 0, 3 * H, d.D1P, 1, H, d.HP, 3, d.D1T, 3 * d.HT, u2, 256, (size_t)d.D1T * 256, 0, 1);
+        // dir_proj.0^T tiles
+        pk.matrix(m + 0, W, 0, W, d.WP, 1, 3 * H, d.D1P, 1, d.WB, d.D1T, u1, 0, 256, 0, 1);
+    }
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+int oard_gcl_backward_dx(const oard_config* c, const oard_topology* topo, const void* packed_bwd, int layer,
+                         const void* tape, const float* dagg, float* dew, float* dz3, float* mout, float* dz2,
+                         float* da, float* dz1, oard_stream_t stream) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1 || !packed_bwd || !tape || !dagg || !dew || !dz3 || !mout || !dz2 ||
+        !da || !dz1 || layer < 0 || layer >= c->num_layers)
+        return OARD_EINVAL;
+    const TopoDev& tp = topo->parts[0].d;
+    if (tp.E == 0) return OARD_OK;
+    const TapeOff to = make_tape(c, tp);
+    const BwdOff bo = make_bwd_layout(c);
+    int rc = OARD_EINVAL;
+    DISPATCH_DIMS(c, rc = gcl_backward_impl<D>(c, tp, (const float*)packed_bwd, bo.layer[layer], layer, (const char*)tape, to,
+                                               dagg, dew, dz3, mout, dz2, da, dz1, (hipStream_t)stream));
+    return rc;
+}
+
+int oard_equi_backward_dx(const oard_config* c, const oard_topology* topo, const void* packed_bwd, int layer,
+                          const void* tape, const float* dcd, float* dew, float* dzd1, oard_stream_t stream) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1 || !packed_bwd || !tape || !dcd || !dew || !dzd1 || layer < 0 ||
+        layer >= c->num_layers)
+        return OARD_EINVAL;
+    const TopoDev& tp = topo->parts[0].d;
+    if (tp.A == 0) return OARD_OK;
+    const TapeOff to = make_tape(c, tp);
+    const BwdOff bo = make_bwd_layout(c);
+    int rc = OARD_EINVAL;
+    DISPATCH_DIMS(c, rc = equi_backward_impl<D>(tp, (const float*)packed_bwd + bo.layer[layer].equi, dcd,
+                                                (const float*)((const char*)tape + to.zd1[layer]), dew, dzd1, (hipStream_t)stream));
+    return rc;
+}
+
+int oard_edge_node_sums(const oard_config* c, const oard_topology* topo, const float* dz1, float* dP, float* dQ,
+                        oard_stream_t stream) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1 || !dz1 || !dP || !dQ) return OARD_EINVAL;
+    const TopoDev& tp = topo->parts[0].d;
+    const RDims d(c->hidden, c->num_radial);
+    if (d.HP > 256) return OARD_EINVAL;
+    LAUNCH(F_NODE, k_edge_node_sums, tp.N, 64, (hipStream_t)stream, tp, dz1, d.HP, dP, dQ);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows) {
+    if (ncY < 4 || ncX < 4 || rows < 0) return 0;
+    const WgradPlan p = wgrad_plan(ncY, ncX, rows);
+    return ((size_t)p.n_chunks * p.MOp * p.MIp + (size_t)p.n_chunks * p.MOp) * sizeof(float);
+}
+
+int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, const float* X, int ldX, int ncX,
+               int x_silu, int i_len, int i_pad, int MI, int64_t rows, float* dW, float* db, void* scratch,
+               size_t scratch_bytes, oard_stream_t stream) {
+    if (!dY || !X || !dW || !scratch || rows < 0 || (ncY & 3) || (ncX & 3) || (ldY & 3) || (ldX & 3) || ncY > ldY ||
+        ncX > ldX || o_len < 1 || i_len < 1 || o_pad < o_len || i_pad < i_len || MO < 1 || MI < 1)
+        return OARD_EINVAL;
+    if (((MO - 1) / o_len) * o_pad + (MO - 1) % o_len >= ncY || ((MI - 1) / i_len) * i_pad + (MI - 1) % i_len >= ncX)
+        return OARD_EINVAL;
+    const WgradPlan p = wgrad_plan(ncY, ncX, rows);
+    if (scratch_bytes < oard_wgrad_scratch_bytes(ncY, ncX, rows)) return OARD_ENOMEM;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)scratch;
+    float* bpartial = partial + (size_t)p.n_chunks * p.MOp * p.MIp;
+    ScopedLaunch sl_(F_OTHER, st);
+    if (x_silu)
+        hipLaunchKernelGGL(k_wgrad<true>, dim3(p.n_chunks, p.gy, p.gz), dim3(256), 0, st, dY, ldY, ncY, X, ldX, ncX, 0LL,
+                           (long long)rows, p.rpc, partial, db ? bpartial : nullptr, p.MOp, p.MIp);
+    else
+        hipLaunchKernelGGL(k_wgrad<false>, dim3(p.n_chunks, p.gy, p.gz), dim3(256), 0, st, dY, ldY, ncY, X, ldX, ncX, 0LL,
+                           (long long)rows, p.rpc, partial, db ? bpartial : nullptr, p.MOp, p.MIp);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 256)), dim3(256), 0, st, partial, p.n_chunks,
+                       p.MOp, p.MIp, o_len, o_pad, MO, i_len, i_pad, MI, dW);
+    if (db)
+        hipLaunchKernelGGL(k_bgrad_reduce, dim3((unsigned)cdiv(MO, 256)), dim3(256), 0, st, bpartial, p.n_chunks, p.MOp,
+                           o_len, o_pad, MO, db);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
@@ -885,7 +1183,6 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
     if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
-    if (strcmp(name, "gcl_split") == 0) { g_gcl_split = value; return OARD_OK; }
     if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }
     if (strcmp(name, "poison") == 0) { g_poison = value; return OARD_OK; }
     if (strcmp(name, "auto_small") == 0) { g_auto_small = value; return OARD_OK; }

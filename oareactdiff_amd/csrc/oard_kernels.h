@@ -49,6 +49,8 @@ struct PackJob {
     // perm_ht > 0 (thirds interleave): slot(t) = (t % perm_ht) * 3 + t / perm_ht
     size_t tstride, bstride;
     int perm_ht;
+    int transpose;                // 1: the chunk rows index the SOURCE columns and the chunk K index the source rows
+                                  //    (packs W^T for the backward pass: dX = W^T dY); col_off applies to the row index
 };
 
 // matrix -> MFMA chunks: dst[((t*KB + b)*64 + lane)*4 + c] = W[row(16t + (lane&15))][col(16b + 4(lane>>4) + c)]
@@ -63,7 +65,8 @@ __global__ void k_pack_matrix(PackJob j, float* __restrict__ blob) {
         const int ks = k / j.ksect_pad, kw = k % j.ksect_pad;
         float v = 0.f;
         if (rs < j.msects && rw < j.msect_len && ks < j.ksects && kw < j.ksect_len)
-            v = j.src[(size_t)(rs * j.msect_len + rw) * j.src_ld + j.col_off + ks * j.ksect_len + kw];
+            v = j.transpose ? j.src[(size_t)(ks * j.ksect_len + kw) * j.src_ld + j.col_off + rs * j.msect_len + rw]
+                            : j.src[(size_t)(rs * j.msect_len + rw) * j.src_ld + j.col_off + ks * j.ksect_len + kw];
         const int slot = j.perm_ht > 0 ? (t % j.perm_ht) * 3 + t / j.perm_ht : t;
         blob[j.dst + (size_t)slot * j.tstride + (size_t)b * j.bstride + (i & 255)] = v;
     }

@@ -210,7 +210,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_node_pre_v1(TopoDev tp, const fl
 template <class D, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const float* __restrict__ wb, LayerOff lo,
                                                             const float* __restrict__ xh, const float* __restrict__ mbuf,
-                                                            float* __restrict__ s, float* __restrict__ xq) {
+                                                            float* __restrict__ s, float* __restrict__ xq,
+                                                            float* __restrict__ agg_out /* training tape, or NULL */) {
     __shared__ __attribute__((aligned(16))) float sm[4 * D::HT * 256];
     float* in = sm;                        // [2 HT]: xh | agg      (later: xln | hq)
     float* hm = sm + 2 * D::HT * 256;      // [HT]
@@ -226,11 +227,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
         f4 a0 = f4zero(), a1 = f4zero();
         // 8 message rows in flight per step (branch-free: out-of-range slots re-read the last row with weight 0)
         const int last = max(deg - 1, 0);
-#ifdef OARD_ABL_NOGATHER
-        for (int k = 0; k < 0; k += 8) {
-#else
         for (int k = 0; k < mx; k += 8) {
-#endif
             f4 r[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) r[i] = ld_blk(mbuf, e0 + min(k + i, last), D::HP, t, nb.lane);
@@ -241,6 +238,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
             }
         }
         lds_st(in, D::HT + t, nb.lane, (a0 + a1) * inv);
+        if (agg_out != nullptr && nb.valid) st_blk(agg_out, nb.n, D::HP, t, nb.lane, (a0 + a1) * inv);
     }
     __syncthreads();
     constexpr int TPW = (D::HT + WAVES - 1) / WAVES, TPW3 = (3 * D::HT + WAVES - 1) / WAVES;
@@ -393,11 +391,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         int mnext[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) mnext[i] = tp.act_src[(size_t)min((long long)a0 + min(i, max(cnt - 1, 0)), a_hi)];
-#ifdef OARD_ABL_NOGATHER
-        for (int k = 0; k < 0; k += 2) {
-#else
         for (int k = 0; k < mx; k += 2) {
-#endif
             f4 q0[2], q1[2], q2[2], y0[2], y1[2], y2[2], w0[2], w1[2], w2[2];
             float gx[2], gy[2], gz[2];
             const int mc[2] = {mnext[0], mnext[1]};
@@ -460,9 +454,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
             vdk[i] = (v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2]) * inv_sqrt_h;
             f4 sca;
             const int f0 = 16 * t + 4 * nb.g;
-#ifdef OARD_ABL_NOLIN3U
-            sca = sc;
-#else
             if (tp.npb <= 4) {
                 // one value per lane: lane -> (feature lane >> 2, column lane & 3) of this tile, through the LDS block
                 float* blk = in + (HT + t) * 256;
@@ -478,10 +469,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                 sca.z = f0 + 2 < D::H ? sca.z : 0.f; sca.w = f0 + 3 < D::H ? sca.w : 0.f;
                 lds_st(in, HT + t, nb.lane, sca);
             }
-#endif
-#ifdef OARD_ABL_NOLIN3U
-            lds_st(in, HT + t, nb.lane, sca);
-#endif
         }
     }
     __syncthreads();

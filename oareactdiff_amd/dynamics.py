@@ -141,6 +141,8 @@ class EGNNDynamics(nn.Module):
         self.last_status: Optional[Tensor] = None
         self._packed: Optional[Tensor] = None
         self._packed_key = None
+        self._packed_bwd: Optional[Tensor] = None
+        self._packed_bwd_key = None
         self._topo_cache: "OrderedDict[tuple, _Topology]" = OrderedDict()
         self._ws: Optional[Tensor] = None
         self._last_topo: Optional["_Topology"] = None
@@ -193,6 +195,51 @@ class EGNNDynamics(nn.Module):
         self._packed, self._packed_key = packed, key
         return packed
 
+    def _get_packed_bwd(self, cfg: _capi.OardConfig, stream: int) -> Tensor:
+        """Transposed weight streams of the backward edge kernels (repacked when a parameter changes)."""
+        tensors = self._ordered_tensors()
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._packed_bwd is not None and key == self._packed_bwd_key:
+            return self._packed_bwd
+        L = _capi.lib()
+        n = L.oard_param_count(C.byref(cfg))
+        nbytes = L.oard_packed_bwd_bytes(C.byref(cfg))
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=tensors[0].device)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        _capi.check(L.oard_pack_weights_bwd(C.byref(cfg), ptrs, n, packed.data_ptr(), nbytes, stream), "oard_pack_weights_bwd")
+        self._packed_bwd, self._packed_bwd_key = packed, key
+        return packed
+
+    def _param_names(self) -> List[str]:
+        """Canonical (first) state-dict name of every distinct trainable parameter, in state-dict order."""
+        seen, names = set(), []
+        for name, t in zip(self._spec, self._ordered_tensors()):
+            if isinstance(t, nn.Parameter) and id(t) not in seen:
+                seen.add(id(t))
+                names.append(name)
+        return names
+
+    def _param_dict(self) -> Dict[str, Tensor]:
+        canon = set(self._param_names())
+        return {name: t for name, t in zip(self._spec, self._ordered_tensors()) if name in canon}
+
+    def _module_prefix(self, kind: str, k: int) -> str:
+        """Canonical state-dict prefix of the module sitting at encoders[k] / decoders[k] (enforce_same_encoding aliases)."""
+        mods = getattr(self, kind)
+        for j in range(len(mods)):
+            if mods[j] is mods[k]:
+                return f"{kind}.{j}."
+        return f"{kind}.{k}."
+
+    @staticmethod
+    def _c0row(P: Dict[str, Tensor], H: int, R: int) -> Tensor:
+        """State of a masked (inter-object) edge: [lin3(0) x 2H | radial_lin(0) | 0 x R]  (leftnet.py:768-809 with dist = 0)."""
+        m = "model."
+        c0f = torch.nn.functional.linear(torch.nn.functional.silu(P[m + "radial_lin.0.bias"]), P[m + "radial_lin.2.weight"],
+                                         P[m + "radial_lin.2.bias"])
+        c0s = (torch.nn.functional.silu(P[m + "lin3.0.bias"]) @ P[m + "lin3.2.weight"].t() + P[m + "lin3.2.bias"]).reshape(())
+        return torch.cat([c0s.expand(2 * H), c0f, torch.zeros(R, dtype=c0f.dtype, device=c0f.device)])
+
     def _get_topology(self, cfg, edge_index: Tensor, n_frag_switch: Tensor, combined_mask: Tensor,
                       stream: int) -> "_Topology":
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
@@ -203,6 +250,9 @@ class EGNNDynamics(nn.Module):
             self._topo_cache.move_to_end(key)
             return topo
         topo = _Topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+        # the key is made of addresses and versions: the entry keeps the three tensors alive so that the caching
+        # allocator cannot hand their storage to a different layout of the same size while the entry exists
+        topo.key_tensors = (edge_index, n_frag_switch, combined_mask)
         self._topo_cache[key] = topo
         while len(self._topo_cache) > 8:
             self._topo_cache.popitem(last=False)
@@ -223,9 +273,7 @@ class EGNNDynamics(nn.Module):
             raise NotImplementedError                                     # egnn_dynamics.py:125
         if edge_attr is not None:
             raise NotImplementedError("edge attributes are not part of the LEFTNet denoising path")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the MI355X backend is forward-only in this release: call it under "
-                                      "torch.no_grad() (sampling / inpainting)")
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         dev = xh[0].device
         if dev.type != "cuda":
             raise _capi.OardError("EGNNDynamics.forward needs tensors on a ROCm device (no CPU fallback)")
@@ -235,6 +283,8 @@ class EGNNDynamics(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             packed = self._get_packed(cfg, stream)
+            if train:
+                return self._forward_train(cfg, packed, xh, edge_index, t, conditions, n_frag_switch, combined_mask, stream)
             topo = self._get_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
             n_obj = len(self.node_nfs)
             xs = []
@@ -247,10 +297,7 @@ class EGNNDynamics(nn.Module):
                                           f"{(topo.obj_counts[k], self.node_nfs[k])}")
                 xs.append(x)
             outs = [torch.empty_like(x) for x in xs]
-            t_scalar = 1 if t.dim() == 1 else 0
-            tt = t.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
-            if not t_scalar and tt.numel() <= topo.max_sample_id:
-                raise _capi.OardError("t has fewer rows than samples")
+            tt, t_scalar = self._time_argument(t, dev, topo.max_sample_id)
             cond = None
             if self.condition_nf > 0:
                 cond = conditions.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -279,6 +326,72 @@ class EGNNDynamics(nn.Module):
                         v = v - (mean / cnt.clamp(min=1).unsqueeze(1))[idx]
                     outs[k][:, : self.pos_dim] = v
         return outs, None
+
+    @staticmethod
+    def _time_argument(t: Tensor, dev, max_sample_id: int) -> Tuple[Tensor, int]:
+        """egnn_dynamics.py:106-114: a 1-D t is ONE value for every node (`t.item()`, which raises unless numel == 1);
+        otherwise t is indexed by combined_mask, i.e. [B, 1] with a row per sample."""
+        tt = t.detach().to(device=dev, dtype=torch.float32)
+        if t.dim() == 1:
+            if tt.numel() != 1:
+                raise ValueError("a 1-D `t` must hold exactly one value (the reference calls t.item())")
+            return tt.contiguous(), 1
+        if t.dim() != 2 or tt.shape[1] != 1:
+            raise _capi.OardError("t must be 1-D with one element or [B, 1]")
+        if tt.shape[0] <= max_sample_id:
+            raise _capi.OardError("t has fewer rows than samples")
+        return tt.reshape(-1).contiguous(), 0
+
+    def _forward_train(self, cfg, packed: Tensor, xh: List[Tensor], edge_index: Tensor, t: Tensor, conditions: Tensor,
+                       n_frag_switch: Tensor, combined_mask: Tensor, stream: int):
+        """Forward under autograd: training-mode HIP forward (tape) wrapped in `training.DynamicsFunction`."""
+        from . import training
+        L = _capi.lib()
+        dev = xh[0].device
+        n_obj = len(self.node_nfs)
+        # the layout changes every training step: the topology is rebuilt, and the edge_index check is the same
+        check = self._get_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+        topo = training.TrainTopology(cfg, combined_mask, n_frag_switch, stream)
+        xs = []
+        for k in range(n_obj):
+            x = xh[k].detach()
+            if x.dtype != torch.float32 or not x.is_contiguous():
+                x = x.contiguous().float()
+            if x.shape != (check.obj_counts[k], self.node_nfs[k]):
+                raise _capi.OardError(f"xh[{k}] has shape {tuple(x.shape)}")
+            xs.append(x)
+        tt, t_scalar = self._time_argument(t, dev, check.max_sample_id)
+        cond = None
+        if self.condition_nf > 0:
+            cond = conditions.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if cond.shape[0] <= check.max_sample_id or cond.shape[1] != self.condition_nf:
+                raise _capi.OardError("conditions has the wrong shape")
+
+        def run_forward():
+            outs = [torch.empty_like(x) for x in xs]
+            need = L.oard_workspace_bytes(C.byref(cfg), topo.handle)
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            # one tape per call (it lives until that call's backward has run; the caching allocator recycles it)
+            tape = torch.empty(L.oard_tape_bytes(C.byref(cfg), topo.handle), dtype=torch.uint8, device=dev)
+            status = torch.zeros(2, dtype=torch.int32, device=dev)
+            xp = (C.c_void_p * n_obj)(*[x.data_ptr() for x in xs])
+            op = (C.c_void_p * n_obj)(*[o.data_ptr() for o in outs])
+            rc = L.oard_forward_train(C.byref(cfg), topo.handle, packed.data_ptr(), xp, tt.data_ptr(), t_scalar,
+                                      cond.data_ptr() if cond is not None else None, op, self._ws.data_ptr(), self._ws.numel(),
+                                      tape.data_ptr(), tape.numel(), status.data_ptr(), stream)
+            _capi.check(rc, "oard_forward_train")
+            self.last_status = status
+            state = training.TrainState(cfg, topo, training.Tape(cfg, topo, tape), xs, tt, bool(t_scalar), cond)
+            return outs, state
+
+        names = self._param_names()
+        P = self._param_dict()
+        outs = training.DynamicsFunction.apply(self, run_forward, n_obj, *xs, *[P[n] for n in names])
+        if self.nan_check == "sync" and int(self.last_status[0].item()) != 0:       # egnn_dynamics.py:138-143
+            raise FloatingPointError("NaN in the predicted displacement during training (the reference would replace "
+                                     "it with randn and carry on; a training step on that is meaningless)")
+        return list(outs), None
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

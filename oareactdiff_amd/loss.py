@@ -7,9 +7,10 @@ time step, ONE dynamics call (two in evaluation mode: the t = 0 term is computed
 error, discretised-Gaussian likelihood of atom types and charges at t = 0, normalisation constants.
 
 The network call is `oareactdiff_amd.EGNNDynamics` (HIP); everything around it is a handful of element-wise
-and segmented-sum torch ops on [N, 9] tensors that stay on the device.  Values only: the backward pass
-(gradients for training) is not implemented - this is the path `validation_step` takes, and the value a
-training step would log.
+and segmented-sum torch ops on [N, 9] tensors that stay on the device.  With `training=True` the terms are
+differentiable: under autograd the network call runs the training-mode HIP forward and `loss.backward()` reaches
+the parameters through `oareactdiff_amd.training.DynamicsFunction` (hand-written backward of the edge stages).
+Evaluation (`training=False`, what `validation_step` takes) never needs gradients and runs under `torch.no_grad()`.
 """
 from __future__ import annotations
 
@@ -99,11 +100,16 @@ class DiffusionLoss:
         return log_px, log_cat, log_chg
 
     # ---- EnVariationalDiffusion.forward -----------------------------------------------------------------------
-    @torch.no_grad()
     def loss_terms(self, representations: List[Dict[str, Tensor]], conditions: Tensor, training: bool = False,
                    t_int: Optional[Tensor] = None, draw: Optional[Callable] = None) -> Dict:
         """`t_int` ([B,1] float) and `draw(shape) -> N(0,1) tensor` are injectable for tests; by default they are
         drawn on the device like the reference does."""
+        if not training:
+            with torch.no_grad():
+                return self._loss_terms(representations, conditions, False, t_int, draw)
+        return self._loss_terms(representations, conditions, True, t_int, draw)
+
+    def _loss_terms(self, representations, conditions, training, t_int, draw) -> Dict:
         masks = [r["mask"] for r in representations]
         dev = representations[0]["pos"].device
         B = representations[0]["size"].size(0)
@@ -122,7 +128,7 @@ class DiffusionLoss:
         delta_log_px = -((n_nodes.sum() - 1) * self.pos_dim) * math.log(self.norm_values[0])
         if t_int is None:
             t_int = torch.randint(0 if training else 1, self.T + 1, size=(B, 1), device=dev).float()
-        t_int = t_int.to(device=dev, dtype=fdt)
+        t_int = t_int.detach().to(device=dev, dtype=fdt)
         t_is_zero = (t_int == 0).to(fdt)
         s, t = (t_int - 1) / self.T, t_int / self.T
         gamma_s, gamma_t = self._gamma(s), self._gamma(t)
@@ -157,7 +163,6 @@ class DiffusionLoss:
                 "net_eps_xh": net, "eps_xh": eps}
 
     # ---- DDPMModule.compute_loss -------------------------------------------------------------------------------
-    @torch.no_grad()
     def compute_loss(self, representations: List[Dict[str, Tensor]], conditions: Tensor, training: bool = False,
                      t_int: Optional[Tensor] = None, draw: Optional[Callable] = None) -> Tuple[Tensor, Dict[str, float]]:
         lt = self.loss_terms(representations, conditions, training=training, t_int=t_int, draw=draw)

@@ -356,7 +356,7 @@ def leftnet_forward(
 
     # EquiOutput / GatedEquivariantBlock (leftnet.py:566-576), tail :878-891
     o = p + "out_pos.output_network.0"
-    v1 = torch.sqrt(((vec @ sd[o + ".vec1_proj.weight"].t()) ** 2).sum(dim=-2))
+    v1 = torch.norm(vec @ sd[o + ".vec1_proj.weight"].t(), dim=-2)      # :567 (torch.norm: zero subgradient at 0)
     v2 = vec @ sd[o + ".vec2_proj.weight"].t()                             # [N,3,1]
     xg = _linear(_silu(_linear(torch.cat([s, v1], dim=-1), sd, o + ".update_net.0")), sd, o + ".update_net.2")
     gate = xg[:, 1:2]

@@ -16,7 +16,7 @@ def pytest_configure(config):
 # debug options every GPU test starts from: NaN-poisoned workspace, and the launch-shape heuristics OFF so
 # that the small golden cases exercise the throughput kernels (the ones bench.py measures); the tests of the
 # heuristics / latency kernels switch them on explicitly (tests/_cases.py: debug_options(**LIB_AUTO))
-SUITE_OPTIONS = dict(gcl_variant=2, equi_variant=2, node_variant=1, gcl_skip=1, gcl_split=0, parts=0,
+SUITE_OPTIONS = dict(gcl_variant=2, equi_variant=2, node_variant=1, gcl_skip=1, parts=0,
                      auto_small=0, auto_tiny=0, npb=16, poison=1)
 LIB_DEFAULTS = dict(SUITE_OPTIONS, auto_small=4, auto_tiny=8, npb=0, poison=0)
 if os.environ.get("OARD_TEST_SHAPES") == "auto":      # whole suite under the library's default launch shapes

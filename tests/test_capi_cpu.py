@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/oard.h but not exported"
     assert set(_capi.EXPORTS) <= declared
-    assert L.oard_version() >= 1001
+    assert L.oard_version() >= 2000
 
 
 def test_config_support_and_param_count():
@@ -82,7 +82,7 @@ def test_no_cpu_fallback_and_config_errors():
     d.load_state_dict(c.state_dict())
     with torch.no_grad(), pytest.raises(OardError):
         d(c.xh, c.edge_index, c.t, c.conditions, c.n_frag_switch, c.combined_mask)
-    with pytest.raises(NotImplementedError):                    # forward-only in this release
+    with pytest.raises(OardError):                              # the training path has no CPU fallback either
         d(c.xh, c.edge_index, c.t, c.conditions, c.n_frag_switch, c.combined_mask)
     with pytest.raises(NotImplementedError):                    # update_pocket_coords=False (egnn_dynamics.py:125)
         d2 = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["a", "b", "c"], node_nfs=c.node_nfs, edge_nf=0,
