@@ -1,0 +1,125 @@
+"""One training step of the diffusion model around the HIP denoiser (BASELINE config 4).
+
+`DDPMTrainer.training_step` mirrors `DDPMModule.training_step` + `configure_optimizers` + `configure_gradient_clipping`
+(oa_reactdiff/trainer/pl_trainer.py:327-347, :150-160, :391-418) and the data-parallel strategy of
+oa_reactdiff/trainer/train_ts1x.py:197-203 (Lightning `DDPStrategy`):
+
+    nll, info = compute_loss(batch);  loss = nll.mean(0)            pl_trainer.py:328-329
+    loss.backward()                                                  HIP backward (oareactdiff_amd/training.py)
+    gradients averaged over the ranks                                DDP: here ONE all-reduce of one flat bucket
+    adaptive gradient clipping (queue of recent norms)               pl_trainer.py:391-418
+    AdamW(amsgrad=True) step                                         pl_trainer.py:150, train_ts1x.py:66-71
+
+Multi-GPU: one process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on ROCm), every rank holds a
+replica and its own shard of the batch.  All trainable gradients live in ONE contiguous fp32 buffer (`flat_grad`,
+42.6 MB for the production model): `param.grad` are views into it, so the backward pass accumulates in place and the
+step needs exactly one `all_reduce` — sized for xGMI's per-link bound rather than bucketed for overlap (the backward
+of this model takes tens of ms, the all-reduce of 42.6 MB over 7 links well under 1 ms).  The two modules the forward
+never uses (`model.distance_embedding`, `model.last_layer`; Lightning needs `find_unused_parameters=True` for them) are
+left out of the bucket and never get a gradient, as in the reference.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from .loss import DiffusionLoss
+
+UNUSED_PREFIXES = ("model.distance_embedding.", "model.last_layer.")
+DEFAULT_OPTIMIZER = dict(lr=2.5e-4, betas=(0.9, 0.999), weight_decay=0, amsgrad=True)      # train_ts1x.py:66-71
+
+
+class Queue:
+    """oa_reactdiff/utils/training_tools.py:6-23."""
+
+    def __init__(self, max_len: int = 50):
+        self.items: List[float] = []
+        self.max_len = max_len
+
+    def __len__(self):
+        return len(self.items)
+
+    def add(self, item: float) -> None:
+        self.items.insert(0, item)
+        if len(self) > self.max_len:
+            self.items.pop()
+
+    def mean(self) -> float:
+        return float(np.mean(self.items))
+
+    def std(self) -> float:
+        return float(np.std(self.items))
+
+
+class DDPMTrainer:
+    def __init__(self, dynamics: nn.Module, noise_schedule: str = "polynomial_2", timesteps: int = 1000,
+                 precision: float = 1e-5, norm_values: Sequence[float] = (1.0, 1.0, 1.0),
+                 norm_biases: Sequence[float] = (0.0, 0.0, 0.0), loss_type: str = "l2", pos_only: bool = False,
+                 scales: Sequence[float] = (1.0, 1.0, 1.0), fixed_idx: Optional[List[int]] = None,
+                 optimizer_config: Optional[Dict] = None, clip_grad: bool = True,
+                 process_group: Optional["dist.ProcessGroup"] = None):
+        self.dynamics = dynamics
+        self.loss = DiffusionLoss(dynamics, noise_schedule, timesteps, precision, norm_values=norm_values,
+                                  norm_biases=norm_biases, pos_only=pos_only, fixed_idx=fixed_idx, loss_type=loss_type,
+                                  scales=scales)
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # distinct trainable parameters the forward uses, in state-dict order (shared encoders count once)
+        seen, self.params, self.names = set(), [], []
+        for name, p in dynamics.named_parameters():
+            if p.requires_grad and id(p) not in seen and not name.startswith(UNUSED_PREFIXES):
+                seen.add(id(p))
+                self.params.append(p)
+                self.names.append(name)
+        n = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
+        off = 0
+        for p in self.params:                          # p.grad = view into the bucket: backward accumulates in place
+            p.grad = self.flat_grad[off: off + p.numel()].view_as(p)
+            off += p.numel()
+        self.optimizer = torch.optim.AdamW(self.params, **dict(DEFAULT_OPTIMIZER, **(optimizer_config or {})))
+        self.clip_grad = clip_grad
+        if clip_grad:                                  # pl_trainer.py:143-146
+            self.gradnorm_queue = Queue()
+            self.gradnorm_queue.add(3000)
+
+    # pl_trainer.py:208-282
+    def compute_loss(self, batch, training: bool = True, **kw) -> Tuple[Tensor, Dict[str, float]]:
+        representations, conditions = batch
+        return self.loss.compute_loss(representations, conditions, training=training, **kw)
+
+    def all_reduce_gradients(self) -> None:
+        """DDP's gradient averaging as one collective over the flat bucket (sum, then / world)."""
+        if self.world > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat_grad.div_(self.world)
+
+    def clip_gradients(self) -> Tuple[float, float]:
+        """pl_trainer.py:391-418: allow 150 % of the recent mean norm + 3 standard deviations."""
+        max_grad_norm = 1.5 * self.gradnorm_queue.mean() + 3 * self.gradnorm_queue.std()
+        # get_grad_norm (training_tools.py:29-55): 2-norm of the per-parameter 2-norms == 2-norm of the flat bucket
+        grad_norm = float(torch.linalg.vector_norm(self.flat_grad, 2.0))
+        if grad_norm > max_grad_norm:                  # clip_grad_norm_: g *= max_norm / (norm + 1e-6)
+            self.flat_grad.mul_(max_grad_norm / (grad_norm + 1e-6))
+            self.gradnorm_queue.add(float(max_grad_norm))
+            print(f"Clipped gradient with value {grad_norm:.1f} while allowed {max_grad_norm:.1f}")
+        else:
+            self.gradnorm_queue.add(grad_norm)
+        return grad_norm, max_grad_norm
+
+    def training_step(self, batch, **kw) -> Dict[str, float]:
+        """`kw` (t_int=, draw=) injects the step's randomness for tests; by default it is drawn like the reference does."""
+        self.flat_grad.zero_()
+        nll, info = self.compute_loss(batch, training=True, **kw)
+        loss = nll.mean(0)                             # pl_trainer.py:329
+        loss.backward()
+        self.all_reduce_gradients()
+        if self.clip_grad:
+            info["grad_norm"], info["max_grad_norm"] = self.clip_gradients()
+        self.optimizer.step()
+        info["loss"] = float(loss.detach())
+        return info

@@ -1,0 +1,127 @@
+"""The training step's data-parallel half on CPU: two gloo ranks, each with its shard of a batch, end up with the
+gradients (and, after AdamW, the weights) a single process computes on the whole batch.  The denoiser is the CPU
+oracle under torch autograd here (the HIP backward is checked on the GPU in test_grad.py); what is under test is
+`DDPMTrainer`: the flat gradient bucket, its single all-reduce, the adaptive clipping and the optimiser step."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+CFG = dict(pos_require_grad=False, cutoff=10.0, num_layers=1, hidden_channels=32, num_radial=8, in_hidden_channels=8,
+           reflect_equiv=True, legacy=True, update=True, pos_grad=False, single_layer_output=True, object_aware=True)
+SIZES = [3, 4, 2, 5]
+T = 50
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_dynamics():
+    """`oareactdiff_amd.EGNNDynamics` as the parameter container (reference state-dict names) with the CPU oracle as
+    its forward - float64, differentiable by torch autograd."""
+    import leftnet_oracle as oracle
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.spec import state_spec, synthetic_state_dict
+
+    class OracleDynamics(EGNNDynamics):
+        def forward(self, xh, edge_index, t, conditions, n_frag_switch, combined_mask, edge_attr=None):
+            sd = dict(self.named_parameters())
+            sd.update(dict(self.named_buffers()))
+            return oracle.dynamics_forward(sd, CFG, xh, edge_index, t, conditions, n_frag_switch, combined_mask, 1,
+                                           nodeframe="exact"), None
+    d = OracleDynamics(model_config=dict(CFG), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
+                       condition_nf=1, device=torch.device("cpu"))
+    d.load_state_dict(synthetic_state_dict(state_spec(CFG, [9, 9, 9], 1), CFG, seed=42))
+    return d.double()
+
+
+def _batch(sizes, lo, hi):
+    """Reactions [lo, hi) of the full synthetic batch, plus this shard's rows of the full batch's noise draws."""
+    g = torch.Generator().manual_seed(7)
+    B = len(sizes)
+    full_mask = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+    keep = (full_mask >= lo) & (full_mask < hi)
+    reps, draws = [], []
+    for k in range(3):
+        n = full_mask.numel()
+        pos = torch.randn(n, 3, generator=g, dtype=torch.float64)
+        typ = torch.randint(0, 4, (n,), generator=g)
+        one_hot = torch.zeros(n, 5, dtype=torch.long)
+        one_hot[torch.arange(n), typ] = 1
+        charge = torch.tensor([1, 6, 7, 8])[typ].view(n, 1)
+        draws += [torch.randn(n, 3, generator=g, dtype=torch.float64)[keep], torch.randn(n, 6, generator=g, dtype=torch.float64)[keep]]
+        reps.append({"size": torch.tensor(sizes[lo:hi]), "pos": pos[keep], "one_hot": one_hot[keep], "charge": charge[keep],
+                     "mask": full_mask[keep] - lo})
+    t_int = torch.tensor([[7.0], [0.0], [50.0], [23.0]], dtype=torch.float64)[lo:hi]
+    it = iter(draws)
+    return (reps, torch.zeros(hi - lo, 1, dtype=torch.float64)), t_int, (lambda shape: next(it))
+
+
+def _step(rank, world):
+    from oareactdiff_amd.shard import shard_range
+    from oareactdiff_amd.trainer import DDPMTrainer
+    lo, hi = shard_range(len(SIZES), rank, world)
+    tr = DDPMTrainer(_oracle_dynamics(), timesteps=T, norm_values=(1.0, 4.0, 10.0), scales=(1.0, 2.0, 1.0))
+    batch, t_int, draw = _batch(SIZES, lo, hi)
+    info = tr.training_step(batch, t_int=t_int, draw=draw)
+    return tr, info
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr, info = _step(rank, world)
+        q.put((rank, tr.flat_grad.numpy().copy(), torch.cat([p.detach().reshape(-1) for p in tr.params]).numpy().copy(),
+               info["loss"], info["grad_norm"]))        # numpy: torch tensors would travel as shared-memory handles
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_step_equals_single_process():
+    single, info1 = _step(0, 1)
+    assert single.world == 1 and len(single.names) == len(single.params)
+    assert not any(n.startswith(("model.distance_embedding.", "model.last_layer.")) for n in single.names)
+    assert float(single.flat_grad.abs().max()) > 0 and info1["grad_norm"] > 0
+    w1 = torch.cat([p.detach().reshape(-1) for p in single.params])
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=300) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, w0, l0, n0), (_, g1, wr1, l1, n1) = [(r, torch.from_numpy(g), torch.from_numpy(w), l, n) for r, g, w, l, n in out]
+    assert torch.equal(g0, g1) and torch.equal(w0, wr1)            # the all-reduce leaves the replicas identical
+    assert abs(n0 - info1["grad_norm"]) <= 1e-9 * info1["grad_norm"]
+    scale = float(single.flat_grad.abs().max())
+    assert float((g0 - single.flat_grad).abs().max()) <= 1e-10 * scale   # mean of the shard means == mean over the batch
+    assert float((w0 - w1).abs().max()) <= 1e-12
+    assert abs(0.5 * (l0 + l1) - info1["loss"]) <= 1e-10 * abs(info1["loss"])
+
+
+def test_gradient_clipping_follows_the_reference_rule():
+    from oareactdiff_amd.trainer import DDPMTrainer, Queue
+    q = Queue(max_len=3)
+    for v in (1.0, 2.0, 3.0, 4.0):
+        q.add(v)
+    assert q.items == [4.0, 3.0, 2.0] and abs(q.mean() - 3.0) < 1e-12
+    tr = DDPMTrainer(_oracle_dynamics(), timesteps=T)
+    tr.gradnorm_queue = Queue()
+    tr.gradnorm_queue.add(1e-3)                                   # allows 1.5e-3: the step's gradient must be clipped
+    tr.flat_grad.fill_(1.0)
+    norm, allowed = tr.clip_gradients()
+    assert abs(allowed - 1.5e-3) < 1e-12 and norm > allowed
+    assert abs(float(torch.linalg.vector_norm(tr.flat_grad)) - allowed) <= 1e-6 * allowed
+    assert tr.gradnorm_queue.items[0] == allowed                 # the clipped value enters the history (pl_trainer.py:409-412)
