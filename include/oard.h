@@ -165,7 +165,7 @@ int oard_debug_option(const char* name, int value);
 
 /* Average duration (ms) and launch count per kernel family since the last reset, measured with
  * HIP events on the launch stream when timing is enabled (bench.py's roofline leg).
- * names: "gcl_edge", "equi_edge", "node", "init", "other". */
+ * names: "gcl_edge", "equi_edge", "node", "init", "other" (forward), "gcl_edge_bwd", "equi_edge_bwd", "wgrad" (backward). */
 int oard_timing_enable(int on);
 int oard_timing_reset(void);
 int oard_timing_get(const char* family, double* total_ms, int64_t* launches);
@@ -250,6 +250,15 @@ int oard_edge_node_sums(const oard_config* cfg, const oard_topology* topo, const
 int oard_equi_backward_dx(const oard_config* cfg, const oard_topology* topo, const void* packed_bwd_dev, int layer,
                           const void* tape_dev, const float* dcd_dev, float* dew_dev, float* dzd1_dev,
                           oard_stream_t stream);
+/* Adjoint of the edge scalarisation + lin3 (leftnet.py:792-806, k_scalarize): from the gradient of the initial edge state
+ * (dew_dev [E+1][WP], columns [0, 2H) of the inner rows) and NE1 (ne1_dev [N][3][ld], ld >= H, the CFConvS2V output) to
+ *   dne1_dev [N][3][ld]     gradient w.r.t. NE1
+ *   part_dev [N][5*(H/4)+1] per-node partial sums of the lin3 gradients: lin3.0.weight [H/4][3] | lin3.0.bias [H/4] |
+ *                           lin3.2.weight [H/4] | lin3.2.bias [1]  (the caller adds the N rows up)
+ * packed_dev: oard_pack_weights blob (lin3 weights), tape_dev: the forward's tape (edge frames). */
+int oard_scalarize_backward(const oard_config* cfg, const oard_topology* topo, const void* packed_dev, const void* tape_dev,
+                            const float* ne1_dev, int ld, const float* dew_dev, float* dne1_dev, float* part_dev,
+                            oard_stream_t stream);
 /* Weight gradient of a Linear layer from row-major operands (nn.Linear backward, dW = dY^T X, db = sum dY):
  *   dW[o][i] = sum_{r < rows} dY[r][op(o)] * act(X[r][ip(i)]),   db[o] = sum_r dY[r][op(o)]   (db may be NULL)
  * op(o) = (o / o_len) * o_pad + o % o_len undoes section padding (e.g. three 196-wide thirds stored 208 apart);

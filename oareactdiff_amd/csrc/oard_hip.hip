@@ -13,6 +13,7 @@
 #include "oard_node_v1.h"
 #include "oard_edge_small.h"
 #include "oard_edge_bwd.h"
+#include "oard_node_bwd.h"
 
 #define OARD_VERSION 2000
 
@@ -24,8 +25,8 @@
 // per-family kernel timing with HIP events on the launch stream (bench.py's roofline leg)
 // ------------------------------------------------------------------------------------------------
 namespace {
-enum Family { F_GCL_EDGE = 0, F_EQUI_EDGE, F_NODE, F_INIT, F_OTHER, F_COUNT };
-const char* kFamilyNames[F_COUNT] = {"gcl_edge", "equi_edge", "node", "init", "other"};
+enum Family { F_GCL_EDGE = 0, F_EQUI_EDGE, F_NODE, F_INIT, F_OTHER, F_GCL_BWD, F_EQUI_BWD, F_WGRAD, F_COUNT };
+const char* kFamilyNames[F_COUNT] = {"gcl_edge", "equi_edge", "node", "init", "other", "gcl_edge_bwd", "equi_edge_bwd", "wgrad"};
 struct TimingRec { hipEvent_t a, b; int fam; };
 struct Timing {
     bool on = false;
@@ -528,10 +529,10 @@ static int gcl_backward_impl(const oard_config* c, const TopoDev& tp, const floa
     const bool last = layer == c->num_layers - 1;
     const long long r_full = last ? tp.A : tp.E;       // rows whose forward ran S3
     if (r_full > 0)
-        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_bwd<D, 8, 2, true>), cdiv(r_full, 128), 512, (GclBwdStream<D, 2>::LDS_BYTES), st,
+        LAUNCH_LDS(F_GCL_BWD, (k_gcl_edge_bwd<D, 8, 2, true>), cdiv(r_full, 128), 512, (GclBwdStream<D, 2>::LDS_BYTES), st,
                    tp, stream, 0LL, r_full, a);
     if (last && tp.E > tp.A)
-        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_bwd<D, 8, 2, false>), cdiv(tp.E - tp.A, 128), 512, (GclBwdStream<D, 2>::LDS_BYTES), st,
+        LAUNCH_LDS(F_GCL_BWD, (k_gcl_edge_bwd<D, 8, 2, false>), cdiv(tp.E - tp.A, 128), 512, (GclBwdStream<D, 2>::LDS_BYTES), st,
                    tp, stream, tp.A, tp.E, a);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
@@ -540,8 +541,18 @@ static int gcl_backward_impl(const oard_config* c, const TopoDev& tp, const floa
 template <class D>
 static int equi_backward_impl(const TopoDev& tp, const float* stream, const float* dcd, const float* zd1, float* dew,
                               float* dzd1, hipStream_t st) {
-    LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_bwd<D, 8>), cdiv(tp.A, 128), 512, (EquiBwdStream<D>::LDS_BYTES), st, tp, stream, dcd,
+    LAUNCH_LDS(F_EQUI_BWD, (k_equi_edge_bwd<D, 8>), cdiv(tp.A, 128), 512, (EquiBwdStream<D>::LDS_BYTES), st, tp, stream, dcd,
                zd1, dew, dzd1);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+template <class D>
+static int scalarize_backward_impl(const oard_config* c, const TopoDev& tp, const float* wb, const char* tape, const TapeOff& to,
+                                   const float* ne1, int ld, const float* dew, float* dne1, float* part, hipStream_t st) {
+    const PackOff po = make_layout(c);
+    constexpr int NW = D::HT < 4 ? D::HT : 4;      // one wave per SIMD: the kernel keeps ~150 accumulators / constants per lane
+    LAUNCH(F_INIT, (k_scalarize_bwd<D, NW>), tp.N, NW * 64, st, tp, wb + po.lin3, ne1, ld, (const float*)(tape + to.geo), dew, dne1, part);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
@@ -1099,9 +1110,21 @@ int oard_edge_node_sums(const oard_config* c, const oard_topology* topo, const f
     const TopoDev& tp = topo->parts[0].d;
     const RDims d(c->hidden, c->num_radial);
     if (d.HP > 256) return OARD_EINVAL;
-    LAUNCH(F_NODE, k_edge_node_sums, tp.N, 64, (hipStream_t)stream, tp, dz1, d.HP, dP, dQ);
+    LAUNCH(F_GCL_BWD, k_edge_node_sums, tp.N, 64, (hipStream_t)stream, tp, dz1, d.HP, dP, dQ);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
+}
+
+int oard_scalarize_backward(const oard_config* c, const oard_topology* topo, const void* packed, const void* tape,
+                            const float* ne1, int ld, const float* dew, float* dne1, float* part, oard_stream_t stream) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1 || !packed || !tape || !ne1 || !dew || !dne1 || !part || ld < c->hidden)
+        return OARD_EINVAL;
+    const TopoDev& tp = topo->parts[0].d;
+    const TapeOff to = make_tape(c, tp);
+    int rc = OARD_EINVAL;
+    DISPATCH_DIMS(c, rc = scalarize_backward_impl<D>(c, tp, (const float*)packed, (const char*)tape, to, ne1, ld, dew, dne1, part,
+                                                     (hipStream_t)stream));
+    return rc;
 }
 
 size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows) {
@@ -1123,7 +1146,7 @@ int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, 
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)scratch;
     float* bpartial = partial + (size_t)p.n_chunks * p.MOp * p.MIp;
-    ScopedLaunch sl_(F_OTHER, st);
+    ScopedLaunch sl_(F_WGRAD, st);
     if (x_silu)
         hipLaunchKernelGGL(k_wgrad<true>, dim3(p.n_chunks, p.gy, p.gz), dim3(256), 0, st, dY, ldY, ncY, X, ldX, ncX, 0LL,
                            (long long)rows, p.rpc, partial, db ? bpartial : nullptr, p.MOp, p.MIp);

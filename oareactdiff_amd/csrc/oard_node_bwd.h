@@ -1,0 +1,146 @@
+// oard_node_bwd.h — hand-written backward of init / node stages whose torch formulation is memory-bound.
+//
+// k_scalarize_bwd: adjoint of k_scalarize (edge scalarisation + lin3, leftnet.py:792-806):
+//     S_c = <NE1[node], frame_c>,  S_1 = |S_1|,   out = (lin3(S) + S_0) * env,   lin3 = Linear(3, H/4) SiLU Linear(H/4, 1)
+// evaluated for every (inner edge, side, channel).  The per-(edge, channel) MLP is tiny but there are 2 A H ~ 4e7 items
+// at B = 64: an eager formulation materialises [items, H/4] tensors several times (hundreds of ms); here the hidden
+// layer is ONE MFMA per 16 hidden units: A = [W0 | b0] (16 hidden x 4), B = (S_0, S_1, S_2, 1) x 16 channels, so a
+// lane (g, j) holds the pre-activations of hidden units 16q + 4g + r for channel j (C layout) and keeps its own
+// partial sums of the weight gradients in registers.  A workgroup owns one node n and all its inner edges (as
+// target: side 1, as source: side 0), so d NE1[n] is accumulated in registers in a fixed order - no atomics.
+#pragma once
+#include "oard_kernels.h"
+#include "oard_edge_bwd.h"
+
+template <class D>
+struct ScalarizeBwd {
+    static constexpr int H4 = D::H4, HQ = (H4 + 15) / 16;
+    static constexpr int NPART = 5 * H4 + 1;      // per-node partial: dw0 [H4][3] | db0 [H4] | dw2 [H4] | db2
+};
+
+// ne1: [N][3][ld] (ld >= H), gdew: gradient of the initial edge state, rows = inner edges, row stride WP, columns [0, 2H)
+// dne1: [N][3][ld] out;  part: [N][NPART] out (summed over the node's edges and channels; the caller adds the nodes up)
+template <class D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_scalarize_bwd(TopoDev tp, const float* __restrict__ l3, const float* __restrict__ ne1,
+                                                              int ld, const float* __restrict__ geo, const float* __restrict__ gdew,
+                                                              float* __restrict__ dne1, float* __restrict__ part) {
+    using SB = ScalarizeBwd<D>;
+    constexpr int H4 = SB::H4, HQ = SB::HQ, HT = D::HT;
+    __shared__ float red[WAVES][4 * HQ * 4 * 5 + 4];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x;
+    const float* w0 = l3;
+    const float* b0 = l3 + H4 * 3;
+    const float* w2 = b0 + H4;
+    // A operand: [W0 | b0] rows 16q + j, column g
+    float aw[HQ];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) {
+        const int row = 16 * q + j;
+        aw[q] = row < H4 ? (g < 3 ? w0[row * 3 + g] : b0[row]) : 0.f;
+    }
+    // constants of this lane's rows 16q + 4g + r
+    float w2r[HQ][4], w0r[HQ][4][3];
+#pragma unroll
+    for (int q = 0; q < HQ; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * q + 4 * g + r;
+            const bool ok = row < H4;
+            w2r[q][r] = ok ? w2[row] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w0r[q][r][c] = ok ? w0[row * 3 + c] : 0.f;
+        }
+    float aw0[HQ][4][3], ab0[HQ][4], aw2[HQ][4], ab2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < HQ; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ab0[q][r] = 0.f; aw2[q][r] = 0.f; aw0[q][r][0] = 0.f; aw0[q][r][1] = 0.f; aw0[q][r][2] = 0.f; }
+
+    const int q_grp = tp.node_sample[n] * tp.n_obj + tp.node_obj[n];
+    const int g0 = tp.grp_ptr[q_grp], ng = tp.grp_ptr[q_grp + 1] - g0, self = n - g0;
+    const int a_n = tp.act_ptr[n];
+    for (int t = wave; t < HT; t += WAVES) {
+        const int ch = 16 * t + j;
+        const bool chok = ch < D::H;
+        const float n0 = chok ? ne1[((size_t)n * 3 + 0) * ld + ch] : 0.f;
+        const float n1 = chok ? ne1[((size_t)n * 3 + 1) * ld + ch] : 0.f;
+        const float n2 = chok ? ne1[((size_t)n * 3 + 2) * ld + ch] : 0.f;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        for (int kk = 0; kk < ng; ++kk) {
+            if (kk == self) continue;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                // side 1: edge (m -> n), n is the target;  side 0: edge (n -> m), n is the source
+                const size_t a = side == 1 ? (size_t)a_n + kk - (kk > self ? 1 : 0)
+                                           : (size_t)tp.act_ptr[g0 + kk] + self - (self > kk ? 1 : 0);
+                const float* ge = geo + a * GEO_STRIDE;
+                const float env = ge[1];
+                const float ux = ge[2], uy = ge[3], uz = ge[4], cx = ge[5], cy = ge[6], cz = ge[7], vx = ge[8], vy = ge[9], vz = ge[10];
+                const float S0 = n0 * ux + n1 * uy + n2 * uz;
+                const float S1r = n0 * cx + n1 * cy + n2 * cz;
+                const float S2 = n0 * vx + n1 * vy + n2 * vz;
+                const float S1 = fabsf(S1r);
+                const float bval = g == 0 ? S0 : (g == 1 ? S1 : (g == 2 ? S2 : 1.0f));
+                const float dout = chok ? gdew[a * D::WP + side * D::H + ch] * env : 0.f;
+                float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) {
+                    const f4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[q], bval, f4zero(), 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float zz = z[r];
+                        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-zz));
+                        const float h = zz * sg;
+                        aw2[q][r] += dout * h;
+                        const float dz = dout * w2r[q][r] * (sg * (1.0f + zz * (1.0f - sg)));
+                        ab0[q][r] += dz;
+                        aw0[q][r][0] += dz * S0; aw0[q][r][1] += dz * S1; aw0[q][r][2] += dz * S2;
+                        p0 += dz * w0r[q][r][0]; p1 += dz * w0r[q][r][1]; p2 += dz * w0r[q][r][2];
+                    }
+                }
+                p0 = col_reduce(p0); p1 = col_reduce(p1); p2 = col_reduce(p2);
+                const float dS0 = p0 + dout, dS1 = S1r < 0.f ? -p1 : (S1r > 0.f ? p1 : 0.f), dS2 = p2;
+                d0 += dS0 * ux + dS1 * cx + dS2 * vx;
+                d1 += dS0 * uy + dS1 * cy + dS2 * vy;
+                d2 += dS0 * uz + dS1 * cz + dS2 * vz;
+                if (g == 0) ab2 += dout;
+            }
+        }
+        if (g == 0 && chok) {
+            dne1[((size_t)n * 3 + 0) * ld + ch] = d0;
+            dne1[((size_t)n * 3 + 1) * ld + ch] = d1;
+            dne1[((size_t)n * 3 + 2) * ld + ch] = d2;
+        }
+    }
+    // reduce the weight-gradient partials over the 16 channel lanes, then over the waves
+    auto red16 = [](float v) {
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        return v;
+    };
+#pragma unroll
+    for (int q = 0; q < HQ; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s0 = red16(aw0[q][r][0]), s1 = red16(aw0[q][r][1]), s2 = red16(aw0[q][r][2]);
+            const float sb = red16(ab0[q][r]), sw = red16(aw2[q][r]);
+            if (j == 0) {
+                float* dst = &red[wave][((q * 4 + g) * 4 + r) * 5];        // row 16q + 4g + r
+                dst[0] = s0; dst[1] = s1; dst[2] = s2; dst[3] = sb; dst[4] = sw;
+            }
+        }
+    ab2 = red16(ab2);
+    if (lane == 0) red[wave][4 * HQ * 4 * 5] = ab2;
+    __syncthreads();
+    float* out = part + (size_t)n * SB::NPART;
+    for (int i = threadIdx.x; i < SB::NPART; i += WAVES * 64) {
+        float s = 0.f;
+        int slot;
+        if (i < 3 * H4) { const int row = i / 3, c = i % 3; slot = row * 5 + c; }
+        else if (i < 4 * H4) slot = (i - 3 * H4) * 5 + 3;
+        else if (i < 5 * H4) slot = (i - 4 * H4) * 5 + 4;
+        else slot = 4 * HQ * 4 * 5;
+        for (int w = 0; w < WAVES; ++w) s += red[w][slot];
+        out[i] = s;
+    }
+}

@@ -136,9 +136,11 @@ class EGNNDynamics(nn.Module):
             self.decoders.load_state_dict(source["decoders"])
 
         #: "sync": reference behaviour (egnn_dynamics.py:138-143) — one host sync per call, NaN -> randn.
-        #: "async": no host sync; the device-side flag is kept in `self.last_status`.
+        #: "async": no host sync; the device-side flag of the last call is kept in `self.last_status` and OR-ed into
+        #: the sticky flag `self.nan_seen` (reset it with `reset_nan_seen()`; the sampling loops read it once at the end).
         self.nan_check = "sync"
         self.last_status: Optional[Tensor] = None
+        self.nan_seen: Optional[Tensor] = None
         self._packed: Optional[Tensor] = None
         self._packed_key = None
         self._packed_bwd: Optional[Tensor] = None
@@ -315,6 +317,10 @@ class EGNNDynamics(nn.Module):
             _capi.check(rc, "oard_forward")
             self._last_topo = topo
             self.last_status = status
+            if self.nan_check != "sync":
+                if self.nan_seen is None or self.nan_seen.device != dev:
+                    self.nan_seen = torch.zeros(2, dtype=torch.int32, device=dev)
+                self.nan_seen.bitwise_or_(status)         # device-side, no sync
             if self.nan_check == "sync" and int(status[0].item()) != 0:   # egnn_dynamics.py:138-143
                 print("Warning: detected nan in pos, resetting EGNN output to randn.")
                 for k in range(n_obj):
@@ -326,6 +332,10 @@ class EGNNDynamics(nn.Module):
                         v = v - (mean / cnt.clamp(min=1).unsqueeze(1))[idx]
                     outs[k][:, : self.pos_dim] = v
         return outs, None
+
+    def reset_nan_seen(self) -> None:
+        if self.nan_seen is not None:
+            self.nan_seen.zero_()
 
     @staticmethod
     def _time_argument(t: Tensor, dev, max_sample_id: int) -> Tuple[Tensor, int]:

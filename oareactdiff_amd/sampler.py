@@ -23,7 +23,14 @@ from .schedule import Schedule, get_repaint_schedule
 class DiffusionSampler:
     def __init__(self, dynamics: EGNNDynamics, noise_schedule: str = "polynomial_2", timesteps: int = 1000,
                  precision: float = 1e-5, pos_only: bool = False,
-                 norm_values: Sequence[float] = (1.0, 1.0, 1.0), norm_biases: Sequence[float] = (0.0, 0.0, 0.0)):
+                 norm_values: Sequence[float] = (1.0, 1.0, 1.0), norm_biases: Sequence[float] = (0.0, 0.0, 0.0),
+                 on_nan: str = "raise"):
+        """`on_nan`: what to do when any network call of a run predicted a NaN displacement.  The reference replaces that
+        step's velocity by randn, prints a warning and keeps sampling (egnn_dynamics.py:138-143) - one host sync per
+        step.  Here the loop never syncs: every call ORs its NaN flag into a device-side sticky flag which is read ONCE
+        after the loop; "raise" (default) raises FloatingPointError, "warn" warns and returns the (NaN) samples."""
+        assert on_nan in ("raise", "warn")
+        self.on_nan = on_nan
         self.dynamics = dynamics
         self.schedule = Schedule(noise_schedule, timesteps, precision)
         self.T = timesteps
@@ -49,6 +56,16 @@ class DiffusionSampler:
                 self._layout_cache.pop(next(iter(self._layout_cache)))
             self._layout_cache[key] = hit
         return hit
+
+    def _check_nan(self, dyn) -> None:
+        """The single host read of a sampling run: did any of its network calls produce a NaN displacement?"""
+        if dyn.nan_seen is not None and int(dyn.nan_seen[0].item()) != 0:
+            msg = ("a network call of this sampling run predicted NaN positions; the reference would have replaced that "
+                   "step by randn (egnn_dynamics.py:138-143), this loop does not: the affected samples are NaN")
+            if self.on_nan == "raise":
+                raise FloatingPointError(msg)
+            import warnings
+            warnings.warn(msg)
 
     # --------------------------------------------------------------------------------------------
     def _step_kernel(self, topo, mode, z, eh, noise, h0, a, b, c, out, stream):
@@ -82,6 +99,7 @@ class DiffusionSampler:
         sizes = [int(m.numel()) for m in masks]
         old_nan = dyn.nan_check
         dyn.nan_check = "async"
+        dyn.reset_nan_seen()
         try:
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
@@ -116,6 +134,7 @@ class DiffusionSampler:
                 self.last_status = dyn.last_status
         finally:
             dyn.nan_check = old_nan
+        self._check_nan(dyn)
         nv, nb, pd = self.norm_values, self.norm_biases, self.pos_dim
         pos = [x[k][:, :pd] * nv[0] + nb[0] for k in range(n_obj)]                              # :680-683
         if self.pos_only:
@@ -158,6 +177,7 @@ class DiffusionSampler:
         sizes = [int(m.numel()) for m in masks]
         old_nan = dyn.nan_check
         dyn.nan_check = "async"
+        dyn.reset_nan_seen()
         try:
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
@@ -205,6 +225,7 @@ class DiffusionSampler:
                 self.last_status = dyn.last_status
         finally:
             dyn.nan_check = old_nan
+        self._check_nan(dyn)
         nv, nb = self.norm_values, self.norm_biases
         pos = [x[k][:, :pd] * nv[0] + nb[0] for k in range(n_obj)]
         if self.pos_only:

@@ -73,9 +73,9 @@ def _lin3_rows(S: Tensor, w0: Tensor, b0: Tensor, w2: Tensor, b2: Tensor) -> Ten
     return (F.silu(x @ w0.t() + b0) @ w2.t() + b2).squeeze(-1) + S[:, 0]
 
 
-def stage_init(P: Dict[str, Tensor], hin: Tensor, g: Geometry, H: int, chunk: int = 8192) -> Tuple[Tensor, Tensor, Tensor]:
-    """k_node_embed, k_radial_lin, k_neighbor_v1, k_s2v_agg_v1, k_scalarize, k_c0row (leftnet.py:744, 781-809).
-    Returns (s0 [N,H], initial inner edge state [A,3H+R], constant row of the inter-object edges [3H+R])."""
+def stage_init_head(P: Dict[str, Tensor], hin: Tensor, g: Geometry, H: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """k_node_embed, k_radial_lin, k_neighbor_v1, k_s2v_agg_v1, k_c0row (leftnet.py:744, 781-791).
+    Returns (s0 [N,H], NE1 [N,3,H], f [A,H] = radial_lin(rbf) * envelope, constant row of the inter-object edges [3H+R])."""
     m = "model."
     N = hin.shape[0]
     z_emb = F.linear(hin, P[m + "embedding.weight"], P[m + "embedding.bias"])                              # :744
@@ -84,14 +84,22 @@ def stage_init(P: Dict[str, Tensor], hin: Tensor, g: Geometry, H: int, chunk: in
                               P[m + "radial_lin.2.bias"])
     f = F.linear(F.silu(F.linear(g.rbf, rl0w, rl0b)), rl2w, rl2b) * g.env[:, None]                          # :784-786
     c0f = F.linear(F.silu(rl0b), rl2w, rl2b)           # radial_lin(0) * envelope(0): the f section of a masked edge
-    l0w, l0b, l2w, l2b = P[m + "lin3.0.weight"], P[m + "lin3.0.bias"], P[m + "lin3.2.weight"], P[m + "lin3.2.bias"]
-    c0s = (F.silu(l0b) @ l2w.t() + l2b).reshape(())    # lin3(0) + 0
+    c0s = (F.silu(P[m + "lin3.0.bias"]) @ P[m + "lin3.2.weight"].t() + P[m + "lin3.2.bias"]).reshape(())    # lin3(0) + 0
     c0 = torch.cat([c0s.expand(2 * H), c0f, torch.zeros(g.rbf.shape[1], dtype=f.dtype, device=f.device)])
     # NeighborEmb (:81-89): sum over ALL incoming edges; inter-object ones carry the constant f
     inter = _seg_sum(nbe, g.node_sample, g.n_samples)[g.node_sample] - _seg_sum(nbe, g.node_group, g.n_groups)[g.node_group]
     s0 = z_emb + _seg_sum(f * nbe[g.src], g.tgt, N) + c0f * inter
     s1 = F.silu(_ln(F.linear(s0, P[m + "s2v.lin1.0.weight"], P[m + "s2v.lin1.0.bias"])))                   # :116
     NE1 = _seg_sum((f * s1[g.src])[:, None, :] * g.u[:, :, None], g.tgt, N)                                 # [N,3,H] :117-125
+    return s0, NE1, f, c0
+
+
+def stage_scalarize(P: Dict[str, Tensor], NE1: Tensor, g: Geometry, H: int, chunk: int = 8192) -> Tensor:
+    """k_scalarize (leftnet.py:792-806): [A, 2H] = (lin3(frame^T NE1[node]) + S_0) * envelope for node = source | target.
+    torch restatement, used by the tests as the reference of the HIP backward `oard_scalarize_backward` (the product's
+    backward never materialises the [rows, H, H/4] hidden layer this formulation needs)."""
+    m = "model."
+    l0w, l0b, l2w, l2b = P[m + "lin3.0.weight"], P[m + "lin3.0.bias"], P[m + "lin3.2.weight"], P[m + "lin3.2.bias"]
     parts = []
     A = g.src.numel()
     for a0 in range(0, A, chunk):                      # checkpointed chunks bound the [rows,H,H/4] intermediate
@@ -107,9 +115,13 @@ def stage_init(P: Dict[str, Tensor], hin: Tensor, g: Geometry, H: int, chunk: in
             return torch.cat(out, dim=1)
         parts.append(checkpoint(piece, NE1, l0w, l0b, l2w, l2b, use_reentrant=False) if A > chunk
                      else piece(NE1, l0w, l0b, l2w, l2b))
-    sc = torch.cat(parts, dim=0) if parts else torch.zeros(0, 2 * H, dtype=f.dtype, device=f.device)
-    ew0 = torch.cat([sc, f, g.rbf], dim=1)                                                                  # :806-809
-    return s0, ew0, c0
+    return torch.cat(parts, dim=0) if parts else torch.zeros(0, 2 * H, dtype=NE1.dtype, device=NE1.device)
+
+
+def stage_init(P: Dict[str, Tensor], hin: Tensor, g: Geometry, H: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """All init stages: (s0 [N,H], initial inner edge state [A,3H+R] (:806-809), constant inter-object row [3H+R])."""
+    s0, NE1, f, c0 = stage_init_head(P, hin, g, H)
+    return s0, torch.cat([stage_scalarize(P, NE1, g, H), f, g.rbf], dim=1), c0
 
 
 def stage_node_pre(P: Dict[str, Tensor], l: int, s_in: Tensor, g: Geometry, H: int) -> Tuple[Tensor, Tensor, Tensor]:
@@ -246,6 +258,22 @@ def _wgrad(dY: Tensor, ncY: int, o_len: int, o_pad: int, MO: int, X: Tensor, ncX
                              1 if x_silu else 0, i_len, i_pad, MI, rows, dW.data_ptr(),
                              db.data_ptr() if db is not None else None, sc.data_ptr(), sc.numel(), stream), "oard_wgrad")
     return dW, db
+
+
+def scalarize_backward(dyn, cfg, topo: TrainTopology, tape: Tape, NE1: Tensor, dew: Tensor, H: int, stream: int):
+    """oard_scalarize_backward: adjoint of k_scalarize.  NE1 [N,3,H] contiguous, dew [E+1,WP] (gradient of the initial
+    edge state, columns [0, 2H) of the inner rows are read) -> (d NE1 [N,3,H], {lin3 parameter name: gradient})."""
+    L = _capi.lib()
+    H4 = H // 4
+    dNE1 = torch.empty_like(NE1)
+    part = torch.empty(topo.N, 5 * H4 + 1, dtype=torch.float32, device=NE1.device)
+    packed = dyn._get_packed(cfg, stream)
+    _capi.check(L.oard_scalarize_backward(C.byref(cfg), topo.handle, packed.data_ptr(), tape.buf.data_ptr(), NE1.data_ptr(), H,
+                                          dew.data_ptr(), dNE1.data_ptr(), part.data_ptr(), stream), "oard_scalarize_backward")
+    tot = part.sum(dim=0)
+    m = "model."
+    return dNE1, {m + "lin3.0.weight": tot[: 3 * H4].view(H4, 3), m + "lin3.0.bias": tot[3 * H4: 4 * H4],
+                  m + "lin3.2.weight": tot[4 * H4: 5 * H4].view(1, H4), m + "lin3.2.bias": tot[5 * H4:]}
 
 
 def _local(fn: Callable, inputs: Sequence[Tensor], params: Dict[str, Tensor]):
@@ -402,11 +430,18 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
         return torch.cat([h, hin_tape[:, emb:n_in]], dim=1)      # time / condition columns are constants
 
     def init():
-        return stage_init(P, head(), g, H)
+        return stage_init_head(P, head(), g, H)
     init_params = params_of("model.embedding.", "model.neighbor_emb.", "model.s2v.", "model.radial_lin.", "model.lin3.", *enc)
-    _, bw_init = _local(init, [], init_params)
+    (_, NE1, _, _), bw_init = _local(init, [], init_params)
+    dNE1 = df = None
+    if A > 0:
+        # edge scalarisation + lin3 (k_scalarize): HIP adjoint -> d NE1 and the lin3 gradients
+        dNE1, gl3 = scalarize_backward(dyn, cfg, topo, tape, NE1.contiguous(), dew, H, stream)
+        for n_, g_ in gl3.items():
+            grads[n_] = grads[n_] + g_ if n_ in grads else g_
+        df = dew[:A, 2 * H:3 * H]
     dc0 = dew[A:E, :W].sum(dim=0) if E > A else None
-    bw_init([ds, dew[:A, :W] if A > 0 else None, dc0], grads)
+    bw_init([ds, dNE1, df, dc0], grads)
     return grads
 
 

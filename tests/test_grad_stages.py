@@ -1,0 +1,20 @@
+"""Teacher-forced stage tests of the training path: every torch stage function against the taped output of
+the HIP kernel it restates, and every HIP backward kernel of the edge stages against torch autograd on the same taped inputs
+with random cotangents (tests/_stage_checks.py).  Tolerance 1e-5 of the largest entry, as for the forward stages."""
+import pytest
+
+from _grad_cases import GRAD_CASES
+
+TOL = 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_training_stages_teacher_forced(name):
+    from _stage_checks import run
+    lines = []
+    out, errs, flat, gap = run(name, log=lines.append)
+    print("\n" + "\n".join(lines))
+    assert any(k.startswith("bwd layer") for k in out) and any(k.startswith("fwd layer") for k in out)
+    bad = {k: v for k, v in out.items() if max(v) > TOL}
+    assert not bad, bad

@@ -7,7 +7,8 @@
 tag=${1:-r1}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export OARD_PARTS=1
-B="python bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+B="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --quick"
+python -c "import bench; print(bench.source_stamp())" > gpurun_out/${tag}_source_stamp.txt
 P=1    # sub-batches in this profiling configuration
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_trace -o t -- $B > gpurun_out/${tag}_trace.log 2>&1
 python tools/prof_summary.py gpurun_out/${tag}_trace/t_results.db > gpurun_out/${tag}_kernel_trace_summary.txt
