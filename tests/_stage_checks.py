@@ -82,7 +82,11 @@ def run(name, log=print):
         dews = torch.zeros(E + 1, WP, device=dev)
         dews[:A, :2 * H] = Gs
         dNE1, gl3 = training.scalarize_backward(dyn, cfg, topo, tape, NE1.contiguous(), dews, H, stream)
-        note("bwd scalarize: dNE1, lin3 w0 b0 w2 b2", rel(dNE1, gs[0]), *[rel(gl3[n].reshape(gs[1 + i].shape), gs[1 + i]) for i, n in enumerate(l3n)])
+        # A three-atom object is coplanar with its centre of mass, so S_1 = <NE1, cross> is rounding noise there and the
+        # sign that d|S_1| carries is arbitrary (in the reference too): those nodes are left out of the comparison.
+        gsz = torch.bincount(topo.node_group, minlength=topo.B * 3)[topo.node_group]
+        ok = gsz != 3
+        note("bwd scalarize: dNE1, lin3 w0 b0 w2 b2", rel(dNE1[ok], gs[0][ok]), *[rel(gl3[n].reshape(gs[1 + i].shape), gs[1 + i]) for i, n in enumerate(l3n)])
     # ---- 2. edge backward kernels, teacher-forced ----------------------------------------------------------------------
     rs = tape_rows(topo, L, dev, stream)
     pbwd = dyn._get_packed_bwd(cfg, stream)
