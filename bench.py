@@ -203,6 +203,36 @@ def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
     return out, dt
 
 
+def dry_run(args, rank, world, dist, backend):
+    """The multi-process skeleton of the timed region without a GPU (OARD_BENCH_DRY=1, tests/test_bench_multirank.py):
+    per-rank stand-in steps, barrier on both sides, MAX of the wall clock over the ranks, ONE JSON line on rank 0."""
+    from oareactdiff_amd.shard import max_over_ranks
+    B = args.batch
+
+    def step(i):
+        time.sleep(0.002 * (rank + 1))                        # ranks differ on purpose: the MAX must pick the slowest
+    for i in range(args.warmup):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dist)
+    if rank == 0:
+        print(json.dumps({"metric": "denoising_steps_per_sec", "value": world * B * args.steps / dt, "unit": "reaction-steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "dry run (no GPU work)", "batch_per_gpu": B,
+                                     "parallelism": f"replica x{world} (no collective)"}, "dry_run": True,
+                          "backend": backend}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,14 +255,18 @@ def main():
     backend = os.environ.get("OARD_BENCH_BACKEND", "nccl")    # "gloo" only to exercise the N>1 code path on a 1-GPU box
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    dry = bool(os.environ.get("OARD_BENCH_DRY"))              # no GPU work: only the launcher / rank / reduction plumbing (CPU test)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        if not dry:
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    if dry:
+        return dry_run(args, rank, world, dist, backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

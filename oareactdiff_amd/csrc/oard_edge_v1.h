@@ -137,8 +137,8 @@ struct GclTape {
 // TRAIN: the new state goes to `ew_out` (a different buffer: the backward pass needs every layer's input state)
 //   and the pre-activations are stored (GclTape).  In inference ew_out == ew_in (in-place update).
 // Columns are the physical rows [r0, r1).
-template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
+template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                                const float* __restrict__ P, const float* __restrict__ Q,
                                                                const float* __restrict__ u0, const float* __restrict__ c0,
                                                                long long r0, long long r1, const float* ew_in, float* ew_out,

@@ -267,6 +267,16 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
     switch (variant) {
         GCL_CASE(2, 8, 2)      // 8 waves x 16 edges, two waves per SIMD
         GCL_CASE(3, 4, 2)      // 4 waves x 16 edges (two workgroups per CU): small launches
+#ifdef OARD_EXPERIMENTS        // A/B shapes, only in experiment builds (tools/ab_gcl.sh)
+        GCL_CASE(8, 8, 3)
+        GCL_CASE(9, 8, 4)
+        case 10: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 12, 1, S1, S3, false, 3>), cdiv(r1 - r0, 16 * 12), 12 * 64,
+                              (GclStream<D, 1>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
+        case 11: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 12, 2, S1, S3, false, 3>), cdiv(r1 - r0, 16 * 12), 12 * 64,
+                              (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
+        case 12: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 4, 1, S1, S3, false, 3>), cdiv(r1 - r0, 16 * 4), 4 * 64,
+                              (GclStream<D, 1>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
+#endif
         default: return OARD_EINVAL;
     }
 }

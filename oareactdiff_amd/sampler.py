@@ -148,6 +148,41 @@ class DiffusionSampler:
         return out_samples, masks
 
     @torch.no_grad()
+    def sample_sharded(self, fragments_nodes: List[Tensor], conditions: Optional[Tensor] = None, seed: int = 0,
+                       gather: bool = False, h0: Optional[List[Tensor]] = None, **kw):
+        """BASELINE configs[2]: a GLOBAL batch (per-object atom counts of all B reactions) sharded over the ranks of the
+        default process group, one process per GPU.  Reactions are independent (utils/_graph_tools.py:30), so every rank
+        samples its contiguous slice `shard_range(B, rank, world)` with its own RNG stream (`seed + rank`) and NO
+        data-path collective.  `gather=True` adds one host-side gather of the final samples on rank 0 (the only
+        communication of the whole run).  Returns (samples, masks, (lo, hi)); with `gather` rank 0 gets the samples of the
+        whole batch per object (in batch order), the other ranks their own."""
+        import torch.distributed as dist
+        from .shard import shard_range
+        on = dist.is_available() and dist.is_initialized()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+        B = int(fragments_nodes[0].numel())
+        lo, hi = shard_range(B, rank, world)
+        local = [f[lo:hi] for f in fragments_nodes]
+        cond = conditions[lo:hi] if conditions is not None else None
+        h0l = None
+        if h0 is not None:
+            h0l = []
+            for f, h in zip(fragments_nodes, h0):
+                off = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.long), f.cpu().long()]), 0)
+                h0l.append(h[int(off[lo]): int(off[hi])])
+        torch.manual_seed(seed + rank)                     # seeds the device generators too
+        out, masks = self.sample(hi - lo, local, conditions=cond, h0=h0l, **kw)
+        if gather and world > 1:
+            mine = (lo, [o.cpu() for o in out[0]])
+            got = [None] * world if rank == 0 else None
+            dist.gather_object(mine, got, dst=0)
+            if rank == 0:
+                got.sort(key=lambda t: t[0])
+                out = list(out)
+                out[0] = [torch.cat([g[1][k] for g in got], dim=0) for k in range(len(self.node_nfs))]
+        return out, masks, (lo, hi)
+
+    @torch.no_grad()
     def inpaint(self, n_samples: int, fragments_nodes: List[Tensor], conditions: Optional[Tensor] = None,
                 return_frames: int = 1, resamplings: int = 1, jump_length: int = 1, timesteps: Optional[int] = None,
                 xh_fixed: Optional[List[Tensor]] = None, frag_fixed: Optional[List[int]] = None,

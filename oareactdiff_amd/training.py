@@ -297,8 +297,34 @@ def _local(fn: Callable, inputs: Sequence[Tensor], params: Dict[str, Tensor]):
     return [o.detach() for o in outs_t], backward
 
 
+class _StageTimer:
+    """OARD_TRAIN_PROFILE=1: device time per stage of the sweep (HIP events on the current stream), printed per call."""
+
+    def __init__(self):
+        import os
+        self.on = bool(os.environ.get("OARD_TRAIN_PROFILE"))
+        self.marks = []
+
+    def mark(self, name: str):
+        if self.on:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.marks.append((name, e))
+
+    def report(self):
+        if not self.on or len(self.marks) < 2:
+            return
+        torch.cuda.synchronize()
+        tot: Dict[str, float] = {}
+        for (n0, e0), (n1, e1) in zip(self.marks[:-1], self.marks[1:]):
+            tot[n1] = tot.get(n1, 0.0) + e0.elapsed_time(e1)
+        print("backward sweep ms: " + "  ".join(f"{k} {v:.2f}" for k, v in tot.items()) + f"  | total {sum(tot.values()):.2f}")
+
+
 def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], stream: int) -> Dict[str, Tensor]:
     """d(loss)/d(parameter) for every parameter the forward uses, given d(loss)/d(out[k])."""
+    tm = _StageTimer()
+    tm.mark("start")
     L = _capi.lib()
     cfg, topo, tape = st.cfg, st.topo, st.tape
     H, R, NL, Cc = dyn._dims
@@ -343,6 +369,7 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
     tail_params = params_of("model.out_pos.", "model.embedding_out.", *dec)
     _, bw = _local(tail, [s_L, vec_L], tail_params)
     ds, dvec = bw([None if go is None else go.to(torch.float32) for go in grad_outs], grads)
+    tm.mark("tail")
     ds = torch.zeros(N, H, device=dev) if ds is None else ds
     dvec = torch.zeros(N, 3, H, device=dev) if dvec is None else dvec
 
@@ -366,7 +393,9 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
         _, bw_mid = _local(lambda a, b, c, d: stage_node_mid(P, l, a, b, c, d, g, H), [xh, agg, cd, vec_in],
                            params_of(q + "node_mlp.", e + "x_layernorm.", e + "x_proj.", e + "rbf_proj.",
                                      f"model.update_layers.{l}."))
+        tm.mark("node_fwd_recompute")
         dxh, dagg, dcd, dvec = bw_mid([ds, dvec], grads)
+        tm.mark("node_mid_bwd")
         # ---- EquiMessage edge part (HIP): dcd -> dew[0:A], dir_proj gradients -------------------------------------------
         if A > 0:
             dcd_p = torch.zeros(A + 1, 3, HP, device=dev)
@@ -381,6 +410,7 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
             gw, gb = _wgrad(dzd1, D1P, 3 * H, 3 * H, 3 * H, tape.get(_capi.TAPE_EW, l + 1), WP, False, W, W, W, A, True,
                             dyn, stream)
             grads[e + "dir_proj.0.weight"], grads[e + "dir_proj.0.bias"] = gw, gb
+        tm.mark("equi_edge_bwd+wgrad")
         # ---- GCLMessage edge part (HIP): dew (new state) + dagg -> dew (old state), dP, dQ, edge MLP gradients ------------
         dP = dQ = None
         if E > 0:
@@ -412,7 +442,9 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
             m0 = F.silu(tape.get(_capi.TAPE_Z2, l)[:E, :H])
             grads[q + "att_mlp.mlp.0.linear.weight"] = (da[:E, None] * m0).sum(dim=0, keepdim=True)
             grads[q + "att_mlp.mlp.0.linear.bias"] = da[:E].sum().reshape(1)
+        tm.mark("gcl_edge_bwd+wgrad")
         (ds,) = bw_pre([dxh, dP, dQ], grads)
+        tm.mark("node_pre_bwd")
         ds = torch.zeros(N, H, device=dev) if ds is None else ds
 
     # ---- init stages + wrapper prologue (k_prep, k_node_embed, ..., k_scalarize; egnn_dynamics.py:91-119) ------------
@@ -442,6 +474,8 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
         df = dew[:A, 2 * H:3 * H]
     dc0 = dew[A:E, :W].sum(dim=0) if E > A else None
     bw_init([ds, dNE1, df, dc0], grads)
+    tm.mark("init_bwd")
+    tm.report()
     return grads
 
 

@@ -82,11 +82,19 @@ def run(name, log=print):
         dews = torch.zeros(E + 1, WP, device=dev)
         dews[:A, :2 * H] = Gs
         dNE1, gl3 = training.scalarize_backward(dyn, cfg, topo, tape, NE1.contiguous(), dews, H, stream)
-        # A three-atom object is coplanar with its centre of mass, so S_1 = <NE1, cross> is rounding noise there and the
-        # sign that d|S_1| carries is arbitrary (in the reference too): those nodes are left out of the comparison.
-        gsz = torch.bincount(topo.node_group, minlength=topo.B * 3)[topo.node_group]
-        ok = gsz != 3
-        note("bwd scalarize: dNE1, lin3 w0 b0 w2 b2", rel(dNE1[ok], gs[0][ok]), *[rel(gl3[n].reshape(gs[1 + i].shape), gs[1 + i]) for i, n in enumerate(l3n)])
+        # d|S_1| carries sign(S_1).  Where S_1 = <NE1, coord_cross> is zero in exact arithmetic (three-atom objects are
+        # coplanar with their centre of mass; (anti)parallel pairs when the cutoff bites) its computed value is rounding
+        # noise and the sign is arbitrary - in the reference too.  Nodes touching such an item are left out.
+        with torch.no_grad():
+            cvec = g.frame[:, :, 1]
+            s1_src, s1_tgt = torch.einsum("axh,ax->ah", NE1[g.src], cvec), torch.einsum("axh,ax->ah", NE1[g.tgt], cvec)
+            thr = 1e-5 * max(float(s1_src.abs().max()), float(s1_tgt.abs().max()))
+            noisy = torch.zeros(N, device=dev)
+            noisy.index_add_(0, g.src, (s1_src.abs() <= thr).any(dim=1).float())
+            noisy.index_add_(0, g.tgt, (s1_tgt.abs() <= thr).any(dim=1).float())
+        ok = noisy == 0
+        log(f"scalarize check: {int(ok.sum())} of {N} nodes have no sign-noisy item")
+        note("bwd scalarize: dNE1, lin3 w0 b0 w2 b2", (rel(dNE1[ok], gs[0][ok]) if bool(ok.any()) else 0.0), *[rel(gl3[n].reshape(gs[1 + i].shape), gs[1 + i]) for i, n in enumerate(l3n)])
     # ---- 2. edge backward kernels, teacher-forced ----------------------------------------------------------------------
     rs = tape_rows(topo, L, dev, stream)
     pbwd = dyn._get_packed_bwd(cfg, stream)

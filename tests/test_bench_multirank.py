@@ -1,0 +1,43 @@
+"""bench.py under the driver's multi-GPU launch line, on CPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+--master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` with the gloo backend and OARD_BENCH_DRY=1 (stand-in steps, no
+GPU work).  Proves the rank / environment handling, the barriers, the MAX-over-ranks wall clock, that exactly one JSON
+line comes out (rank 0) and that every rank exits cleanly.  On the 8-GPU node the same code runs with backend nccl = RCCL."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_gloo_dry_run():
+    env = dict(os.environ, OARD_BENCH_BACKEND="gloo", OARD_BENCH_DRY="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dry_run"]
+    # MAX over ranks: rank 1 sleeps 4 ms per step, rank 0 only 2 ms
+    assert d["ms_per_step"] >= 3.9
+    assert abs(d["value"] - 2 * 64 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-6     # whole-job aggregate
+
+
+def test_bench_single_process_dry_run():
+    env = dict(os.environ, OARD_BENCH_DRY="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2

@@ -50,6 +50,50 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_sampler(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oareactdiff_amd.sampler import DiffusionSampler
+
+        class Stub(DiffusionSampler):                        # the sharding logic only: sample() itself needs a GPU
+            def __init__(self):
+                self.node_nfs = [9, 9, 9]
+
+            def sample(self, n, frags, conditions=None, h0=None, **kw):
+                seed = torch.initial_seed()
+                outs = [torch.full((int(f.sum()), 9), float(seed)) for f in frags]
+                assert conditions.shape[0] == n and all(h.shape[0] == int(f.sum()) for h, f in zip(h0, frags))
+                return [outs], [torch.repeat_interleave(torch.arange(n), f) for f in frags]
+        sizes = torch.tensor([3, 4, 2, 5, 6])
+        frags = [sizes, sizes + 1, sizes]
+        h0 = [torch.arange(int(f.sum())).float().view(-1, 1).repeat(1, 6) for f in frags]
+        out, masks, (lo, hi) = Stub().sample_sharded(frags, conditions=torch.zeros(5, 1), seed=100, gather=True, h0=h0)
+        q.put((rank, lo, hi, [tuple(o.shape) for o in out[0]], [float(o[0, 0]) for o in out[0]], [float(o[-1, 0]) for o in out[0]]))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_sample_sharded_splits_the_global_batch_and_gathers_on_rank0():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sampler, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, sh0, first0, last0), (r1, lo1, hi1, sh1, first1, last1) = out
+    assert (lo0, hi0, lo1, hi1) == (0, 3, 3, 5)
+    assert sh0 == [(20, 9), (25, 9), (20, 9)]                 # rank 0 holds the gathered batch (all 5 reactions)
+    assert sh1 == [(11, 9), (13, 9), (11, 9)]                 # rank 1 keeps its own slice
+    assert first0 == [100.0] * 3 and last0 == [101.0] * 3     # seed + rank, slices in batch order
+
+
 def test_two_rank_replicas_gloo():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")

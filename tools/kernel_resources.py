@@ -8,7 +8,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oareactdiff_amd", "csrc")
 pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else r"k_(gcl_edge|equi_edge|wgrad)")
 r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Wno-unused-result",
-                    "-Rpass-analysis=kernel-resource-usage", "oard_hip.hip", "-o", "/tmp/oard_res.o"], cwd=CSRC,
+                    "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:] + ["oard_hip.hip", "-o", "/tmp/oard_res.o"], cwd=CSRC,
                    capture_output=True, text=True)
 for b in r.stderr.split("Function Name: ")[1:]:
     name = b.split("\n")[0].split()[0].strip()
