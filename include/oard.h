@@ -214,6 +214,8 @@ int oard_topology_export(const oard_topology* topo, int which, int32_t* dst_dev,
 #define OARD_TAPE_Z3 24      /* [E+1][WP]    edge_out_trans pre-activation                                    */
 #define OARD_TAPE_ZD1 25     /* [A+1][D1P]   dir_proj.0 pre-activation                                        */
 #define OARD_TAPE_CD 26      /* [A+1][3][HP] dir_proj output (before the product with rbf_proj)               */
+#define OARD_TAPE_S_A 27     /* [N][HP]      s after the EquiMessage aggregation, (s + dx)/sqrt2 (EquiUpdate input) */
+#define OARD_TAPE_VEC_A 28   /* [N][3][HP]   vec after the EquiMessage aggregation (EquiUpdate input)          */
 size_t oard_tape_bytes(const oard_config* cfg, const oard_topology* topo);
 int oard_tape_entry(const oard_config* cfg, const oard_topology* topo, int which, int layer,
                     size_t* offset_bytes, int64_t* rows, int64_t* row_floats);
@@ -250,6 +252,14 @@ int oard_edge_node_sums(const oard_config* cfg, const oard_topology* topo, const
 int oard_equi_backward_dx(const oard_config* cfg, const oard_topology* topo, const void* packed_bwd_dev, int layer,
                           const void* tape_dev, const float* dcd_dev, float* dew_dev, float* dzd1_dev,
                           oard_stream_t stream);
+/* Adjoint of EquiMessage's message formation + aggregation (leftnet.py:264-283, the gather half of k_equi_node_v1):
+ *   in : xq_dev [N][3][H] x_proj output, cr_dev [A][3][H] rbf_proj(rbf), gx_dev [N][H] / gv_dev [N][3][H] gradients w.r.t. the
+ *        aggregated scalar / vector messages (dense, unpadded);  vec_in, dir_proj's output and the edge frames come from the tape
+ *   out: dcd_dev / dcr_dev [A+1][3][HP] gradients w.r.t. dir_proj's output / rbf_proj's output (pads untouched: pass zeroed
+ *        buffers), dxq_dev [N][3][H], dvec_dev [N][3][H] (gradient w.r.t. vec entering the layer, identity path included). */
+int oard_equi_msg_backward(const oard_config* cfg, const oard_topology* topo, const void* tape_dev, int layer,
+                           const float* xq_dev, const float* cr_dev, const float* gx_dev, const float* gv_dev,
+                           float* dcd_dev, float* dcr_dev, float* dxq_dev, float* dvec_dev, oard_stream_t stream);
 /* Adjoint of the edge scalarisation + lin3 (leftnet.py:792-806, k_scalarize): from the gradient of the initial edge state
  * (dew_dev [E+1][WP], columns [0, 2H) of the inner rows) and NE1 (ne1_dev [N][3][ld], ld >= H, the CFConvS2V output) to
  *   dne1_dev [N][3][ld]     gradient w.r.t. NE1

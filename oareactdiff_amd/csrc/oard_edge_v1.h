@@ -137,8 +137,10 @@ struct GclTape {
 // TRAIN: the new state goes to `ew_out` (a different buffer: the backward pass needs every layer's input state)
 //   and the pre-activations are stored (GclTape).  In inference ew_out == ew_in (in-place update).
 // Columns are the physical rows [r0, r1).
-template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2>
-__global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
+// LOADER: a (WAVES+1)-th wave does nothing but issue the LDS-DMA of the next phase's slab (the compute waves then carry no
+//   DMA issue cost); it needs a third wave slot on one SIMD, i.e. the kernel held to 168 registers (MINW = 3).
+template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2, bool LOADER = false>
+__global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                                const float* __restrict__ P, const float* __restrict__ Q,
                                                                const float* __restrict__ u0, const float* __restrict__ c0,
                                                                long long r0, long long r1, const float* ew_in, float* ew_out,
@@ -149,17 +151,31 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
     const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
 
-    SlabPrefetch<WAVES, S::SLAB> pf;
-    pf.wave = wave;
+    SlabPrefetch<LOADER ? 1 : WAVES, S::SLAB> pf;
+    pf.wave = LOADER ? 0 : wave;
     const float* stream_lane = stream + lane * 4;
     auto pf_begin = [&](int p) {                               // p = phase to prefetch
+        if (LOADER && wave != WAVES) return;                   // compute waves of a loader build never issue DMA
         int start = 0, n = 0;
         if (p < S::NP1) { start = p * GP * G1; n = min(GP, WB - p * GP) * G1; }
         else if (p < S::NP1 + S::NP2) { const int q = p - S::NP1; start = S::C1 + q * GP * G2; n = min(GP, S::NG2 - q * GP) * G2; }
         else if (p < S::NPH && DO_S3) { const int q = p - S::NP1 - S::NP2; start = S::C1 + S::C2 + q * GP * G2; n = min(GP, WB - q * GP) * G2; }
         pf.begin(stream_lane, smem, p, start, n);
     };
-    auto hook = [&]() { pf.tick(); };
+    auto hook = [&]() { if (!LOADER) pf.tick(); };
+    if (LOADER && wave == WAVES) {                             // the loader wave: one phase ahead of the compute waves
+        int p = DO_S1 ? 0 : S::NP1;
+        const int p_end = DO_S3 ? S::NPH : S::NP1 + S::NP2;
+        pf_begin(p);
+        pf.flush();
+        for (; p < p_end; ++p) {
+            phase_barrier();
+            pf_begin(p + 1);
+            pf.flush();
+        }
+        return;
+    }
+    if (LOADER) { pf.n = 0; pf.k = SlabPrefetch<1, S::SLAB>::KMAX; pf.next = 1 << 30; }      // flush() is a no-op in compute waves
     auto A = [&](int p, int j) -> f4 {
         return *reinterpret_cast<const f4*>(smem + ((size_t)(p & 1) * S::SLAB + j) * 256 + lane * 4);
     };

@@ -276,6 +276,10 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
                               (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
         case 12: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 4, 1, S1, S3, false, 3>), cdiv(r1 - r0, 16 * 4), 4 * 64,
                               (GclStream<D, 1>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
+        case 13: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, false, 3, true>), cdiv(r1 - r0, 16 * 8), 9 * 64,
+                              (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
+        case 14: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 11, 2, S1, S3, false, 3, true>), cdiv(r1 - r0, 16 * 11), 12 * 64,
+                              (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
 #endif
         default: return OARD_EINVAL;
     }
@@ -327,6 +331,7 @@ struct TapeOff {
     size_t hin, geo, rbuf, pp0, x1;                                  // init-stage constants
     size_t s_in[OARD_MAX_LAYERS + 1], vec_in[OARD_MAX_LAYERS + 1];  // node state at the start of layer l (index L: final)
     size_t agg[OARD_MAX_LAYERS], s_mid[OARD_MAX_LAYERS];           // mean message per node; s after the GCL node update
+    size_t s_a[OARD_MAX_LAYERS], vec_a[OARD_MAX_LAYERS];           // s, vec after the EquiMessage aggregation (before EquiUpdate)
     size_t ew[OARD_MAX_LAYERS + 1];                                  // edge state entering layer l (index L: final)
     size_t z1[OARD_MAX_LAYERS], z2[OARD_MAX_LAYERS], att[OARD_MAX_LAYERS], z3[OARD_MAX_LAYERS];
     size_t zd1[OARD_MAX_LAYERS], cd[OARD_MAX_LAYERS];
@@ -344,6 +349,7 @@ static TapeOff make_tape(const oard_config* c, const TopoDev& td) {
         t.s_in[l] = take(N * d.HP * 4); t.vec_in[l] = take(N * 3 * d.HP * 4); t.ew[l] = take(E * d.WP * 4);
         if (l == c->num_layers) break;
         t.agg[l] = take(N * d.HP * 4); t.s_mid[l] = take(N * d.HP * 4);
+        t.s_a[l] = take(N * d.HP * 4); t.vec_a[l] = take(N * 3 * d.HP * 4);
         t.z1[l] = take(E * d.HP * 4); t.z2[l] = take(E * d.HP * 4); t.att[l] = take(E * 4); t.z3[l] = take(E * d.WP * 4);
         t.zd1[l] = take(A * d.D1P * 4); t.cd[l] = take(A * 3 * d.HP * 4);
     }
@@ -477,7 +483,8 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
             }
             if (nv1) {
                 LAUNCH(F_NODE, (k_equi_node_v1<D, NW>), gN16, NW * 64, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
-                       (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext);
+                       (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext,
+                       train ? (float*)(tape + to.s_a[l]) : nullptr, train ? (float*)(tape + to.vec_a[l]) : nullptr);
             } else {
                 LAUNCH(F_NODE, (k_equi_agg_v1<D>), gN, 256, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
                        (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext, v2buf, scal, vdot);
@@ -563,6 +570,17 @@ static int scalarize_backward_impl(const oard_config* c, const TopoDev& tp, cons
     const PackOff po = make_layout(c);
     constexpr int NW = D::HT < 4 ? D::HT : 4;      // one wave per SIMD: the kernel keeps ~150 accumulators / constants per lane
     LAUNCH(F_INIT, (k_scalarize_bwd<D, NW>), tp.N, NW * 64, st, tp, wb + po.lin3, ne1, ld, (const float*)(tape + to.geo), dew, dne1, part);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+template <class D>
+static int equi_msg_backward_impl(const TopoDev& tp, const char* tape, const TapeOff& to, int layer, const float* xq, const float* cr,
+                                  const float* gs, const float* gv, float* dcd, float* dcr, float* dxq, float* dvec, hipStream_t st) {
+    const Strided3 xq3{xq, 3 * D::H, D::H}, vec3{(const float*)(tape + to.vec_in[layer]), 3 * D::HP, D::HP}, cr3{cr, 3 * D::H, D::H},
+        gv3{gv, 3 * D::H, D::H};
+    LAUNCH(F_NODE, (k_equi_msg_bwd<D>), tp.N, 256, st, tp, (const float*)(tape + to.geo), xq3, vec3, (const float*)(tape + to.cd[layer]), cr3,
+           gs, D::H, gv3, dcd, dcr, dxq, dvec);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
@@ -1024,6 +1042,8 @@ int oard_tape_entry(const oard_config* c, const oard_topology* topo, int which, 
         case OARD_TAPE_Z3: *offset_bytes = t.z3[layer]; *rows = E1; *row_floats = r.WP; break;
         case OARD_TAPE_ZD1: *offset_bytes = t.zd1[layer]; *rows = A1; *row_floats = r.D1P; break;
         case OARD_TAPE_CD: *offset_bytes = t.cd[layer]; *rows = A1; *row_floats = 3 * r.HP; break;
+        case OARD_TAPE_S_A: *offset_bytes = t.s_a[layer]; *rows = N; *row_floats = r.HP; break;
+        case OARD_TAPE_VEC_A: *offset_bytes = t.vec_a[layer]; *rows = N; *row_floats = 3 * r.HP; break;
         default: return OARD_EINVAL;
     }
     return OARD_OK;
@@ -1134,6 +1154,19 @@ int oard_scalarize_backward(const oard_config* c, const oard_topology* topo, con
     int rc = OARD_EINVAL;
     DISPATCH_DIMS(c, rc = scalarize_backward_impl<D>(c, tp, (const float*)packed, (const char*)tape, to, ne1, ld, dew, dne1, part,
                                                      (hipStream_t)stream));
+    return rc;
+}
+
+int oard_equi_msg_backward(const oard_config* c, const oard_topology* topo, const void* tape, int layer, const float* xq,
+                           const float* cr, const float* gx, const float* gv, float* dcd, float* dcr, float* dxq, float* dvec,
+                           oard_stream_t stream) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1 || !tape || !xq || !cr || !gx || !gv || !dcd || !dcr || !dxq || !dvec ||
+        layer < 0 || layer >= c->num_layers || c->hidden > 256)
+        return OARD_EINVAL;
+    const TopoDev& tp = topo->parts[0].d;
+    const TapeOff to = make_tape(c, tp);
+    int rc = OARD_EINVAL;
+    DISPATCH_DIMS(c, rc = equi_msg_backward_impl<D>(tp, (const char*)tape, to, layer, xq, cr, gx, gv, dcd, dcr, dxq, dvec, (hipStream_t)stream));
     return rc;
 }
 

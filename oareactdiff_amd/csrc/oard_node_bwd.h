@@ -144,3 +144,88 @@ __global__ __launch_bounds__(WAVES * 64) void k_scalarize_bwd(TopoDev tp, const 
         out[i] = s;
     }
 }
+
+// =====================================================================================================
+// k_equi_msg_bwd: adjoint of the message formation + aggregation of EquiMessage (leftnet.py:264-283, the first part of
+// k_equi_node_v1):  per inner edge a = (m -> n), per channel
+//     xs_k = xq[m][k] + xq[n][k],  q_k = cd_k cr_k,   dx[n] += xs_0 q_0,   a2 = xs_1 q_1 / sqrt3,   a3 = xs_2 q_2,
+//     dvec[n][x] += (vec[m][x] a2 + a3 u_a[x]) / sqrt(H)
+// given gX = d/d(dx) and gV = d/d(dvec).  One workgroup per node, one thread per channel; the node is visited in both
+// of its roles - as the target of its incoming edges (writes the per-edge gradients d cd, d cr, accumulates d xq[n]) and
+// as the source of its outgoing edges (accumulates d xq[n] and d vec[n]) - so every sum runs in a fixed order in
+// registers and nothing is scattered with atomics.  The [A, 3H]-sized gather / product / scatter chain this replaces is
+// what an eager formulation spends most of its node-stage time on.
+// =====================================================================================================
+struct Strided3 {            // element (row, k, ch) of a [rows][3][channels] tensor with arbitrary strides
+    const float* p;
+    int row, comp;
+    OARD_DEV float at(size_t r, int k, int ch) const { return p[r * (size_t)row + (size_t)k * comp + ch]; }
+};
+
+template <class D>
+__global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* __restrict__ geo, Strided3 xq, Strided3 vec,
+                                                      const float* __restrict__ cd, Strided3 cr, const float* __restrict__ gX,
+                                                      int gx_row, Strided3 gV, float* __restrict__ dcd, float* __restrict__ dcr,
+                                                      float* __restrict__ dxq, float* __restrict__ dvec) {
+    const int n = blockIdx.x, ch = threadIdx.x;
+    if (ch >= D::H) return;
+    const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt_h = 1.0f / sqrtf((float)D::H);
+    const int q_grp = tp.node_sample[n] * tp.n_obj + tp.node_obj[n];
+    const int g0 = tp.grp_ptr[q_grp], ng = tp.grp_ptr[q_grp + 1] - g0, self = n - g0;
+    const int a_n = tp.act_ptr[n];
+    const float xn[3] = {xq.at(n, 0, ch), xq.at(n, 1, ch), xq.at(n, 2, ch)};
+    const float wn[3] = {vec.at(n, 0, ch), vec.at(n, 1, ch), vec.at(n, 2, ch)};
+    const float gxn = gX[(size_t)n * gx_row + ch];
+    const float gvn[3] = {gV.at(n, 0, ch), gV.at(n, 1, ch), gV.at(n, 2, ch)};
+    float ax[3] = {0.f, 0.f, 0.f};                       // d xq[n]
+    float av[3] = {gvn[0], gvn[1], gvn[2]};              // d vec_in[n]: identity path of vec_a = vec_in + dvec
+    for (int kk = 0; kk < ng; ++kk) {
+        if (kk == self) continue;
+        const int m = g0 + kk;
+#pragma unroll
+        for (int role = 0; role < 2; ++role) {
+            // role 0: edge (m -> n), n is the target;  role 1: edge (n -> m), n is the source
+            const size_t a = role == 0 ? (size_t)a_n + kk - (kk > self ? 1 : 0) : (size_t)tp.act_ptr[m] + self - (self > kk ? 1 : 0);
+            const float* ge = geo + a * GEO_STRIDE;
+            const float u[3] = {ge[2], ge[3], ge[4]};
+            const float* cdr = cd + a * (size_t)(3 * D::HP) + ch;
+            const float c[3] = {cdr[0], cdr[D::HP], cdr[2 * D::HP]};
+            const float r[3] = {cr.at(a, 0, ch), cr.at(a, 1, ch), cr.at(a, 2, ch)};
+            // target-side quantities of this edge (the node itself in role 0, the partner in role 1)
+            float gx, gv[3], xt[3], xs_src[3], w[3];
+            if (role == 0) {
+                gx = gxn;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { gv[k] = gvn[k]; xt[k] = xn[k]; xs_src[k] = xq.at(m, k, ch); w[k] = vec.at(m, k, ch); }
+            } else {
+                gx = gX[(size_t)m * gx_row + ch];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { gv[k] = gV.at(m, k, ch); xt[k] = xq.at(m, k, ch); xs_src[k] = xn[k]; w[k] = wn[k]; }
+            }
+            const float q[3] = {c[0] * r[0], c[1] * r[1], c[2] * r[2]};
+            const float xs[3] = {xs_src[0] + xt[0], xs_src[1] + xt[1], xs_src[2] + xt[2]};
+            const float a2 = xs[1] * q[1] * inv_sqrt3;
+            const float ga2 = (gv[0] * w[0] + gv[1] * w[1] + gv[2] * w[2]) * inv_sqrt_h;
+            const float ga3 = (gv[0] * u[0] + gv[1] * u[1] + gv[2] * u[2]) * inv_sqrt_h;
+            const float dm[3] = {gx, ga2 * inv_sqrt3, ga3};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ax[k] += dm[k] * q[k];             // d xs -> d xq of BOTH end points; this is n's share
+            if (role == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float dq = dm[k] * xs[k];
+                    dcd[a * (size_t)(3 * D::HP) + (size_t)k * D::HP + ch] = dq * r[k];
+                    dcr[a * (size_t)(3 * D::HP) + (size_t)k * D::HP + ch] = dq * c[k];
+                }
+            } else {
+#pragma unroll
+                for (int x = 0; x < 3; ++x) av[x] += gv[x] * a2 * inv_sqrt_h;   // d vec[source = n]
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        dxq[((size_t)n * 3 + k) * D::H + ch] = ax[k];
+        dvec[((size_t)n * 3 + k) * D::H + ch] = av[k];
+    }
+}

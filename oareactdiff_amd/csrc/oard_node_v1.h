@@ -366,7 +366,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                                                              const float* __restrict__ qbuf, const float* __restrict__ xq,
                                                              const float* __restrict__ geo, const float* __restrict__ x1,
                                                              float* __restrict__ s, const float* __restrict__ vec_in,
-                                                             float* __restrict__ vec_out) {
+                                                             float* __restrict__ vec_out,
+                                                             float* __restrict__ sa_out, float* __restrict__ va_out /* training tape: state after the aggregation, or NULL */) {
     constexpr int HT = D::HT;
     constexpr int TPW = (HT + WAVES - 1) / WAVES;            // tiles owned per wave (upper bound)
     __shared__ __attribute__((aligned(16))) float sm[6 * HT * 256 + 48 * 12];
@@ -423,10 +424,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                     v2 += (w2[i] * a2 + a3 * gz[i]) * inv_sqrt_h;
                 }
         }
-        lds_st(in, t, nb.lane, (ld_blk(s, n, D::HP, t, nb.lane) + dx) * inv_sqrt2);
-        lds_st(vx + 0 * HT * 256, t, nb.lane, v0 + ld_blk(vec_in, (size_t)n * 3 + 0, D::HP, t, nb.lane));
-        lds_st(vx + 1 * HT * 256, t, nb.lane, v1 + ld_blk(vec_in, (size_t)n * 3 + 1, D::HP, t, nb.lane));
-        lds_st(vx + 2 * HT * 256, t, nb.lane, v2 + ld_blk(vec_in, (size_t)n * 3 + 2, D::HP, t, nb.lane));
+        const f4 sa = (ld_blk(s, n, D::HP, t, nb.lane) + dx) * inv_sqrt2;
+        v0 += ld_blk(vec_in, (size_t)n * 3 + 0, D::HP, t, nb.lane);
+        v1 += ld_blk(vec_in, (size_t)n * 3 + 1, D::HP, t, nb.lane);
+        v2 += ld_blk(vec_in, (size_t)n * 3 + 2, D::HP, t, nb.lane);
+        lds_st(in, t, nb.lane, sa);
+        lds_st(vx + 0 * HT * 256, t, nb.lane, v0);
+        lds_st(vx + 1 * HT * 256, t, nb.lane, v1);
+        lds_st(vx + 2 * HT * 256, t, nb.lane, v2);
+        if (sa_out != nullptr && nb.valid) {
+            st_blk(sa_out, n, D::HP, t, nb.lane, sa);
+            st_blk(va_out, (size_t)n * 3 + 0, D::HP, t, nb.lane, v0);
+            st_blk(va_out, (size_t)n * 3 + 1, D::HP, t, nb.lane, v1);
+            st_blk(va_out, (size_t)n * 3 + 2, D::HP, t, nb.lane, v2);
+        }
     }
     __syncthreads();
 

@@ -135,25 +135,34 @@ def stage_node_pre(P: Dict[str, Tensor], l: int, s_in: Tensor, g: Geometry, H: i
     return xh, F.linear(xh, w1[:, :H], P[q + "edge_mlp.mlp.0.linear.bias"]), F.linear(xh, w1[:, H:2 * H])
 
 
-def stage_node_mid(P: Dict[str, Tensor], l: int, xh: Tensor, agg: Tensor, cd: Tensor, vec_in: Tensor, g: Geometry,
-                   H: int) -> Tuple[Tensor, Tensor]:
-    """k_gcl_node_v1 + k_equi_node_v1: GCL node update (:172-183), x_proj (:245), message formation and aggregation
-    (:264-283, 857-859), EquiUpdate (:325-346, 861-864).  cd [A,3,H] is dir_proj's output from the HIP edge kernel."""
+def stage_gcl_node(P: Dict[str, Tensor], l: int, xh: Tensor, agg: Tensor, H: int) -> Tuple[Tensor, Tensor]:
+    """k_gcl_node_v1: GCL node update (:172-183) and EquiMessage's node part x_proj (:245) -> (s_mid [N,H], xq [N,3H])."""
     m = "model."
     q = m + f"gcl_layers.{l}."
-    N = xh.shape[0]
     hm = F.silu(F.linear(torch.cat([xh, agg], dim=1), P[q + "node_mlp.mlp.0.linear.weight"], P[q + "node_mlp.mlp.0.linear.bias"]))
     s = xh + F.linear(hm, P[q + "node_mlp.mlp.1.linear.weight"], P[q + "node_mlp.mlp.1.linear.bias"])
     e = m + f"message_layers.{l}."
     xq = F.linear(F.silu(F.linear(_ln(s, P[e + "x_layernorm.weight"], P[e + "x_layernorm.bias"]), P[e + "x_proj.0.weight"])),
                   P[e + "x_proj.2.weight"])
-    cr = F.linear(g.rbf, P[e + "rbf_proj.weight"])                                   # [A,3H]
+    return s, xq
+
+
+def stage_equi_message(P: Dict[str, Tensor], l: int, s: Tensor, xq: Tensor, cd: Tensor, vec_in: Tensor, g: Geometry,
+                       H: int) -> Tuple[Tensor, Tensor]:
+    """Gather half of k_equi_node_v1: message formation and aggregation (:264-283, 857-859) -> (s_a, vec_a).
+    torch restatement: the reference of the HIP adjoint `oard_equi_msg_backward` in the tests (the product's backward does
+    not run this [A, 3H]-sized gather / scatter chain)."""
+    N = s.shape[0]
+    cr = F.linear(g.rbf, P[f"model.message_layers.{l}.rbf_proj.weight"])             # [A,3H]
     msg = (xq[g.src] + xq[g.tgt]) * (cd.reshape(cd.shape[0], 3 * H) * cr)
     x_m, a2, a3 = torch.split(msg, H, dim=-1)
     vmsg = (vec_in[g.src] * (a2 * INV_SQRT3)[:, None, :] + a3[:, None, :] * g.u[:, :, None]) * (1.0 / math.sqrt(H))
-    s = (s + _seg_sum(x_m, g.tgt, N)) * INV_SQRT2
-    vec = vec_in + _seg_sum(vmsg, g.tgt, N)
-    u = m + f"update_layers.{l}."
+    return (s + _seg_sum(x_m, g.tgt, N)) * INV_SQRT2, vec_in + _seg_sum(vmsg, g.tgt, N)
+
+
+def stage_equi_update(P: Dict[str, Tensor], l: int, s: Tensor, vec: Tensor, g: Geometry, H: int) -> Tuple[Tensor, Tensor]:
+    """Second half of k_equi_node_v1: EquiUpdate (:325-346, 861-864) on the aggregated state -> (s_out, vec_out)."""
+    u = f"model.update_layers.{l}."
     v1, v2 = torch.split(vec @ P[u + "vec_proj.weight"].t(), H, dim=-1)             # [N,3,H] each
     sc = (v1 * g.x1[:, :, None]).sum(dim=1)                                          # nodeframe = [x1, 0, 0]
     t3 = torch.stack((sc, torch.zeros_like(sc), torch.zeros_like(sc)), dim=-1)       # [N,H,3]; |0| = 0 (:328-332)
@@ -164,6 +173,14 @@ def stage_node_mid(P: Dict[str, Tensor], l: int, xh: Tensor, agg: Tensor, cd: Te
     xv = F.linear(F.silu(F.linear(torch.cat([s, scalar], dim=-1), P[u + "xvec_proj.0.weight"])), P[u + "xvec_proj.2.weight"])
     xa, xb, xc = torch.split(xv, H, dim=-1)
     return s + (xa + xb + vdot) * INV_SQRT2, vec + xc[:, None, :] * v2
+
+
+def stage_node_mid(P: Dict[str, Tensor], l: int, xh: Tensor, agg: Tensor, cd: Tensor, vec_in: Tensor, g: Geometry,
+                   H: int) -> Tuple[Tensor, Tensor]:
+    """k_gcl_node_v1 + k_equi_node_v1 as one function (tests): cd [A,3,H] is dir_proj's output from the HIP edge kernel."""
+    s, xq = stage_gcl_node(P, l, xh, agg, H)
+    s, vec = stage_equi_message(P, l, s, xq, cd, vec_in, g, H)
+    return stage_equi_update(P, l, s, vec, g, H)
 
 
 def stage_out(P: Dict[str, Tensor], s: Tensor, vec: Tensor) -> Tuple[Tensor, Tensor]:
@@ -379,6 +396,7 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
     mout, dz2, dz1 = (torch.empty(E + 1, HP, device=dev) for _ in range(3))
     da = torch.empty(E + 1, device=dev)
     dzd1 = torch.empty(A + 1, D1P, device=dev)
+    dcd_p, dcr_p = torch.zeros(A + 1, 3, HP, device=dev), torch.zeros(A + 1, 3, HP, device=dev)   # pads / spare row stay zero
     dPQ = torch.empty(2, N, HP, device=dev)
 
     for l in reversed(range(NL)):
@@ -386,20 +404,33 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
         s_in = tape.get(_capi.TAPE_S_IN, l)[:, :H]
         vec_in = tape.get(_capi.TAPE_VEC_IN, l).view(N, 3, HP)[:, :, :H]
         agg = tape.get(_capi.TAPE_AGG, l)[:, :H]
-        cd = tape.get(_capi.TAPE_CD, l)[:A].view(A, 3, HP)[:, :, :H]
         # node stages: k_node_pre_v1 graph first (its outputs feed both the edge kernel and the next node stage)
         (xh, _, _), bw_pre = _local(lambda s: stage_node_pre(P, l, s, g, H), [s_in],
                                     params_of("model.pos_expansion.", q + "x_layernorm.", q + "edge_mlp.mlp.0."))
-        _, bw_mid = _local(lambda a, b, c, d: stage_node_mid(P, l, a, b, c, d, g, H), [xh, agg, cd, vec_in],
-                           params_of(q + "node_mlp.", e + "x_layernorm.", e + "x_proj.", e + "rbf_proj.",
-                                     f"model.update_layers.{l}."))
+        (_, xq), bw_gcl = _local(lambda a, b: stage_gcl_node(P, l, a, b, H), [xh, agg],
+                                 params_of(q + "node_mlp.", e + "x_layernorm.", e + "x_proj."))
+        s_a = tape.get(_capi.TAPE_S_A, l)[:, :H]
+        vec_a = tape.get(_capi.TAPE_VEC_A, l).view(N, 3, HP)[:, :, :H]
+        _, bw_upd = _local(lambda a, b: stage_equi_update(P, l, a, b, g, H), [s_a, vec_a], params_of(f"model.update_layers.{l}."))
         tm.mark("node_fwd_recompute")
-        dxh, dagg, dcd, dvec = bw_mid([ds, dvec], grads)
+        gs_a, gvec_a = bw_upd([ds, dvec], grads)
+        # ---- message formation + aggregation (HIP adjoint): -> d cd, d cr per edge, d xq, d vec entering the layer -------------
+        gx = (gs_a * INV_SQRT2).contiguous()              # s_a = (s_mid + dx) / sqrt2
+        cr = F.linear(g.rbf, P[e + "rbf_proj.weight"])    # [A,3H]
+        dxq = torch.empty(N, 3 * H, device=dev)
+        dvec = torch.empty(N, 3, H, device=dev)
+        _capi.check(L.oard_equi_msg_backward(C.byref(cfg), topo.handle, tape.buf.data_ptr(), l, xq.contiguous().data_ptr(),
+                                             cr.data_ptr(), gx.data_ptr(), gvec_a.contiguous().data_ptr(), dcd_p.data_ptr(),
+                                             dcr_p.data_ptr(), dxq.data_ptr(), dvec.data_ptr(), stream), "oard_equi_msg_backward")
+        if A > 0:
+            grads[e + "rbf_proj.weight"] = _wgrad(dcr_p.view(A + 1, 3 * HP), 3 * HP, H, HP, 3 * H, tape.get(_capi.TAPE_RBF), RP, False,
+                                                  R, R, R, A, False, dyn, stream)[0]
+        else:
+            grads[e + "rbf_proj.weight"] = torch.zeros(3 * H, R, device=dev)
+        dxh, dagg = bw_gcl([gx, dxq], grads)
         tm.mark("node_mid_bwd")
         # ---- EquiMessage edge part (HIP): dcd -> dew[0:A], dir_proj gradients -------------------------------------------
         if A > 0:
-            dcd_p = torch.zeros(A + 1, 3, HP, device=dev)
-            dcd_p[:A, :, :H] = dcd
             _capi.check(L.oard_equi_backward_dx(C.byref(cfg), topo.handle, pbwd.data_ptr(), l, tape.buf.data_ptr(),
                                                 dcd_p.data_ptr(), dew.data_ptr(), dzd1.data_ptr(), stream),
                         "oard_equi_backward_dx")

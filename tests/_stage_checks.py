@@ -154,6 +154,32 @@ def run(name, log=print):
         note(f"bwd layer {l} gcl: dW1c", rel(gw, gr[3][:, 2 * H:]))
         m0t = F.silu(tape.get(_capi.TAPE_Z2, l)[:E, :H])
         note(f"bwd layer {l} gcl: dwatt, dbatt", rel((da[:E, None] * m0t).sum(0, keepdim=True), gr[8]), rel(da[:E].sum().reshape(1), gr[9]))
+        # ---- EquiMessage gather half (k_equi_node_v1 part 1): HIP adjoint vs torch autograd ----
+        if A > 0:
+            with torch.no_grad():
+                agg0 = tape.get(_capi.TAPE_AGG, l)[:, :H]
+                s_mid, xq0 = training.stage_gcl_node(P, l, xh, agg0, H)
+            xq_t = xq0.detach().clone().requires_grad_(True)
+            cd_t = tape.get(_capi.TAPE_CD, l)[:A].view(A, 3, HP)[:, :, :H].detach().clone().requires_grad_(True)
+            vec_t = tape.get(_capi.TAPE_VEC_IN, l).view(N, 3, HP)[:, :, :H].detach().clone().requires_grad_(True)
+            rbfw = P[e + "rbf_proj.weight"]
+            with torch.enable_grad():
+                s_a, vec_a = training.stage_equi_message(P, l, s_mid, xq_t, cd_t, vec_t, g, H)
+            note(f"fwd layer {l} equi message: s_a, vec_a", rel(s_a, tape.get(_capi.TAPE_S_A, l)[:, :H]),
+                 rel(vec_a, tape.get(_capi.TAPE_VEC_A, l).view(N, 3, HP)[:, :, :H]))
+            gS, gVc = torch.randn(N, H, generator=gen).to(dev), torch.randn(N, 3, H, generator=gen).to(dev)
+            gm = torch.autograd.grad([s_a, vec_a], [xq_t, cd_t, vec_t, rbfw], [gS, gVc])
+            gxh = (gS * training.INV_SQRT2).contiguous()
+            crh = F.linear(g.rbf, rbfw).detach()
+            dcdh, dcrh = torch.zeros(A + 1, 3, HP, device=dev), torch.zeros(A + 1, 3, HP, device=dev)
+            dxqh, dvech = torch.empty(N, 3 * H, device=dev), torch.empty(N, 3, H, device=dev)
+            _capi.check(L.oard_equi_msg_backward(C.byref(cfg), topo.handle, tape.buf.data_ptr(), l, xq0.contiguous().data_ptr(), crh.data_ptr(),
+                                                 gxh.data_ptr(), gVc.contiguous().data_ptr(), dcdh.data_ptr(), dcrh.data_ptr(), dxqh.data_ptr(),
+                                                 dvech.data_ptr(), stream), "equi msg bwd")
+            grbf = training._wgrad(dcrh.view(A + 1, 3 * HP), 3 * HP, H, HP, 3 * H, tape.get(_capi.TAPE_RBF), training._pad16(R), False, R, R, R,
+                                   A, False, dyn, stream)[0]
+            note(f"bwd layer {l} equi message: dxq, dcd, dvec, drbf_proj", rel(dxqh, gm[0]), rel(dcdh[:A, :, :H], gm[1]), rel(dvech, gm[2]),
+                 rel(grbf, gm[3]))
         # ---- Equi edge ----
         if A > 0:
             ew1 = tape.get(_capi.TAPE_EW, l + 1)[:A, :W].detach().clone().requires_grad_(True)
