@@ -260,6 +260,18 @@ int oard_equi_backward_dx(const oard_config* cfg, const oard_topology* topo, con
 int oard_equi_msg_backward(const oard_config* cfg, const oard_topology* topo, const void* tape_dev, int layer,
                            const float* xq_dev, const float* cr_dev, const float* gx_dev, const float* gv_dev,
                            float* dcd_dev, float* dcr_dev, float* dxq_dev, float* dvec_dev, oard_stream_t stream);
+/* EquiUpdate's frame-scalar MLP lin3 (leftnet.py:304-310, 333: Linear(3,48) SiLU Linear(48,8) SiLU Linear(8,1) on (x, 0, 0)) as a
+ * differentiable op on n = N*H items (training; the inference forward fuses it into k_equi_node_v1).
+ *   forward : out[i] = lin3(x[i], 0, 0)
+ *   backward: dx[i], and per item the operands of the weight gradients for oard_wgrad:
+ *             xa [n][4] = (x, 1, 0, 0), h1 [n][48], dz1 [n][48], dz2 [n][8], h2a [n][12] = dout * (h2[8], 1, 0, 0, 0)
+ *             (lin3.0: dz1^T xa -> [48][4] = (d weight[:,0] | d bias);  lin3.2: dz2^T h1, bias = column sums of dz2;
+ *              lin3.4: column sums of h2a = (d weight[8] | d bias)). */
+int oard_lin3u_forward(const oard_config* cfg, const void* packed_dev, int layer, const float* x_dev, int64_t n,
+                       float* out_dev, oard_stream_t stream);
+int oard_lin3u_backward(const oard_config* cfg, const void* packed_dev, int layer, const float* x_dev, const float* dout_dev,
+                        int64_t n, float* dx_dev, float* xa_dev, float* h1_dev, float* dz1_dev, float* h2a_dev,
+                        float* dz2_dev, oard_stream_t stream);
 /* Adjoint of the edge scalarisation + lin3 (leftnet.py:792-806, k_scalarize): from the gradient of the initial edge state
  * (dew_dev [E+1][WP], columns [0, 2H) of the inner rows) and NE1 (ne1_dev [N][3][ld], ld >= H, the CFConvS2V output) to
  *   dne1_dev [N][3][ld]     gradient w.r.t. NE1

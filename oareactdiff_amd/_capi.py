@@ -21,7 +21,7 @@ EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_by
            "oard_timing_get",
            "oard_topology_create_parts", "oard_topology_export", "oard_tape_bytes", "oard_tape_entry", "oard_forward_train",
            "oard_packed_bwd_bytes", "oard_pack_weights_bwd", "oard_gcl_backward_dx", "oard_edge_node_sums",
-           "oard_equi_backward_dx", "oard_scalarize_backward", "oard_equi_msg_backward", "oard_wgrad_scratch_bytes", "oard_wgrad"]
+           "oard_equi_backward_dx", "oard_scalarize_backward", "oard_equi_msg_backward", "oard_lin3u_forward", "oard_lin3u_backward", "oard_wgrad_scratch_bytes", "oard_wgrad"]
 
 # oard_topology_export tables / oard_tape_entry tensors (include/oard.h)
 TOPO_NODE_REF, TOPO_NODE_OBJ, TOPO_NODE_ROW, TOPO_NODE_SAMPLE, TOPO_NODE_TIDX, TOPO_SAMPLE_PTR, TOPO_GROUP_PTR, \
@@ -96,6 +96,8 @@ def lib() -> C.CDLL:
     L.oard_equi_backward_dx.argtypes = [cfgp, vp, vp, ci, vp, vp, vp, vp, vp]; L.oard_equi_backward_dx.restype = ci
     L.oard_scalarize_backward.argtypes = [cfgp, vp, vp, vp, vp, ci, vp, vp, vp, vp]; L.oard_scalarize_backward.restype = ci
     L.oard_equi_msg_backward.argtypes = [cfgp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]; L.oard_equi_msg_backward.restype = ci
+    L.oard_lin3u_forward.argtypes = [cfgp, vp, ci, vp, i64, vp, vp]; L.oard_lin3u_forward.restype = ci
+    L.oard_lin3u_backward.argtypes = [cfgp, vp, ci, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]; L.oard_lin3u_backward.restype = ci
     L.oard_wgrad_scratch_bytes.argtypes = [ci, ci, i64]; L.oard_wgrad_scratch_bytes.restype = sz
     L.oard_wgrad.argtypes = [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, i64, vp, vp, vp, sz, vp]; L.oard_wgrad.restype = ci
     L.oard_debug_stop_after.argtypes = [C.c_int]; L.oard_debug_stop_after.restype = C.c_int

@@ -1170,6 +1170,27 @@ int oard_equi_msg_backward(const oard_config* c, const oard_topology* topo, cons
     return rc;
 }
 
+int oard_lin3u_forward(const oard_config* c, const void* packed, int layer, const float* x, int64_t n, float* out,
+                       oard_stream_t stream) {
+    if (!config_ok(c) || !packed || !x || !out || n < 0 || layer < 0 || layer >= c->num_layers) return OARD_EINVAL;
+    const PackOff po = make_layout(c);
+    if (n > 0) LAUNCH(F_NODE, k_lin3u_fwd, cdiv(n, 256), 256, (hipStream_t)stream, (const float*)packed + po.layer[layer].l3u, x, (long long)n, out);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+int oard_lin3u_backward(const oard_config* c, const void* packed, int layer, const float* x, const float* dout, int64_t n,
+                        float* dx, float* xa, float* h1, float* dz1, float* h2a, float* dz2, oard_stream_t stream) {
+    if (!config_ok(c) || !packed || !x || !dout || !dx || !xa || !h1 || !dz1 || !h2a || !dz2 || n < 0 || layer < 0 ||
+        layer >= c->num_layers)
+        return OARD_EINVAL;
+    const PackOff po = make_layout(c);
+    if (n > 0) LAUNCH(F_NODE, k_lin3u_bwd, cdiv(n, 256), 256, (hipStream_t)stream, (const float*)packed + po.layer[layer].l3u, x, dout,
+                      (long long)n, dx, xa, h1, dz1, h2a, dz2);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
 size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows) {
     if (ncY < 4 || ncX < 4 || rows < 0) return 0;
     const WgradPlan p = wgrad_plan(ncY, ncX, rows);

@@ -229,3 +229,78 @@ __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* _
         dvec[((size_t)n * 3 + k) * D::H + ch] = av[k];
     }
 }
+
+// =====================================================================================================
+// EquiUpdate's frame-scalar MLP (leftnet.py:304-310, 333) as its own differentiable op (training):
+//     out = lin3.4( SiLU( lin3.2( SiLU( lin3.0 (x, 0, 0) ) ) ) )          per (node, channel) item, x = <vec1, x1>
+// (the node frame is [x1, 0, 0] exactly, so rows 1, 2 of the scalarisation are zero and |0| = 0: only column 0 of
+// lin3.0.weight takes part).  N*H ~ 8.7e5 items of a 1 -> 48 -> 8 -> 1 MLP: in eager torch the K = 3 / N = 3 GEMMs and the
+// [items, 48] reductions cost ~3 ms per layer; here one thread per item, weights through scalar loads.
+// The backward kernel writes, per item, the operands of the weight gradients in row-major arrays and oard_wgrad (the same
+// deterministic GEMM the edge stages use) reduces them:  xa = (x, 1, 0, 0), h1 [48], dz1 [48], dz2 [8] and
+// h2a = dout * (h2[8], 1, 0, 0, 0), whose column sums are the gradients of lin3.4's weight and bias.
+// p: raw parameter block  w0[48][3] b0[48] w2[8][48] b2[8] w4[8] b4[1]  (LayerOff::l3u)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_lin3u_fwd(const float* __restrict__ p, const float* __restrict__ x, long long n,
+                                                   float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = lin3u(p, x[i]);
+}
+
+__global__ __launch_bounds__(256) void k_lin3u_bwd(const float* __restrict__ p, const float* __restrict__ x,
+                                                   const float* __restrict__ dout, long long n, float* __restrict__ dx,
+                                                   float* __restrict__ xa, float* __restrict__ h1o, float* __restrict__ dz1o,
+                                                   float* __restrict__ h2a, float* __restrict__ dz2o) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* w0 = p;
+    const float* b0 = p + 144;
+    const float* w2 = p + 192;
+    const float* b2 = p + 576;
+    const float* w4 = p + 584;
+    const float xv = x[i], g = dout[i];
+    float z2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z2[j] = b2[j];
+    float* h1row = h1o + i * 48;
+    for (int k0 = 0; k0 < 48; k0 += 4) {
+        f4 h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = k0 + c;
+            const float hk = silu1(w0[3 * k] * xv + b0[k]);
+            h[c] = hk;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z2[j] += w2[j * 48 + k] * hk;
+        }
+        st_f4(h1row + k0, h);
+    }
+    float dz2[8];
+    f4 ha = f4zero(), hb = f4zero();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float h2 = silu1(z2[j]);
+        dz2[j] = g * w4[j] * dsilu1(z2[j]);
+        if (j < 4) ha[j] = g * h2; else hb[j - 4] = g * h2;
+    }
+    st_f4(h2a + i * 12, ha); st_f4(h2a + i * 12 + 4, hb); st_f4(h2a + i * 12 + 8, (f4){g, 0.f, 0.f, 0.f});
+    st_f4(dz2o + i * 8, (f4){dz2[0], dz2[1], dz2[2], dz2[3]}); st_f4(dz2o + i * 8 + 4, (f4){dz2[4], dz2[5], dz2[6], dz2[7]});
+    st_f4(xa + i * 4, (f4){xv, 1.f, 0.f, 0.f});
+    float dxv = 0.f;
+    float* dz1row = dz1o + i * 48;
+    for (int k0 = 0; k0 < 48; k0 += 4) {
+        f4 d;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = k0 + c;
+            float dh = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dh += w2[j * 48 + k] * dz2[j];
+            const float dz = dh * dsilu1(w0[3 * k] * xv + b0[k]);
+            d[c] = dz;
+            dxv += w0[3 * k] * dz;
+        }
+        st_f4(dz1row + k0, d);
+    }
+    dx[i] = dxv;
+}

@@ -160,15 +160,58 @@ def stage_equi_message(P: Dict[str, Tensor], l: int, s: Tensor, xq: Tensor, cd: 
     return (s + _seg_sum(x_m, g.tgt, N)) * INV_SQRT2, vec_in + _seg_sum(vmsg, g.tgt, N)
 
 
-def stage_equi_update(P: Dict[str, Tensor], l: int, s: Tensor, vec: Tensor, g: Geometry, H: int) -> Tuple[Tensor, Tensor]:
-    """Second half of k_equi_node_v1: EquiUpdate (:325-346, 861-864) on the aggregated state -> (s_out, vec_out)."""
+class Lin3uFunction(torch.autograd.Function):
+    """EquiUpdate's frame-scalar MLP (leftnet.py:304-310, 333) on [N, H] items through oard_lin3u_forward / _backward;
+    the weight gradients are reduced by oard_wgrad.  `hip` = (dyn, cfg, layer, stream)."""
+
+    @staticmethod
+    def forward(ctx, sc, w0, b0, w2, b2, w4, b4, hip):
+        dyn, cfg, layer, stream = hip
+        x = sc.contiguous()
+        out = torch.empty_like(x)
+        packed = dyn._get_packed(cfg, stream)
+        _capi.check(_capi.lib().oard_lin3u_forward(C.byref(cfg), packed.data_ptr(), layer, x.data_ptr(), x.numel(), out.data_ptr(),
+                                                   stream), "oard_lin3u_forward")
+        ctx.save_for_backward(x)
+        ctx.hip = hip
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        dyn, cfg, layer, stream = ctx.hip
+        n, dev = x.numel(), x.device
+        g = dout.contiguous()
+        dx = torch.empty_like(x)
+        xa, h1, dz1 = torch.empty(n, 4, device=dev), torch.empty(n, 48, device=dev), torch.empty(n, 48, device=dev)
+        h2a, dz2 = torch.empty(n, 12, device=dev), torch.empty(n, 8, device=dev)
+        packed = dyn._get_packed(cfg, stream)
+        _capi.check(_capi.lib().oard_lin3u_backward(C.byref(cfg), packed.data_ptr(), layer, x.data_ptr(), g.data_ptr(), n,
+                                                    dx.data_ptr(), xa.data_ptr(), h1.data_ptr(), dz1.data_ptr(), h2a.data_ptr(),
+                                                    dz2.data_ptr(), stream), "oard_lin3u_backward")
+        g0 = _wgrad(dz1, 48, 48, 48, 48, xa, 4, False, 2, 2, 2, n, False, dyn, stream)[0]           # [48, 2] = (d w0[:,0] | d b0)
+        gw0 = torch.zeros(48, 3, device=dev)
+        gw0[:, 0] = g0[:, 0]
+        gw2, gb2 = _wgrad(dz2, 8, 8, 8, 8, h1, 48, False, 48, 48, 48, n, True, dyn, stream)
+        g4 = _wgrad(h2a, 12, 9, 9, 9, xa, 4, False, 1, 1, 1, n, True, dyn, stream)[1]                # column sums of h2a
+        return dx, gw0, g0[:, 1].contiguous(), gw2, gb2, g4[:8].view(1, 8), g4[8:9], None
+
+
+def stage_equi_update(P: Dict[str, Tensor], l: int, s: Tensor, vec: Tensor, g: Geometry, H: int, hip=None) -> Tuple[Tensor, Tensor]:
+    """Second half of k_equi_node_v1: EquiUpdate (:325-346, 861-864) on the aggregated state -> (s_out, vec_out).
+    `hip` = (dyn, cfg, layer, stream): the frame-scalar MLP runs as the HIP op `Lin3uFunction` (product path); None: the
+    plain torch formulation (tests: the reference of that op)."""
     u = f"model.update_layers.{l}."
     v1, v2 = torch.split(vec @ P[u + "vec_proj.weight"].t(), H, dim=-1)             # [N,3,H] each
     sc = (v1 * g.x1[:, :, None]).sum(dim=1)                                          # nodeframe = [x1, 0, 0]
-    t3 = torch.stack((sc, torch.zeros_like(sc), torch.zeros_like(sc)), dim=-1)       # [N,H,3]; |0| = 0 (:328-332)
-    t3 = F.silu(F.linear(t3, P[u + "lin3.0.weight"], P[u + "lin3.0.bias"]))
-    t3 = F.silu(F.linear(t3, P[u + "lin3.2.weight"], P[u + "lin3.2.bias"]))
-    scalar = F.linear(t3, P[u + "lin3.4.weight"], P[u + "lin3.4.bias"]).squeeze(-1)
+    if hip is not None:
+        scalar = Lin3uFunction.apply(sc, P[u + "lin3.0.weight"], P[u + "lin3.0.bias"], P[u + "lin3.2.weight"], P[u + "lin3.2.bias"],
+                                     P[u + "lin3.4.weight"], P[u + "lin3.4.bias"], hip)
+    else:
+        t3 = torch.stack((sc, torch.zeros_like(sc), torch.zeros_like(sc)), dim=-1)   # [N,H,3]; |0| = 0 (:328-332)
+        t3 = F.silu(F.linear(t3, P[u + "lin3.0.weight"], P[u + "lin3.0.bias"]))
+        t3 = F.silu(F.linear(t3, P[u + "lin3.2.weight"], P[u + "lin3.2.bias"]))
+        scalar = F.linear(t3, P[u + "lin3.4.weight"], P[u + "lin3.4.bias"]).squeeze(-1)
     vdot = (v1 * v2).sum(dim=1) * (1.0 / math.sqrt(H))
     xv = F.linear(F.silu(F.linear(torch.cat([s, scalar], dim=-1), P[u + "xvec_proj.0.weight"])), P[u + "xvec_proj.2.weight"])
     xa, xb, xc = torch.split(xv, H, dim=-1)
@@ -411,7 +454,8 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
                                  params_of(q + "node_mlp.", e + "x_layernorm.", e + "x_proj."))
         s_a = tape.get(_capi.TAPE_S_A, l)[:, :H]
         vec_a = tape.get(_capi.TAPE_VEC_A, l).view(N, 3, HP)[:, :, :H]
-        _, bw_upd = _local(lambda a, b: stage_equi_update(P, l, a, b, g, H), [s_a, vec_a], params_of(f"model.update_layers.{l}."))
+        _, bw_upd = _local(lambda a, b: stage_equi_update(P, l, a, b, g, H, hip=(dyn, cfg, l, stream)), [s_a, vec_a],
+                           params_of(f"model.update_layers.{l}."))
         tm.mark("node_fwd_recompute")
         gs_a, gvec_a = bw_upd([ds, dvec], grads)
         # ---- message formation + aggregation (HIP adjoint): -> d cd, d cr per edge, d xq, d vec entering the layer -------------

@@ -180,6 +180,19 @@ def run(name, log=print):
                                    A, False, dyn, stream)[0]
             note(f"bwd layer {l} equi message: dxq, dcd, dvec, drbf_proj", rel(dxqh, gm[0]), rel(dcdh[:A, :, :H], gm[1]), rel(dvech, gm[2]),
                  rel(grbf, gm[3]))
+        # ---- EquiUpdate with the HIP frame-scalar op (Lin3uFunction) vs the plain torch formulation ----
+        un = [n_ for n_ in P if n_.startswith(f"model.update_layers.{l}.")]
+        sa0 = tape.get(_capi.TAPE_S_A, l)[:, :H]
+        va0 = tape.get(_capi.TAPE_VEC_A, l).view(N, 3, HP)[:, :, :H]
+        cs, cv = torch.randn(N, H, generator=gen).to(dev), torch.randn(N, 3, H, generator=gen).to(dev)
+        res = []
+        for hip in (None, (dyn, cfg, l, stream)):
+            a_, b_ = sa0.detach().clone().requires_grad_(True), va0.detach().clone().requires_grad_(True)
+            with torch.enable_grad():
+                o1, o2 = training.stage_equi_update(P, l, a_, b_, g, H, hip=hip)
+            res.append((o1.detach(), o2.detach(), torch.autograd.grad([o1, o2], [a_, b_] + [P[n_] for n_ in un], [cs, cv])))
+        note(f"fwd layer {l} equi update (HIP lin3u vs torch): s, vec", rel(res[1][0], res[0][0]), rel(res[1][1], res[0][1]))
+        note(f"bwd layer {l} equi update (HIP lin3u vs torch)", *[rel(x_, y_) for x_, y_ in zip(res[1][2], res[0][2])])
         # ---- Equi edge ----
         if A > 0:
             ew1 = tape.get(_capi.TAPE_EW, l + 1)[:A, :W].detach().clone().requires_grad_(True)

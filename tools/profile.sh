@@ -21,3 +21,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${tag}_write -o p -- $B 
 python tools/pmc_summary.py gpurun_out/${tag}_write/p_results.db --per-forward $P k_gcl_edge k_equi_edge > gpurun_out/${tag}_pmc_write.txt
 rm -rf gpurun_out/${tag}_trace gpurun_out/${tag}_sq gpurun_out/${tag}_fetch gpurun_out/${tag}_write
 head -14 gpurun_out/${tag}_kernel_trace_summary.txt; cat gpurun_out/${tag}_pmc_sq.txt gpurun_out/${tag}_pmc_fetch.txt gpurun_out/${tag}_pmc_write.txt
+# training step (BASELINE config 4): kernel trace of bench.py --mode train (3 timed steps + 1 warm-up + 2 timing steps)
+unset OARD_PARTS
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_ttrace -o t -- python bench.py --mode train --steps 3 --warmup 1 > gpurun_out/${tag}_ttrace.log 2>&1
+python tools/prof_summary.py gpurun_out/${tag}_ttrace/t_results.db > gpurun_out/${tag}_train_kernel_trace_summary.txt
+grep '"metric"' gpurun_out/${tag}_ttrace.log | tail -1 > gpurun_out/${tag}_train_bench_line_under_profiler.json
+rm -rf gpurun_out/${tag}_ttrace
