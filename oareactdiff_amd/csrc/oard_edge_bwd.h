@@ -398,6 +398,52 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ dY, 
     }
 }
 
+// Small outputs (MO * (MI + 1) <= 1024, e.g. the 8 x 48 / 48 x 2 / 1 x 9 layers of the frame-scalar MLPs over ~1e6 rows): the MFMA
+// kernel above would run 128 x 256 tiles that are almost all padding and is latency-bound there.  Here a workgroup stages 64
+// rows of both operands in LDS and every thread owns up to four outputs (o, i); column i == MI is the bias (X = 1).
+// partial layout: [chunk][MO][MI + 1].
+__global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ dY, int ldY, int MO, const float* __restrict__ X, int ldX,
+                                                     int MI, int x_silu, long long rows, long long rows_per_chunk,
+                                                     float* __restrict__ partial) {
+    __shared__ float sy[64 * 65], sx[64 * 65];
+    const int tid = threadIdx.x, nout = MO * (MI + 1);
+    const long long rb = (long long)blockIdx.x * rows_per_chunk;
+    const long long re = rb + rows_per_chunk < rows ? rb + rows_per_chunk : rows;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int oo[4], ii[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int idx = min(tid + 256 * q, nout - 1); oo[q] = idx / (MI + 1); ii[q] = idx % (MI + 1); }
+    for (long long r0 = rb; r0 < re; r0 += 64) {
+        const int nr = (int)(re - r0 < 64 ? re - r0 : 64);
+        __syncthreads();
+        for (int k = tid; k < 64 * MO; k += 256) { const int r = k / MO, c = k % MO; sy[r * 65 + c] = r < nr ? dY[(size_t)(r0 + r) * ldY + c] : 0.f; }
+        for (int k = tid; k < 64 * (MI + 1); k += 256) {
+            const int r = k / (MI + 1), c = k % (MI + 1);
+            float v = c == MI ? 1.0f : (r < nr ? X[(size_t)(r0 + r) * ldX + c] : 0.f);
+            if (x_silu && c < MI) v = silu1(v);
+            sx[r * 65 + c] = r < nr ? v : 0.f;
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += sy[r * 65 + oo[q]] * sx[r * 65 + ii[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (tid + 256 * q < nout) partial[(size_t)blockIdx.x * nout + tid + 256 * q] = acc[q];
+}
+// dW [MO][MI] and db [MO] from the small kernel's partials, chunks in ascending order
+__global__ void k_wgrad_small_reduce(const float* __restrict__ partial, int n_chunks, int MO, int MI, float* __restrict__ dW,
+                                     float* __restrict__ db) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, nout = MO * (MI + 1);
+    if (idx >= nout) return;
+    float s = 0.f;
+    for (int ch = 0; ch < n_chunks; ++ch) s += partial[(size_t)ch * nout + idx];
+    const int o = idx / (MI + 1), i = idx % (MI + 1);
+    if (i < MI) dW[o * MI + i] = s;
+    else if (db != nullptr) db[o] = s;
+}
+
 // second pass: out[o][i] (dense, logical shape) = sum over chunks in ascending order; logical index -> padded
 // index by sections (o = s * len + w  ->  s * pad + w), which undoes the 196 -> 208 padding of split projections
 __global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int MOp, int MIp, int o_len, int o_pad,

@@ -1194,7 +1194,8 @@ int oard_lin3u_backward(const oard_config* c, const void* packed, int layer, con
 size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows) {
     if (ncY < 4 || ncX < 4 || rows < 0) return 0;
     const WgradPlan p = wgrad_plan(ncY, ncX, rows);
-    return ((size_t)p.n_chunks * p.MOp * p.MIp + (size_t)p.n_chunks * p.MOp) * sizeof(float);
+    const size_t big = ((size_t)p.n_chunks * p.MOp * p.MIp + (size_t)p.n_chunks * p.MOp) * sizeof(float);
+    return std::max(big, (size_t)1024 * 1024 * sizeof(float));        // the small-output path: <= 1024 chunks x <= 1024 outputs
 }
 
 int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, const float* X, int ldX, int ncX,
@@ -1209,6 +1210,16 @@ int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, 
     if (scratch_bytes < oard_wgrad_scratch_bytes(ncY, ncX, rows)) return OARD_ENOMEM;
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)scratch;
+    if (o_len >= MO && i_len >= MI && MO <= 64 && MI < 64 && MO * (MI + 1) <= 1024) {      // small, unsectioned outputs
+        const int n_chunks = (int)std::max<long long>(1, std::min<long long>(1024, cdiv(rows, 256)));
+        const long long rpc = align_up((size_t)cdiv(std::max<long long>(rows, 1), n_chunks), 64);
+        const int nch = (int)cdiv(std::max<long long>(rows, 1), rpc);
+        ScopedLaunch sl_(F_WGRAD, st);
+        hipLaunchKernelGGL(k_wgrad_small, dim3(nch), dim3(256), 0, st, dY, ldY, MO, X, ldX, MI, x_silu, (long long)rows, rpc, partial);
+        hipLaunchKernelGGL(k_wgrad_small_reduce, dim3((unsigned)cdiv(MO * (MI + 1), 256)), dim3(256), 0, st, partial, nch, MO, MI, dW, db);
+        HIP_TRY(hipGetLastError());
+        return OARD_OK;
+    }
     float* bpartial = partial + (size_t)p.n_chunks * p.MOp * p.MIp;
     ScopedLaunch sl_(F_WGRAD, st);
     if (x_silu)
