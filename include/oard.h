@@ -124,6 +124,14 @@ int oard_sampler_step(const oard_config* cfg, const oard_topology* topo, int mod
                       const float* const* h0_dev, float a, float b, float c, int zero_feature_noise,
                       float* const* out_dev, oard_stream_t stream);
 
+/* As oard_sampler_step with the three scalars (a, b, c) read from device memory (coef_dev[3]): the launch is then
+ * identical for every step, so one captured hipGraph of [oard_forward, oard_sampler_step_dev] replays the whole loop
+ * (the host only advances a device-side step index that selects the row of the schedule table). */
+int oard_sampler_step_dev(const oard_config* cfg, const oard_topology* topo, int mode,
+                          const float* const* z_dev, const float* const* eps_hat_dev, const float* const* noise_dev,
+                          const float* const* h0_dev, const float* coef_dev, int zero_feature_noise,
+                          float* const* out_dev, oard_stream_t stream);
+
 /* ---- introspection (tests / profiling) --------------------------------------------------------
  * Copies an intermediate tensor of the LAST oard_forward on this workspace into dst_dev, in the
  * reference's node / edge order, dense [rows, cols] fp32.  `which`: see OARD_TAP_*.  `layer`

@@ -6,6 +6,7 @@ See DESIGN.md (path, kernels, measurement) and INTEGRATION.md (binding)."""
 from .dynamics import EGNNDynamics  # noqa: F401
 from .sampler import DiffusionSampler  # noqa: F401
 from .loss import DiffusionLoss  # noqa: F401
+from .trainer import DDPMTrainer  # noqa: F401
 from .graph_tools import get_edges_index, get_mask_for_frag, get_n_frag_switch, get_subgraph_mask  # noqa: F401
 
-__all__ = ["EGNNDynamics", "DiffusionSampler", "DiffusionLoss", "get_edges_index", "get_mask_for_frag", "get_n_frag_switch", "get_subgraph_mask"]
+__all__ = ["EGNNDynamics", "DiffusionSampler", "DiffusionLoss", "DDPMTrainer", "get_edges_index", "get_mask_for_frag", "get_n_frag_switch", "get_subgraph_mask"]

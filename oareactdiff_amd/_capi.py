@@ -17,7 +17,7 @@ TAP_S, TAP_VEC, TAP_EDGE, TAP_POS_FRAME, TAP_DPOS, TAP_HOUT, TAP_LABELS, TAP_NE1
 EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_bytes", "oard_pack_weights",
            "oard_topology_create", "oard_topology_destroy", "oard_topology_num_nodes", "oard_topology_num_edges",
            "oard_topology_num_inner_edges", "oard_topology_num_samples", "oard_topology_check_edge_index",
-           "oard_workspace_bytes", "oard_forward", "oard_sampler_step", "oard_tap", "oard_debug_stop_after", "oard_debug_option", "oard_timing_enable", "oard_timing_reset",
+           "oard_workspace_bytes", "oard_forward", "oard_sampler_step", "oard_sampler_step_dev", "oard_tap", "oard_debug_stop_after", "oard_debug_option", "oard_timing_enable", "oard_timing_reset",
            "oard_timing_get",
            "oard_topology_create_parts", "oard_topology_export", "oard_tape_bytes", "oard_tape_entry", "oard_forward_train",
            "oard_packed_bwd_bytes", "oard_pack_weights_bwd", "oard_gcl_backward_dx", "oard_edge_node_sums",
@@ -80,6 +80,9 @@ def lib() -> C.CDLL:
     L.oard_sampler_step.argtypes = [cfgp, vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                     C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(vp), vp]
     L.oard_sampler_step.restype = C.c_int
+    L.oard_sampler_step_dev.argtypes = [cfgp, vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, C.c_int,
+                                        C.POINTER(vp), vp]
+    L.oard_sampler_step_dev.restype = C.c_int
     L.oard_tap.argtypes = [cfgp, vp, vp, C.c_int, C.c_int, vp, vp]; L.oard_tap.restype = C.c_int
     ci = C.c_int
     L.oard_topology_create_parts.argtypes = [cfgp, C.POINTER(i64), C.POINTER(i64), i64, ci, C.POINTER(vp)]

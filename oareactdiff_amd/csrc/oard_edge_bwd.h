@@ -316,85 +316,98 @@ __global__ __launch_bounds__(64) void k_edge_node_sums(TopoDev tp, const float* 
 }
 
 // =====================================================================================================
-// weight gradient GEMM:  partial[chunk][o][i] = sum_{rows of the chunk} dY[row][o] * act(X[row][i])
-// block = 4 waves; wave (wo, wi) owns dY block 2*blockIdx.y + wo (64 features) x X blocks 4*blockIdx.z + 2*wi + {0,1}.
-// ncY / ncX = readable columns of a row (multiples of 4); features beyond them contribute zeros.
-// bpartial (optional): per-chunk column sums of dY (the bias gradient).
+// weight gradient GEMM:  partial[chunk][pf][qf] = sum_{rows of the chunk} P[row][pf] * act(Q[row][qf])
+// Both operands are row-major [rows][features]: the contraction index is their SLOW index.  The "wide" operand P is read as
+// one float4 per lane (4 rows x 64 features, coalesced 256-byte segments): component c of lane (g, i) is P[row g][64 pb + 4 i + c],
+// i.e. the A operand of an MFMA whose output row i stands for feature 4 i + c - four accumulators per P block, no transpose.
+// The "narrow" operand Q is read as 16-feature tiles, one dword per lane (lane (g, j): Q[row g][16 t + j] = the B operand), so
+// widths that are multiples of 16 but not of 64 (H = 196 -> 208 = 13 tiles, 3H -> 592 = 37 tiles) cost no padding.
+// A wave owns one P block (64 features) x NT Q tiles: 4 NT accumulators, 4 NT MFMAs per 4 rows from 1 + NT loads.
+// psum / qsum (optional): per-chunk column sums of P / Q (the bias gradient is the column sum of dY).
 // =====================================================================================================
 #define OARD_WG_PD 2                 // prefetch distance in 4-row steps (3 spills at the 256-register bound)
-template <bool XSILU>
-__global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ dY, int ldY, int ncY,
-                                                  const float* __restrict__ X, int ldX, int ncX, long long r0, long long r1,
-                                                  long long rows_per_chunk, float* __restrict__ partial,
-                                                  float* __restrict__ bpartial, int MOp, int MIp) {
+template <bool QSILU, int NT>
+__global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ P, int ldP, int ncP, const float* __restrict__ Q, int ldQ,
+                                                  int ncQ, long long r0, long long r1, long long rows_per_chunk, int nPB, int nQG,
+                                                  float* __restrict__ partial, float* __restrict__ psum, float* __restrict__ qsum) {
     const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
-    const int wave = threadIdx.x >> 6, wo = wave >> 1, wi = wave & 1;
-    const int ob = blockIdx.y * 2 + wo, ib0 = blockIdx.z * 4 + 2 * wi;
-    const long long rb = r0 + (long long)blockIdx.x * rows_per_chunk;
+    // grid.x = chunk * gy + task group (4 consecutive (P block, Q group) tasks per workgroup, Q group fastest): the workgroups
+    // that stream the same row chunk are dispatched back to back.  Measured alternatives (profiles/round2_wgrad_notes.txt):
+    // XCD-aware placement of a chunk's workgroups -15 %, 8-wave workgroups owning 4 P blocks x 2 Q groups -23 %.
+    const int gy = (nPB * nQG + 3) / 4;
+    const int chunk = blockIdx.x / gy;
+    const int task = (blockIdx.x % gy) * 4 + (threadIdx.x >> 6);
+    const long long rb = r0 + (long long)chunk * rows_per_chunk;
+    if (task >= nPB * nQG || rb >= r1) return;
+    const int pb = task / nQG, qg = task - pb * nQG;
+    const int PP = nPB * 64, QP = nQG * NT * 16;
     const long long re = rb + rows_per_chunk < r1 ? rb + rows_per_chunk : r1;
-    const int cy = 64 * ob + 4 * i, cx0 = 64 * ib0 + 4 * i, cx1 = cx0 + 64;
-    const bool oky = cy < ncY, okx0 = cx0 < ncX, okx1 = cx1 < ncX;
-    const float* py = dY + cy;
-    const float* px0 = X + cx0;
-    const float* px1 = X + cx1;
+    const int cp = 64 * pb + 4 * i;
+    const bool okp = cp < ncP;
+    const float* pp = P + cp;
+    const float* pq = Q + 16 * qg * NT + i;
+    bool okq[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) okq[u] = 16 * (qg * NT + u) + i < ncQ;
 
-    f4 acc[2][4][4];
+    f4 acc[4][NT];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int u = 0; u < NT; ++u) acc[c][u] = f4zero();
+    f4 ps = f4zero();
+    float qs[NT];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) acc[b][c][d] = f4zero();
-    f4 bs = f4zero();
-    f4 ry[OARD_WG_PD], rx0[OARD_WG_PD], rx1[OARD_WG_PD];
+    for (int u = 0; u < NT; ++u) qs[u] = 0.f;
+    f4 ra[OARD_WG_PD];
+    float rq[OARD_WG_PD][NT];
     auto load = [&](int slot, long long row) {
         const bool v = row < re;
-        ry[slot] = (v && oky) ? ld_f4(py + (size_t)row * ldY) : f4zero();
-        f4 a = (v && okx0) ? ld_f4(px0 + (size_t)row * ldX) : f4zero();
-        f4 b = (v && okx1) ? ld_f4(px1 + (size_t)row * ldX) : f4zero();
-        rx0[slot] = a; rx1[slot] = b;
+        ra[slot] = (v && okp) ? ld_f4(pp + (size_t)row * ldP) : f4zero();
+#pragma unroll
+        for (int u = 0; u < NT; ++u) rq[slot][u] = (v && okq[u]) ? pq[(size_t)row * ldQ + 16 * u] : 0.f;
     };
 #pragma unroll
     for (int u = 0; u < OARD_WG_PD; ++u) load(u, rb + 4 * u + g);
     for (long long r = rb; r < re; r += 4 * OARD_WG_PD) {
 #pragma unroll
-        for (int u = 0; u < OARD_WG_PD; ++u) {
-            const f4 y = ry[u];
-            f4 x0 = rx0[u], x1 = rx1[u];
-            load(u, r + 4 * (u + OARD_WG_PD) + g);
-            if (XSILU) { x0 = silu4(x0); x1 = silu4(x1); }
-            bs += y;
-            const float yc[4] = {y.x, y.y, y.z, y.w};
-            const float xa[4] = {x0.x, x0.y, x0.z, x0.w};
-            const float xb[4] = {x1.x, x1.y, x1.z, x1.w};
+        for (int s = 0; s < OARD_WG_PD; ++s) {
+            const f4 a = ra[s];
+            float b[NT];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int u = 0; u < NT; ++u) b[u] = QSILU ? silu1(rq[s][u]) : rq[s][u];
+            load(s, r + 4 * (s + OARD_WG_PD) + g);
+            ps += a;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    acc[0][c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(yc[c], xa[d], acc[0][c][d], 0, 0, 0);
-                    acc[1][c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(yc[c], xb[d], acc[1][c][d], 0, 0, 0);
-                }
-        }
-    }
-    // accumulator (c, d), component q of lane (g, j):  dW[64 ob + 4 (4g + q) + c][64 ib + 4 j + d]
-    float* out = partial + (size_t)blockIdx.x * MOp * MIp;
+            for (int u = 0; u < NT; ++u) qs[u] += b[u];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int o = 64 * ob + 4 * (4 * g + q) + c;
-                const int col = 64 * (ib0 + b) + 4 * i;
-                st_f4(out + (size_t)o * MIp + col, (f4){acc[b][c][0][q], acc[b][c][1][q], acc[b][c][2][q], acc[b][c][3][q]});
+            for (int u = 0; u < NT; ++u) {
+                acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[u], acc[0][u], 0, 0, 0);
+                acc[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[u], acc[1][u], 0, 0, 0);
+                acc[2][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[u], acc[2][u], 0, 0, 0);
+                acc[3][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u], acc[3][u], 0, 0, 0);
             }
         }
-    if (bpartial != nullptr && blockIdx.z == 0 && wi == 0) {
-        bs.x += __shfl_xor(bs.x, 16, 64); bs.x += __shfl_xor(bs.x, 32, 64);
-        bs.y += __shfl_xor(bs.y, 16, 64); bs.y += __shfl_xor(bs.y, 32, 64);
-        bs.z += __shfl_xor(bs.z, 16, 64); bs.z += __shfl_xor(bs.z, 32, 64);
-        bs.w += __shfl_xor(bs.w, 16, 64); bs.w += __shfl_xor(bs.w, 32, 64);
-        if (g == 0) st_f4(bpartial + (size_t)blockIdx.x * MOp + 64 * ob + 4 * i, bs);
+    }
+    // accumulator (c, u), component q of lane (g, j):  out[64 pb + 4 (4g + q) + c][16 (qg NT + u) + j]
+    float* out = partial + (size_t)chunk * PP * QP;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                out[(size_t)(64 * pb + 4 * (4 * g + q) + c) * QP + 16 * (qg * NT + u) + i] = acc[c][u][q];
+    if (psum != nullptr && qg == 0) {
+        ps.x = col_reduce(ps.x); ps.y = col_reduce(ps.y); ps.z = col_reduce(ps.z); ps.w = col_reduce(ps.w);
+        if (g == 0) st_f4(psum + (size_t)chunk * PP + 64 * pb + 4 * i, ps);
+    }
+    if (qsum != nullptr && pb == 0) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float v = col_reduce(qs[u]);
+            if (g == 0) qsum[(size_t)chunk * QP + 16 * (qg * NT + u) + i] = v;
+        }
     }
 }
 
@@ -444,25 +457,26 @@ __global__ void k_wgrad_small_reduce(const float* __restrict__ partial, int n_ch
     else if (db != nullptr) db[o] = s;
 }
 
-// second pass: out[o][i] (dense, logical shape) = sum over chunks in ascending order; logical index -> padded
-// index by sections (o = s * len + w  ->  s * pad + w), which undoes the 196 -> 208 padding of split projections
-__global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int MOp, int MIp, int o_len, int o_pad,
+// second pass: dW[o][i] (dense, logical nn.Linear shape) = sum over chunks in ascending order.  Logical index -> padded index by
+// sections (o = s * len + w -> s * pad + w), which undoes the 196 -> 208 padding of split projections.  `transposed`: the
+// partials are [x feature][dY feature] (the kernel ran with P = X, Q = dY).
+__global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int PP, int QP, int transposed, int o_len, int o_pad,
                                int MO, int i_len, int i_pad, int MI, float* __restrict__ out) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)MO * MI) return;
     const int o = (int)(idx / MI), i = (int)(idx % MI);
     const int op = (o / o_len) * o_pad + o % o_len, ip = (i / i_len) * i_pad + i % i_len;
-    const float* p = partial + (size_t)op * MIp + ip;
+    const float* p = partial + (transposed ? (size_t)ip * QP + op : (size_t)op * QP + ip);
     float s = 0.f;
-    for (int ch = 0; ch < n_chunks; ++ch) s += p[(size_t)ch * MOp * MIp];
+    for (int ch = 0; ch < n_chunks; ++ch) s += p[(size_t)ch * PP * QP];
     out[idx] = s;
 }
-__global__ void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int MOp, int o_len, int o_pad, int MO,
+__global__ void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int stride, int o_len, int o_pad, int MO,
                                float* __restrict__ out) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= MO) return;
     const int op = (o / o_len) * o_pad + o % o_len;
     float s = 0.f;
-    for (int ch = 0; ch < n_chunks; ++ch) s += bpartial[(size_t)ch * MOp + op];
+    for (int ch = 0; ch < n_chunks; ++ch) s += bpartial[(size_t)ch * stride + op];
     out[o] = s;
 }

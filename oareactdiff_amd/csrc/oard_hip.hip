@@ -585,15 +585,22 @@ static int equi_msg_backward_impl(const TopoDev& tp, const char* tape, const Tap
     return OARD_OK;
 }
 
-// chunking of the weight-gradient GEMM: a pure function of the shape, so that the summation order (and with it the
-// result, bit for bit) does not depend on anything else
-struct WgradPlan { int gy, gz, MOp, MIp; long long rpc; int n_chunks; };
+// plan of the weight-gradient GEMM: a pure function of the shape, so that the summation order (and with it the result,
+// bit for bit) does not depend on anything else.  Q (16-wide tiles, no padding waste) is the narrower operand; when that is
+// dY the kernel produces the transposed product.
+struct WgradPlan { int transposed, NT, nPB, nQG, PP, QP, gy; long long rpc; int n_chunks; };
 static WgradPlan wgrad_plan(int ncY, int ncX, long long rows) {
     WgradPlan p;
-    p.gy = (int)cdiv(ncY, 128); p.gz = (int)cdiv(ncX, 256); p.MOp = p.gy * 128; p.MIp = p.gz * 256;
-    long long want = std::max<long long>(1, 1024 / (p.gy * p.gz));
+    p.transposed = ncX > ncY ? 1 : 0;
+    const int ncP = p.transposed ? ncX : ncY, ncQ = p.transposed ? ncY : ncX;
+    const int nQT = (int)cdiv(ncQ, 16);
+    p.NT = (cdiv(nQT, 7) * 7 <= cdiv(nQT, 8) * 8) ? 7 : 8;
+    p.nPB = (int)cdiv(ncP, 64); p.nQG = (int)cdiv(nQT, p.NT);
+    p.PP = p.nPB * 64; p.QP = p.nQG * p.NT * 16;
+    p.gy = (int)cdiv((long long)p.nPB * p.nQG, 4);            // workgroups (4 waves = 4 (P block, Q group) tasks) per row chunk
+    long long want = std::max<long long>(1, 1024 / p.gy);
     want = std::min(want, std::max<long long>(1, cdiv(rows, 64)));
-    p.rpc = align_up((size_t)cdiv(std::max<long long>(rows, 1), want), 16);
+    p.rpc = align_up((size_t)cdiv(std::max<long long>(rows, 1), want), 4 * OARD_WG_PD);
     p.n_chunks = (int)cdiv(std::max<long long>(rows, 1), p.rpc);
     return p;
 }
@@ -957,9 +964,26 @@ int oard_forward(const oard_config* c, const oard_topology* topo, const void* pa
     return OARD_OK;
 }
 
+static int sampler_step_impl(const oard_config* c, const oard_topology* topo, int mode, const float* const* z,
+                             const float* const* eh, const float* const* noise, const float* const* h0, float a, float b,
+                             float cc, const float* coef, int zero_feature_noise, float* const* out, oard_stream_t stream);
+
 int oard_sampler_step(const oard_config* c, const oard_topology* topo, int mode, const float* const* z,
                       const float* const* eh, const float* const* noise, const float* const* h0, float a, float b,
                       float cc, int zero_feature_noise, float* const* out, oard_stream_t stream) {
+    return sampler_step_impl(c, topo, mode, z, eh, noise, h0, a, b, cc, nullptr, zero_feature_noise, out, stream);
+}
+
+int oard_sampler_step_dev(const oard_config* c, const oard_topology* topo, int mode, const float* const* z,
+                          const float* const* eh, const float* const* noise, const float* const* h0, const float* coef,
+                          int zero_feature_noise, float* const* out, oard_stream_t stream) {
+    if (!coef) return OARD_EINVAL;
+    return sampler_step_impl(c, topo, mode, z, eh, noise, h0, 0.f, 0.f, 0.f, coef, zero_feature_noise, out, stream);
+}
+
+static int sampler_step_impl(const oard_config* c, const oard_topology* topo, int mode, const float* const* z,
+                             const float* const* eh, const float* const* noise, const float* const* h0, float a, float b,
+                             float cc, const float* coef, int zero_feature_noise, float* const* out, oard_stream_t stream) {
     if (!config_ok(c) || !topo || !noise || !out || mode < 0 || mode > 4) return OARD_EINVAL;
     if (mode != 2 && !z) return OARD_EINVAL;
     if (mode <= 1 && !eh) return OARD_EINVAL;
@@ -976,7 +1000,7 @@ int oard_sampler_step(const oard_config* c, const oard_topology* topo, int mode,
     }
     hipStream_t st = (hipStream_t)stream;
     for (int p = 0; p < topo->n_parts; ++p)
-        LAUNCH(F_OTHER, k_sampler_step, cdiv(topo->parts[p].d.N, 128), 128, st, topo->parts[p].d, sp, mode, a, b, cc,
+        LAUNCH(F_OTHER, k_sampler_step, cdiv(topo->parts[p].d.N, 128), 128, st, topo->parts[p].d, sp, mode, a, b, cc, coef,
                zero_feature_noise);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
@@ -1194,7 +1218,7 @@ int oard_lin3u_backward(const oard_config* c, const void* packed, int layer, con
 size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows) {
     if (ncY < 4 || ncX < 4 || rows < 0) return 0;
     const WgradPlan p = wgrad_plan(ncY, ncX, rows);
-    const size_t big = ((size_t)p.n_chunks * p.MOp * p.MIp + (size_t)p.n_chunks * p.MOp) * sizeof(float);
+    const size_t big = ((size_t)p.n_chunks * p.PP * p.QP + (size_t)p.n_chunks * std::max(p.PP, p.QP)) * sizeof(float);
     return std::max(big, (size_t)1024 * 1024 * sizeof(float));        // the small-output path: <= 1024 chunks x <= 1024 outputs
 }
 
@@ -1207,6 +1231,7 @@ int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, 
     if (((MO - 1) / o_len) * o_pad + (MO - 1) % o_len >= ncY || ((MI - 1) / i_len) * i_pad + (MI - 1) % i_len >= ncX)
         return OARD_EINVAL;
     const WgradPlan p = wgrad_plan(ncY, ncX, rows);
+    if (x_silu && p.transposed) return OARD_EINVAL;          // SiLU-on-load exists for the narrow operand only (never needed otherwise)
     if (scratch_bytes < oard_wgrad_scratch_bytes(ncY, ncX, rows)) return OARD_ENOMEM;
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)scratch;
@@ -1220,19 +1245,26 @@ int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, 
         HIP_TRY(hipGetLastError());
         return OARD_OK;
     }
-    float* bpartial = partial + (size_t)p.n_chunks * p.MOp * p.MIp;
-    ScopedLaunch sl_(F_WGRAD, st);
-    if (x_silu)
-        hipLaunchKernelGGL(k_wgrad<true>, dim3(p.n_chunks, p.gy, p.gz), dim3(256), 0, st, dY, ldY, ncY, X, ldX, ncX, 0LL,
-                           (long long)rows, p.rpc, partial, db ? bpartial : nullptr, p.MOp, p.MIp);
-    else
-        hipLaunchKernelGGL(k_wgrad<false>, dim3(p.n_chunks, p.gy, p.gz), dim3(256), 0, st, dY, ldY, ncY, X, ldX, ncX, 0LL,
-                           (long long)rows, p.rpc, partial, db ? bpartial : nullptr, p.MOp, p.MIp);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 256)), dim3(256), 0, st, partial, p.n_chunks,
-                       p.MOp, p.MIp, o_len, o_pad, MO, i_len, i_pad, MI, dW);
-    if (db)
-        hipLaunchKernelGGL(k_bgrad_reduce, dim3((unsigned)cdiv(MO, 256)), dim3(256), 0, st, bpartial, p.n_chunks, p.MOp,
-                           o_len, o_pad, MO, db);
+    float* bpartial = partial + (size_t)p.n_chunks * p.PP * p.QP;
+    const float* Pm = p.transposed ? X : dY;
+    const float* Qm = p.transposed ? dY : X;
+    const int ldP = p.transposed ? ldX : ldY, ncP = p.transposed ? ncX : ncY, ldQ = p.transposed ? ldY : ldX, ncQ = p.transposed ? ncY : ncX;
+    float* psum = (db && !p.transposed) ? bpartial : nullptr;
+    float* qsum = (db && p.transposed) ? bpartial : nullptr;
+    {
+        ScopedLaunch sl_(F_WGRAD, st);
+        const dim3 grid((unsigned)(p.n_chunks * p.gy)), block(256);
+#define WG_LAUNCH(SILU_, NT_) hipLaunchKernelGGL((k_wgrad<SILU_, NT_>), grid, block, 0, st, Pm, ldP, ncP, Qm, ldQ, ncQ, 0LL, (long long)rows, \
+                                                 p.rpc, p.nPB, p.nQG, partial, psum, qsum)
+        if (p.NT == 7) { if (x_silu) WG_LAUNCH(true, 7); else WG_LAUNCH(false, 7); }
+        else { if (x_silu) WG_LAUNCH(true, 8); else WG_LAUNCH(false, 8); }
+#undef WG_LAUNCH
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 256)), dim3(256), 0, st, partial, p.n_chunks, p.PP,
+                           p.QP, p.transposed, o_len, o_pad, MO, i_len, i_pad, MI, dW);
+        if (db)
+            hipLaunchKernelGGL(k_bgrad_reduce, dim3((unsigned)cdiv(MO, 256)), dim3(256), 0, st, bpartial, p.n_chunks,
+                               p.transposed ? p.QP : p.PP, o_len, o_pad, MO, db);
+    }
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }

@@ -226,9 +226,13 @@ struct SamplerPtrs {
     float* out[OARD_MAX_OBJECTS];
     int node_nf[OARD_MAX_OBJECTS];
 };
-__global__ void k_sampler_step(TopoDev tp, SamplerPtrs sp, int mode, float a, float b, float c, int zero_h) {
+// coef != NULL: the three schedule scalars come from device memory (a captured hipGraph replays the same launch for every
+// step; the host only advances a device-side step counter that selects the row of the coefficient table)
+__global__ void k_sampler_step(TopoDev tp, SamplerPtrs sp, int mode, float a, float b, float c, const float* __restrict__ coef,
+                               int zero_h) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= tp.N) return;
+    if (coef != nullptr) { a = coef[0]; b = coef[1]; c = coef[2]; }
     const int obj = tp.node_obj[n], row = tp.node_row[n], nf = sp.node_nf[obj];
     const int q = tp.node_sample[n] * tp.n_obj + obj;
     const int g0 = tp.grp_ptr[q], g1 = tp.grp_ptr[q + 1];

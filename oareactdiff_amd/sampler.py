@@ -77,12 +77,65 @@ class DiffusionSampler:
                                  C.c_float(a), C.c_float(b), C.c_float(c), 1 if self.pos_only else 0, arr(out), stream)
         _capi.check(rc, "oard_sampler_step")
 
+    def _step_kernel_dev(self, topo, mode, z, eh, noise, h0, coef, out, stream):
+        """As `_step_kernel` with the schedule scalars in device memory (`coef` [3]): the launch a hipGraph replays."""
+        L = _capi.lib()
+        cfg = self.dynamics._config()
+        n = len(self.node_nfs)
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts]) if ts is not None else None
+        rc = L.oard_sampler_step_dev(C.byref(cfg), topo.handle, mode, arr(z), arr(eh), arr(noise), arr(h0), coef.data_ptr(),
+                                     1 if self.pos_only else 0, arr(out), stream)
+        _capi.check(rc, "oard_sampler_step_dev")
+
+    def _graphed_steps(self, dyn, topo, timesteps, za, draw, h0d, edge_index, conditions, n_frag_switch, combined_mask, dev):
+        """The T ancestral steps of `sample` as ONE captured hipGraph replayed T times (small batches are launch-bound:
+        ~100 kernel launches per step).  The per-step scalars live in device tables indexed by a device-side step counter:
+        t, the three schedule coefficients and the step's noise draw; the graph holds [table lookups, oard_forward,
+        oard_sampler_step_dev, z <- z_new, counter += 1].  Same kernels and same arithmetic as the eager loop, so the
+        result is bit-identical.  Captured on a side stream after an eager warm-up step, as torch.cuda.graph requires."""
+        n_obj = len(self.node_nfs)
+        steps = list(reversed(range(timesteps)))
+        coefs = [self.schedule.step(s, timesteps) for s in steps]
+        coef_tab = torch.tensor([[c.alpha_ts, c.c_eps, c.sigma] for c in coefs], dtype=torch.float32, device=dev)      # [T,3]
+        # the eager loop's t values, bit for bit: (arange(T + 1) / T)[s + 1]
+        t_tab = (torch.arange(timesteps + 1, device=dev, dtype=torch.float32) / timesteps)[torch.tensor([s + 1 for s in steps], device=dev)]
+        draws = [draw(i + 1) for i in range(timesteps)]                  # the eager loop's draw order: call 1 .. T
+        noise_tab = [torch.stack([d[k] for d in draws]) for k in range(n_obj)]                                           # [T, n_k, nf_k]
+        counter = torch.zeros(1, dtype=torch.long, device=dev)
+        z = [x.clone() for x in za]
+        z_new = [torch.empty_like(x) for x in za]
+
+        def one_step():
+            t_cur = t_tab.index_select(0, counter)                       # [1]: a 1-D t = one value for every node
+            coef = coef_tab.index_select(0, counter).view(3)
+            noise = [nt.index_select(0, counter)[0] for nt in noise_tab]
+            eps_hat, _ = dyn(z, edge_index, t_cur, conditions, n_frag_switch, combined_mask)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            self._step_kernel_dev(topo, 0, z, eps_hat, noise, h0d if self.pos_only else None, coef, z_new, stream)
+            for a, b in zip(z, z_new):
+                a.copy_(b)
+            counter.add_(1)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                                    # eager warm-up on the capture stream (step 0)
+            one_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        if timesteps > 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                one_step()
+            for _ in range(timesteps - 1):
+                g.replay()
+        return z
+
     @torch.no_grad()
     def sample(self, n_samples: int, fragments_nodes: List[Tensor], conditions: Optional[Tensor] = None,
                return_frames: int = 1, timesteps: Optional[int] = None, h0: Optional[List[Tensor]] = None,
-               noise_fn: Optional[Callable[[int], List[Tensor]]] = None) -> Tuple[list, List[Tensor]]:
+               noise_fn: Optional[Callable[[int], List[Tensor]]] = None, graph: Optional[bool] = None) -> Tuple[list, List[Tensor]]:
         """`noise_fn(i)` (tests) supplies the i-th set of raw N(0,1) draws, one [n_k, node_nf_k] tensor per
-        object (i = 0 initial state, 1..T the steps, T+1 the final draw); default: torch.randn on the device."""
+        object (i = 0 initial state, 1..T the steps, T+1 the final draw); default: torch.randn on the device.
+        `graph`: replay the step as a captured hipGraph (`_graphed_steps`); None = automatically for launch-bound batches
+        (n_samples <= 8, one returned frame)."""
         timesteps = self.T if timesteps is None else timesteps
         assert 0 < return_frames <= timesteps and timesteps % return_frames == 0       # en_diffusion.py:473-475
         assert h0 is not None if self.pos_only else True
@@ -117,7 +170,13 @@ class DiffusionSampler:
                 t_table = torch.arange(timesteps + 1, device=dev, dtype=torch.float32) / timesteps
                 out_samples = [None] * return_frames
                 call = 1
-                for s in reversed(range(timesteps)):
+                use_graph = (n_samples <= 8 and return_frames == 1) if graph is None else bool(graph)
+                if use_graph:
+                    assert return_frames == 1, "intermediate frames need the eager loop"
+                    za = self._graphed_steps(dyn, topo, timesteps, za, draw, h0d, edge_index, conditions, n_frag_switch,
+                                             combined_mask, dev)
+                    call = timesteps + 1
+                for s in (reversed(range(timesteps)) if not use_graph else ()):
                     co = self.schedule.step(s, timesteps)
                     eps_hat, _ = dyn(za, edge_index, t_table[s + 1: s + 2], conditions, n_frag_switch, combined_mask)
                     self._step_kernel(topo, 0, za, eps_hat, draw(call), h0d if self.pos_only else None,
