@@ -28,6 +28,18 @@ OARD_DEV void phase_barrier() {
     __syncthreads();
 }
 
+// Counted form: the `n` most recent vector-memory operations of this wave may stay in flight across the barrier (they are the
+// edge-state loads for the phase AFTER the next one, issued after this phase's last DMA piece; vmcnt retires in issue order,
+// so everything older - every DMA piece, every store - has landed).
+// The barrier is issued from the same asm statement: __syncthreads() is also a workgroup-scope fence, for which hipcc drains
+// vmcnt to 0 whenever a global store is in flight - exactly the wait this form exists to avoid.  Nothing this kernel exchanges
+// between waves goes through global memory (only LDS: lgkmcnt(0) + the DMA's vmcnt), so the fence is not needed.
+OARD_DEV void phase_barrier_keep(int n) {
+    if (n >= 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // two (a, b, acc) triples interleaved: consecutive MFMAs never depend on each other
 // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency)
 OARD_DEV void mma_pair(f4 a0, f4 b0, f4& c0, f4 a1, f4 b1, f4& c1) {
@@ -139,7 +151,9 @@ struct GclTape {
 // Columns are the physical rows [r0, r1).
 // LOADER: a (WAVES+1)-th wave does nothing but issue the LDS-DMA of the next phase's slab (the compute waves then carry no
 //   DMA issue cost); it needs a third wave slot on one SIMD, i.e. the kernel held to 168 registers (MINW = 3).
-template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2, bool LOADER = false>
+// PF2: the edge-state blocks are fetched TWO phases ahead and the phase barrier waits with a counted vmcnt, so an HBM round trip
+//   (several microseconds under load) has two phases to complete instead of one (GP <= 2, inference only).
+template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2, bool LOADER = false, bool PF2 = false>
 __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                                const float* __restrict__ P, const float* __restrict__ Q,
                                                                const float* __restrict__ u0, const float* __restrict__ c0,
@@ -204,13 +218,18 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     pf.flush();                                                // burst form (prologue only)
 
     // ---- S1: h1 += W1c . ew   (K-outer) -------------------------------------------------------------
+    f4 xnn[GP];
+    int kept = 0;                                              // loads issued after the last DMA piece of the previous phase
     for (int p1 = 0; DO_S1 && p1 < S::NP1; ++p1, ++p) {
-        phase_barrier();
+        if (PF2) phase_barrier_keep(kept); else phase_barrier();
         f4 x[GP];
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) x[gg] = xn[gg];
         pf_begin(p + 1);
-        if (p1 + 1 < S::NP1) {
+        if (PF2 && p1 > 0) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) xn[gg] = xnn[gg];
+        } else if (p1 + 1 < S::NP1) {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int b = (p1 + 1) * GP + gg;
@@ -221,6 +240,16 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
         for (int gg = 0; gg < GP; ++gg)
             if (p1 * GP + gg < WB) chain_kouter<HT>(SL(p), gg * G1, x[gg], h1, hook);
         pf.flush();
+        if (PF2) {                                             // blocks of phase p1 + 2, issued after this phase's last DMA piece
+            __builtin_amdgcn_sched_barrier(0);
+            kept = 0;
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) {
+                const int b = (p1 + 2) * GP + gg;
+                if (b < WB) { xnn[gg] = ld_f4(erow + 16 * b); ++kept; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     if (TRAIN) {
 #pragma unroll
@@ -271,8 +300,10 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
         return;
     }
     f4 pend[GP], pendz[TRAIN ? GP : 1];
+    f4 onn[GP];
+    kept = 0;
     for (int p3 = 0; p3 < S::NP3; ++p3, ++p) {
-        phase_barrier();
+        if (PF2) phase_barrier_keep(kept); else phase_barrier();
         if (p3 == 0) {
 #pragma unroll
             for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e], D::HP, t, lane, m[t]);
@@ -287,7 +318,10 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) o[gg] = on[gg];
         pf_begin(p + 1);
-        if (p3 + 1 < S::NP3) {
+        if (PF2 && p3 > 0) {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) on[gg] = onn[gg];
+        } else if (p3 + 1 < S::NP3) {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int t = (p3 + 1) * GP + gg;
@@ -305,6 +339,16 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
             }
         }
         pf.flush();
+        if (PF2) {                                             // old-state tiles of phase p3 + 2, after this phase's last DMA piece
+            __builtin_amdgcn_sched_barrier(0);
+            kept = 0;
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg) {
+                const int t = (p3 + 2) * GP + gg;
+                if (t < WB) { onn[gg] = DO_S1 ? ld_f4(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g); ++kept; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int gg = 0; gg < GP; ++gg) {
