@@ -72,3 +72,63 @@ def test_hip_training_step_gradients_match_reference_f64(name):
             bad.append(n)
         print(f"  {n:62s} ours {errs[n]:.2e}   reference f32 {gap[n]:.2e}{flag}")
     assert flat <= 2e-5 and not bad, (flat, bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pos_only,alias", [(True, None), (False, [1, 2])])
+def test_hip_gradients_pos_only_and_shared_encoders(pos_only, alias):
+    """The production training switches the goldens do not cover: `pos_only=True` (train_ts1x.py:107: feature outputs are zeroed
+    before the loss) and `enforce_same_encoding` (one encoder / decoder shared by several objects, _base.py:110-113: its gradient
+    is the sum over the objects).  Reference: the float64 oracle under torch autograd (pinned on the reference's gradients by
+    test_oracle_autograd_matches_reference_gradients), exact node frame, same recorded t_int / noise."""
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.loss import DiffusionLoss
+    c = GradCase("g9_grad_h32")
+    dev = torch.device("cuda:0")
+    dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=NODE_NFS, edge_nf=0,
+                       condition_nf=CNF, device=dev, enforce_same_encoding=alias)
+    dyn.load_state_dict(c.state_dict(), strict=True)
+    enc_alias = [0 if (alias and k in alias) else k for k in range(3)]
+    sd = c.state_dict(torch.float64)
+    for k, v in sd.items():
+        if v.is_floating_point() and "radial_emb" not in k:
+            v.requires_grad_(True)
+
+    def odyn(xh, edge_index, t, conditions, n_frag_switch, combined_mask, edge_attr=None):
+        return oracle.dynamics_forward(sd, c.cfg, xh, edge_index, t, conditions, n_frag_switch, combined_mask, CNF,
+                                       nodeframe="exact", encoder_alias=enc_alias), None
+    odyn.pos_dim, odyn.node_nfs = 3, NODE_NFS
+
+    def loss_of(dynamics, dtype, device):
+        it = iter(range(c.meta["n_randn"]))
+        dl = DiffusionLoss(dynamics, "polynomial_2", c.meta["T"], 1e-5, norm_values=c.meta["norm_values"], node_nfs=NODE_NFS,
+                           pos_only=pos_only, scales=(1.0, 2.0, 1.0))
+        t_int = torch.tensor(c.meta["t_int"], dtype=dtype, device=device).view(-1, 1)
+        cond = torch.zeros(len(c.meta["sizes"]), 1, dtype=dtype, device=device)
+        nll, _ = dl.compute_loss(c.reps(dtype, device), cond, training=True, t_int=t_int,
+                                 draw=lambda shape: torch.from_numpy(c.z[f"randn{next(it)}"]).to(device=device, dtype=dtype))
+        return nll.mean(0)
+    lo = loss_of(odyn, torch.float64, "cpu")
+    lo.backward()
+    lh = loss_of(dyn, torch.float32, dev)
+    lh.backward()
+    assert abs(float(lh) - float(lo)) <= 2e-5 * abs(float(lo))
+    num = den = 0.0
+    worst = ("", 0.0)
+    for name, p in dyn.named_parameters():                     # named_parameters lists a shared module once (its first name)
+        ref = sd[name].grad
+        if p.grad is None:
+            assert ref is None or float(ref.abs().max()) == 0.0, name
+            continue
+        if alias and name.startswith(("encoders.0.", "decoders.0.")):      # the oracle keeps one tensor per object: add them up
+            ref = sum(sd[name.replace(".0.", f".{j}.", 1)].grad if sd[name.replace(".0.", f".{j}.", 1)].grad is not None else 0
+                      for j in range(3) if enc_alias[j] == 0)
+        d = p.grad.double().cpu() - ref
+        num += float((d ** 2).sum())
+        den += float((ref ** 2).sum())
+        e = float(d.abs().max()) / max(float(ref.abs().max()), 1e-300)
+        if float(ref.abs().max()) > 0 and e > worst[1]:
+            worst = (name, e)
+    flat = (num / den) ** 0.5
+    print(f"pos_only={pos_only} alias={alias}: flat {flat:.2e}, worst tensor {worst[0]} {worst[1]:.2e}")
+    assert flat <= 2e-5 and worst[1] <= 2e-4, (flat, worst)
