@@ -121,6 +121,13 @@ struct SlabPrefetch {
 // S2 = (HT+1) groups x (1+HT)  [bias b2 | W2 tile t] + gate group [batt | watt as a 1-row tile];
 // S3 = WB groups x (1+HT)  [bias b3 | W3 tile t].
 // =====================================================================================================
+// edge-state block load of the GCL kernel (its own name so that a timing experiment can stub it out: -DOARD_ABL_NOEDGELOAD)
+#ifdef OARD_ABL_NOEDGELOAD
+OARD_DEV f4 ld_edge(const float* p) { return (f4){0.25f, -0.5f, 0.125f, 1.0f}; }
+#else
+OARD_DEV f4 ld_edge(const float* p) { return ld_f4(p); }
+#endif
+
 template <class D, int GP>
 struct GclStream {
     static constexpr int HT = D::HT, WB = D::WB, G1 = HT, G2 = HT + 1, NG2 = HT + 1;
@@ -212,7 +219,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     }
     f4 xn[GP];
 #pragma unroll
-    for (int gg = 0; gg < GP; ++gg) xn[gg] = (DO_S1 && gg < WB) ? ld_f4(erow + 16 * gg) : f4zero();
+    for (int gg = 0; gg < GP; ++gg) xn[gg] = (DO_S1 && gg < WB) ? ld_edge(erow + 16 * gg) : f4zero();
     int p = DO_S1 ? 0 : S::NP1;
     pf_begin(p);
     pf.flush();                                                // burst form (prologue only)
@@ -233,7 +240,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int b = (p1 + 1) * GP + gg;
-                if (b < WB) xn[gg] = ld_f4(erow + 16 * b);
+                if (b < WB) xn[gg] = ld_edge(erow + 16 * b);
             }
         }
 #pragma unroll
@@ -246,7 +253,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int b = (p1 + 2) * GP + gg;
-                if (b < WB) { xnn[gg] = ld_f4(erow + 16 * b); ++kept; }
+                if (b < WB) { xnn[gg] = ld_edge(erow + 16 * b); ++kept; }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -268,7 +275,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
         if (DO_S3 && p2 == S::NP2 - 1) {            // prefetch the old edge-state tiles of S3's first phase
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg)
-                on[gg] = gg < WB ? (DO_S1 ? ld_f4(erow + 16 * gg) : ld_f4(c0 + 16 * gg + 4 * g)) : f4zero();
+                on[gg] = gg < WB ? (DO_S1 ? ld_edge(erow + 16 * gg) : ld_f4(c0 + 16 * gg + 4 * g)) : f4zero();
         }
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
@@ -326,7 +333,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
             for (int gg = 0; gg < GP; ++gg) {
                 const int t = (p3 + 1) * GP + gg;
                 if (t < WB)      // !DO_S1: the old state of these rows IS the constant row (never materialised)
-                    on[gg] = DO_S1 ? ld_f4(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
+                    on[gg] = DO_S1 ? ld_edge(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
             }
         }
 #pragma unroll
@@ -345,7 +352,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int t = (p3 + 2) * GP + gg;
-                if (t < WB) { onn[gg] = DO_S1 ? ld_f4(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g); ++kept; }
+                if (t < WB) { onn[gg] = DO_S1 ? ld_edge(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g); ++kept; }
             }
             __builtin_amdgcn_sched_barrier(0);
         }

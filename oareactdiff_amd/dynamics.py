@@ -359,9 +359,8 @@ class EGNNDynamics(nn.Module):
         L = _capi.lib()
         dev = xh[0].device
         n_obj = len(self.node_nfs)
-        # the layout changes every training step: the topology is rebuilt, and the edge_index check is the same
-        check = self._get_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
-        topo = training.TrainTopology(cfg, combined_mask, n_frag_switch, stream)
+        # the layout changes every training step: one (single sub-batch) topology per call, edge_index verified on it
+        topo = check = training.TrainTopology(cfg, combined_mask, n_frag_switch, stream, edge_index=edge_index)
         xs = []
         for k in range(n_obj):
             x = xh[k].detach()

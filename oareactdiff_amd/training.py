@@ -242,7 +242,7 @@ def stage_out(P: Dict[str, Tensor], s: Tensor, vec: Tensor) -> Tuple[Tensor, Ten
 class TrainTopology:
     """parts == 1 topology plus the index tables the stage functions need (internal order, int64 on the device)."""
 
-    def __init__(self, cfg, combined_mask: Tensor, n_frag_switch: Tensor, stream: int):
+    def __init__(self, cfg, combined_mask: Tensor, n_frag_switch: Tensor, stream: int, edge_index: Optional[Tensor] = None):
         L = _capi.lib()
         dev = combined_mask.device
         cm = combined_mask.detach().to("cpu", torch.int64).contiguous()
@@ -269,8 +269,16 @@ class TrainTopology:
         self.inner_src = table(_capi.TOPO_INNER_SRC, self.A)
         self.inner_tgt = table(_capi.TOPO_INNER_TGT, self.A)
         self.node_group = self.node_sample * cfg.n_obj + self.node_obj
-        sp = table(_capi.TOPO_SAMPLE_PTR, self.B + 1)
-        self.deg = ((sp[1:] - sp[:-1])[self.node_sample] - 1).clamp(min=1)
+        if edge_index is not None:       # the kernels assume the complete-per-sample graph in the reference's edge order: verify
+            ei = edge_index.detach()
+            if ei.dim() != 2 or ei.shape[0] != 2 or ei.dtype != torch.int64 or ei.device != dev:
+                raise _capi.OardError("edge_index must be an int64 [2, E] tensor on the same device")
+            ei = ei.contiguous()
+            ok = torch.zeros(1, dtype=torch.int32, device=dev)
+            _capi.check(L.oard_topology_check_edge_index(h, ei.data_ptr(), ei.shape[1], ok.data_ptr(), stream),
+                        "oard_topology_check_edge_index")
+            if int(ok.item()) != 1:
+                raise _capi.OardError("edge_index is not get_edges_index(combined_mask, remove_self_edge=True)")
 
     def __del__(self):
         try:
