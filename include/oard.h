@@ -11,6 +11,10 @@
  * synchronises the stream or the device except oard_topology_create (host work + uploads);
  * all `*_dev` pointers are device pointers on the current HIP device; float tensors are
  * contiguous row-major fp32; the library never touches torch.
+ * Threading: one host thread per process drives the library (one process per GPU is the deployment model:
+ * torch.distributed / RCCL).  The debug options, the timing facility and the per-call-site launch attributes are
+ * process-global and not thread-safe; the launch attributes are tracked per device, so a process may move between
+ * devices, but concurrent calls from several threads are not supported.
  */
 #ifndef OARD_H
 #define OARD_H
