@@ -93,6 +93,65 @@ OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook ho
     if (MT & 1) acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]);
 }
 
+// ---- the same chains, software-pipelined ACROSS consecutive chains of one phase ---------------------------------------
+// Left alone, every chain opens with two exposed LDS round trips (bias + first pair of A fragments, then the second pair:
+// ~2 x 130 cycles per 52-MFMA tile, observed in the ISA).  Here the fragments of the NEXT chain's first two chunks (and its
+// bias chunk) are requested while the current chain's last MFMAs issue and handed over in `ChainPf`.
+struct ChainPf { f4 a0, a1, bias; };
+OARD_DEV void chain_open(ChainPf& cp, const float* sl, int jbias, int j0) {       // after the phase barrier: exposed once per phase
+    if (jbias >= 0) cp.bias = lds_a(sl, jbias);
+    cp.a0 = lds_a(sl, j0);
+    cp.a1 = lds_a(sl, j0 + 1);
+}
+// one output tile; chunks j0 .. j0+KB-1 (the first two already in cp); init = cp.bias if USE_BIAS else `init`.
+// nb / n0: slots of the next chain's bias chunk / first chunk (n0 < 0: none)
+template <int KB, bool USE_BIAS, class Hook>
+OARD_DEV f4 chain_tile_pf(const float* sl, int j0, const f4 (&in)[KB], f4 init, ChainPf& cp, int nb, int n0, Hook hook) {
+    f4 c0 = USE_BIAS ? cp.bias : init, c1 = f4zero();
+    f4 a0 = cp.a0, a1 = cp.a1;
+#pragma unroll
+    for (int b = 0; b + 1 < KB; b += 2) {
+        f4 x0 = a0, x1 = a1;
+        if (b + 2 < KB) x0 = lds_a(sl, j0 + b + 2);
+        if (b + 3 < KB) x1 = lds_a(sl, j0 + b + 3);
+        if (b + 3 >= KB && n0 >= 0) {                       // last pair: the reads that would be idle open the next chain
+            if (nb >= 0) cp.bias = lds_a(sl, nb);
+            if (!(KB & 1)) { cp.a0 = lds_a(sl, n0); cp.a1 = lds_a(sl, n0 + 1); }
+        }
+        mma_pair(a0, in[b], c0, a1, in[b + 1], c1);
+        hook();
+        a0 = x0; a1 = x1;
+    }
+    if (KB & 1) {
+        if (n0 >= 0) { cp.a0 = lds_a(sl, n0); cp.a1 = lds_a(sl, n0 + 1); }
+        // the odd chunk's four MFMAs alternate between the two accumulators (no back-to-back dependency)
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, in[KB - 1].x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, in[KB - 1].y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, in[KB - 1].z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, in[KB - 1].w, c1, 0, 0, 0);
+    }
+    return c0 + c1;
+}
+// K-outer: acc[t] += chunk(j0 + t) x x; the first two chunks in cp; n0: first chunk of the next group (or < 0)
+template <int MT, class Hook>
+OARD_DEV void chain_kouter_pf(const float* sl, int j0, f4 x, f4 (&acc)[MT], ChainPf& cp, int n0, Hook hook) {
+    f4 a0 = cp.a0, a1 = cp.a1;
+#pragma unroll
+    for (int t = 0; t + 1 < MT; t += 2) {
+        f4 x0 = a0, x1 = a1;
+        if (t + 2 < MT) x0 = lds_a(sl, j0 + t + 2);
+        if (t + 3 < MT) x1 = lds_a(sl, j0 + t + 3);
+        if (t + 3 >= MT && !(MT & 1) && n0 >= 0) { cp.a0 = lds_a(sl, n0); cp.a1 = lds_a(sl, n0 + 1); }
+        mma_pair(a0, x, acc[t], a1, x, acc[t + 1]);
+        hook();
+        a0 = x0; a1 = x1;
+    }
+    if (MT & 1) {
+        if (n0 >= 0) { cp.a0 = lds_a(sl, n0); cp.a1 = lds_a(sl, n0 + 1); }
+        acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]);
+    }
+}
+
 // The LDS-DMA prefetcher shared by the streamed kernels: the pieces of the NEXT phase's slab are issued one at
 // a time between MFMA pairs (every third pair), staggered between the two waves that share a SIMD - one
 // global_load_lds costs the issuing wave ~100-180 cycles, a burst after the barrier would stall the chain.
@@ -160,7 +219,9 @@ struct GclTape {
 //   DMA issue cost); it needs a third wave slot on one SIMD, i.e. the kernel held to 168 registers (MINW = 3).
 // PF2: the edge-state blocks are fetched TWO phases ahead and the phase barrier waits with a counted vmcnt, so an HBM round trip
 //   (several microseconds under load) has two phases to complete instead of one (GP <= 2, inference only).
-template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2, bool LOADER = false, bool PF2 = false>
+// CHAIN: the LDS -> MFMA chains are pipelined across the groups of a phase (chain_*_pf).
+template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2, bool LOADER = false, bool PF2 = false,
+          bool CHAIN = false>
 __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                                const float* __restrict__ P, const float* __restrict__ Q,
                                                                const float* __restrict__ u0, const float* __restrict__ c0,
@@ -243,9 +304,18 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
                 if (b < WB) xn[gg] = ld_edge(erow + 16 * b);
             }
         }
+        if (CHAIN) {
+            ChainPf cp;
+            chain_open(cp, SL(p), -1, 0);
 #pragma unroll
-        for (int gg = 0; gg < GP; ++gg)
-            if (p1 * GP + gg < WB) chain_kouter<HT>(SL(p), gg * G1, x[gg], h1, hook);
+            for (int gg = 0; gg < GP; ++gg)
+                if (p1 * GP + gg < WB)
+                    chain_kouter_pf<HT>(SL(p), gg * G1, x[gg], h1, cp, (gg + 1 < GP && p1 * GP + gg + 1 < WB) ? (gg + 1) * G1 : -1, hook);
+        } else {
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg)
+                if (p1 * GP + gg < WB) chain_kouter<HT>(SL(p), gg * G1, x[gg], h1, hook);
+        }
         pf.flush();
         if (PF2) {                                             // blocks of phase p1 + 2, issued after this phase's last DMA piece
             __builtin_amdgcn_sched_barrier(0);
@@ -277,13 +347,22 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
             for (int gg = 0; gg < GP; ++gg)
                 on[gg] = gg < WB ? (DO_S1 ? ld_edge(erow + 16 * gg) : ld_f4(c0 + 16 * gg + 4 * g)) : f4zero();
         }
+        ChainPf cp2;
+        if (CHAIN) chain_open(cp2, SL(p), 0, 1);
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
             const int tg = p2 * GP + gg;            // compile-time after unrolling
             if (tg < S::NG2) {
-                const f4 bias = A(p, gg * G2);
-                const f4 acc = tg < HT ? chain_tile<HT>(SL(p), gg * G2 + 1, h1, bias, hook)
-                                       : chain_tile<HT>(SL(p), gg * G2 + 1, m, bias, hook);
+                const bool more = gg + 1 < GP && tg + 1 < S::NG2;
+                f4 acc;
+                if (CHAIN) {
+                    acc = tg < HT ? chain_tile_pf<HT, true>(SL(p), gg * G2 + 1, h1, f4zero(), cp2, more ? (gg + 1) * G2 : -1, more ? (gg + 1) * G2 + 1 : -1, hook)
+                                  : chain_tile_pf<HT, true>(SL(p), gg * G2 + 1, m, f4zero(), cp2, more ? (gg + 1) * G2 : -1, more ? (gg + 1) * G2 + 1 : -1, hook);
+                } else {
+                    const f4 bias = A(p, gg * G2);
+                    acc = tg < HT ? chain_tile<HT>(SL(p), gg * G2 + 1, h1, bias, hook)
+                                  : chain_tile<HT>(SL(p), gg * G2 + 1, m, bias, hook);
+                }
                 if (tg < HT) {
                     if (TRAIN) st_blk(tape.z2, e, D::HP, tg, lane, acc);
                     m[tg] = silu4(acc);
@@ -336,11 +415,16 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
                     on[gg] = DO_S1 ? ld_edge(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
             }
         }
+        ChainPf cp3;
+        if (CHAIN) chain_open(cp3, SL(p), 0, 1);
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
             const int t = p3 * GP + gg;
             if (t < WB) {
-                const f4 z = chain_tile<HT>(SL(p), gg * G2 + 1, m, A(p, gg * G2), hook);
+                const bool more = gg + 1 < GP && t + 1 < WB;
+                const f4 z = CHAIN ? chain_tile_pf<HT, true>(SL(p), gg * G2 + 1, m, f4zero(), cp3, more ? (gg + 1) * G2 : -1,
+                                                            more ? (gg + 1) * G2 + 1 : -1, hook)
+                                   : chain_tile<HT>(SL(p), gg * G2 + 1, m, A(p, gg * G2), hook);
                 if (TRAIN) pendz[gg] = z;
                 pend[gg] = o[gg] + silu4(z);
             }

@@ -278,6 +278,10 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
                               (GclStream<D, 1>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
         case 13: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, false, 3, true>), cdiv(r1 - r0, 16 * 8), 9 * 64,
                               (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
+        case 16: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, false, 2, false, false, true>), cdiv(r1 - r0, 16 * 8), 8 * 64,
+                              (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
+        case 17: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 4, S1, S3, false, 2, false, false, true>), cdiv(r1 - r0, 16 * 8), 8 * 64,
+                              (GclStream<D, 4>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
         case 15: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, false, 2, false, true>), cdiv(r1 - r0, 16 * 8), 8 * 64,
                               (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
         case 14: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 11, 2, S1, S3, false, 3, true>), cdiv(r1 - r0, 16 * 11), 12 * 64,
