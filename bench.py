@@ -174,13 +174,15 @@ def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
     out = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "batch_per_gpu": B, "loss": info["loss"],
            "grad_norm": info.get("grad_norm"), "trainable_parameters": int(tr.flat_grad.numel()),
            "all_reduce_bytes": int(tr.flat_grad.numel() * 4) if world > 1 else 0, "seconds": dt}
+    # two more steps with per-family kernel timing on rank 0; EVERY rank runs them (each step holds a collective)
+    L_ = _capi.lib()
     if timing:
-        L_ = _capi.lib()
         L_.oard_timing_reset()
         L_.oard_timing_enable(1)
-        for i in range(2):
-            tr.training_step(batches[i % 2])
-        torch.cuda.synchronize(dev)
+    for i in range(2):
+        tr.training_step(batches[i % 2])
+    torch.cuda.synchronize(dev)
+    if timing:
         L_.oard_timing_enable(0)
         E, A = edge_counts(B, nf)
         fam = {}
@@ -291,7 +293,7 @@ def main():
     ts = [torch.full((B, 1), (T - s) / T, device=dev) for s in range(8)]
 
     if args.mode == "train":
-        leg, dt = train_leg(dyn, B, nf, dev, dist, world, args.steps, args.warmup, timing=(rank == 0))
+        leg, dt = train_leg(dyn, B, nf, dev, dist, world, args.steps, args.warmup, timing=(rank == 0))       # collective inside: all ranks
         if dist is not None:
             tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
