@@ -40,6 +40,24 @@ OARD_DEV void phase_barrier_keep(int n) {
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Experiment build only (-DOARD_PHASE_PROBE): where the waves of k_gcl_edge_v1 spend their cycles - the s_waitcnt in front of
+// the phase barrier (own DMA pieces / loads / stores not landed), the barrier itself (waiting for the other waves), the issue of
+// one LDS-DMA piece.  Sums over all waves in g_phase_probe (oard_debug_probe_read).
+#ifdef OARD_PHASE_PROBE
+__device__ unsigned long long g_phase_probe[8];
+#define PROBE_DECL long long pr_t0_ = clock64(), pr_wait_ = 0, pr_bar_ = 0, pr_n_ = 0;
+#define PHASE_BARRIER() do { const long long a_ = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long b_ = clock64(); \
+        __syncthreads(); const long long c_ = clock64(); pr_wait_ += b_ - a_; pr_bar_ += c_ - b_; ++pr_n_; } while (0)
+#define PROBE_END(pf) do { if ((threadIdx.x & 63) == 0) { atomicAdd(&g_phase_probe[0], 1ull); atomicAdd(&g_phase_probe[1], (unsigned long long)(clock64() - pr_t0_)); \
+        atomicAdd(&g_phase_probe[2], (unsigned long long)pr_wait_); atomicAdd(&g_phase_probe[3], (unsigned long long)pr_bar_); \
+        atomicAdd(&g_phase_probe[4], (unsigned long long)(pf).dma_cyc); atomicAdd(&g_phase_probe[5], (unsigned long long)(pf).dma_n); \
+        atomicAdd(&g_phase_probe[6], (unsigned long long)pr_n_); } } while (0)
+#else
+#define PROBE_DECL
+#define PHASE_BARRIER() phase_barrier()
+#define PROBE_END(pf) do {} while (0)
+#endif
+
 // two (a, b, acc) triples interleaved: consecutive MFMAs never depend on each other
 // (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency)
 OARD_DEV void mma_pair(f4 a0, f4 b0, f4& c0, f4 a1, f4 b1, f4& c1) {
@@ -161,6 +179,9 @@ struct SlabPrefetch {
     const float* src;
     float* dst;
     int n, k, next, wave;
+#ifdef OARD_PHASE_PROBE
+    long long dma_cyc = 0, dma_n = 0;
+#endif
     OARD_DEV void begin(const float* stream_lane, float* smem, int phase, int first_chunk, int n_chunks) {
         src = stream_lane + (size_t)first_chunk * 256;
         dst = smem + (size_t)(phase & 1) * SLAB * 256;
@@ -168,7 +189,11 @@ struct SlabPrefetch {
     }
     OARD_DEV void one() {
         const int j = wave + k * WAVES;
+#ifdef OARD_PHASE_PROBE
+        if (j < n) { const long long a_ = clock64(); glds16(src + (size_t)j * 256, dst + j * 256); dma_cyc += clock64() - a_; ++dma_n; }
+#else
         if (j < n) glds16(src + (size_t)j * 256, dst + j * 256);
+#endif
         ++k;
     }
     OARD_DEV void tick() { if (--next == 0) { one(); next = 3; } }
@@ -233,6 +258,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
 
+    PROBE_DECL
     SlabPrefetch<LOADER ? 1 : WAVES, S::SLAB> pf;
     pf.wave = LOADER ? 0 : wave;
     const float* stream_lane = stream + lane * 4;
@@ -289,7 +315,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     f4 xnn[GP];
     int kept = 0;                                              // loads issued after the last DMA piece of the previous phase
     for (int p1 = 0; DO_S1 && p1 < S::NP1; ++p1, ++p) {
-        if (PF2) phase_barrier_keep(kept); else phase_barrier();
+        if (PF2) phase_barrier_keep(kept); else PHASE_BARRIER();
         f4 x[GP];
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) x[gg] = xn[gg];
@@ -340,7 +366,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     f4 on[GP];
 #pragma unroll
     for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
-        phase_barrier();
+        PHASE_BARRIER();
         pf_begin(p + 1);
         if (DO_S3 && p2 == S::NP2 - 1) {            // prefetch the old edge-state tiles of S3's first phase
 #pragma unroll
@@ -383,13 +409,14 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     if (!DO_S3) {
 #pragma unroll
         for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e], D::HP, t, lane, m[t]);
+        PROBE_END(pf);
         return;
     }
     f4 pend[GP], pendz[TRAIN ? GP : 1];
     f4 onn[GP];
     kept = 0;
     for (int p3 = 0; p3 < S::NP3; ++p3, ++p) {
-        if (PF2) phase_barrier_keep(kept); else phase_barrier();
+        if (PF2) phase_barrier_keep(kept); else PHASE_BARRIER();
         if (p3 == 0) {
 #pragma unroll
             for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e], D::HP, t, lane, m[t]);
@@ -449,6 +476,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
             if (TRAIN) st_f4(tape.z3 + e * D::WP + 4 * g + 16 * t, pendz[gg]);
         }
     }
+    PROBE_END(pf);
 }
 
 // =====================================================================================================

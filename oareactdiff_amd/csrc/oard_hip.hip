@@ -1326,6 +1326,17 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "npb") == 0) { g_npb = value; return OARD_OK; }
     return OARD_EINVAL;
 }
+#ifdef OARD_PHASE_PROBE
+// experiment build: read (and clear) the cycle sums of the GCL phase probe (oard_edge_v1.h); not declared in include/oard.h
+int oard_debug_probe_read(unsigned long long* out8) {
+    if (!out8) return OARD_EINVAL;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase_probe), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_probe), z, sizeof(z)));
+    return OARD_OK;
+}
+#endif
 int oard_timing_enable(int on) { g_timing.on = on != 0; return OARD_OK; }
 int oard_timing_reset(void) {
     g_timing.flush();
