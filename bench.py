@@ -409,7 +409,7 @@ def main():
     # the real sampling loop (row N1): a genuine ancestral sampling run of T steps (T+1 network calls + fused sampler
     # kernel + RNG), timed end to end: the BASELINE metric's reactions/s, MEASURED (T = 1000 unless --quick)
     sampler_leg = train = None
-    if rank == 0:
+    if rank == 0 and not os.environ.get("OARD_BENCH_ALLOW_NAN"):
         from oareactdiff_amd.sampler import DiffusionSampler
         frag = [torch.full((B,), nf, dtype=torch.long) for _ in range(3)]
         h0 = [x[:, 3:].clone() for x in inputs[0]]

@@ -15,8 +15,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // one 1-KiB chunk: per-lane global source, wave-uniform LDS destination (+ lane*16 by hardware)
+// timing-only ablations of an experiment build (results are garbage): OARD_ABL_NODMA_INSTR drops the LDS-DMA instruction and keeps
+// the issue logic around it; OARD_ABL_BURST issues a phase's pieces right after the barrier instead of between MFMA pairs
 OARD_DEV void glds16(const float* gsrc_lane, float* lds_chunk) {
+#ifndef OARD_ABL_NODMA_INSTR
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc_lane, (lds_ptr_t)lds_chunk, 16, 0, 0);
+#else
+    asm volatile("" :: "v"(gsrc_lane), "s"(lds_chunk));
+#endif
 }
 
 // Phase barrier: every LDS-DMA piece this wave issued must have landed before any wave reads the slab.
@@ -25,7 +31,9 @@ OARD_DEV void glds16(const float* gsrc_lane, float* lds_chunk) {
 // is stated explicitly.
 OARD_DEV void phase_barrier() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef OARD_ABL_NOBARRIER   // timing-only ablation (experiment build)
     __syncthreads();
+#endif
 }
 
 // Counted form: the `n` most recent vector-memory operations of this wave may stay in flight across the barrier (they are the
@@ -51,11 +59,29 @@ __device__ unsigned long long g_phase_probe[8];
 #define PROBE_END(pf) do { if ((threadIdx.x & 63) == 0) { atomicAdd(&g_phase_probe[0], 1ull); atomicAdd(&g_phase_probe[1], (unsigned long long)(clock64() - pr_t0_)); \
         atomicAdd(&g_phase_probe[2], (unsigned long long)pr_wait_); atomicAdd(&g_phase_probe[3], (unsigned long long)pr_bar_); \
         atomicAdd(&g_phase_probe[4], (unsigned long long)(pf).dma_cyc); atomicAdd(&g_phase_probe[5], (unsigned long long)(pf).dma_n); \
-        atomicAdd(&g_phase_probe[6], (unsigned long long)pr_n_); } } while (0)
+        atomicAdd(&g_phase_probe[6], (unsigned long long)pr_n_); if ((threadIdx.x >> 6) < (blockDim.x >> 7)) atomicAdd(&g_phase_probe[7], (unsigned long long)pr_bar_); } } while (0)
 #else
 #define PROBE_DECL
 #define PHASE_BARRIER() phase_barrier()
 #define PROBE_END(pf) do {} while (0)
+#endif
+
+#ifdef OARD_PRIO_BALANCE
+__device__ int g_prio_k;
+#endif
+
+// experiment build (-DOARD_TIMELINE): timestamps of one workgroup's waves at the phase barriers and around every MFMA chain
+// (tools/timeline.py): code 1 = after the phase barrier, 2 = chain starts, 3 = chain done, 4 = phase work done
+#ifdef OARD_TIMELINE
+#define TL_MAX 1024
+__device__ long long g_timeline[16][TL_MAX];
+#define TL_DECL const bool tl_on_ = DO_S1 && DO_S3 && blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0; int tl_n_ = 0;
+#define TL(code) do { if (tl_on_ && tl_n_ < TL_MAX) g_timeline[threadIdx.x >> 6][tl_n_++] = (clock64() << 3) | (code); } while (0)
+#define TL_END() do { if (tl_on_ && tl_n_ < TL_MAX) g_timeline[threadIdx.x >> 6][tl_n_] = 0; } while (0)
+#else
+#define TL_DECL
+#define TL(code) do {} while (0)
+#define TL_END() do {} while (0)
 #endif
 
 // two (a, b, acc) triples interleaved: consecutive MFMAs never depend on each other
@@ -77,8 +103,42 @@ OARD_DEV void mma_pair(f4 a0, f4 b0, f4& c0, f4 a1, f4 b1, f4& c1) {
 // so the ds_read latency (~100+ cycles) is covered.
 OARD_DEV f4 lds_a(const float* sl, int j) { return *reinterpret_cast<const f4*>(sl + j * 256); }
 
+// -DOARD_LDS_EARLY (experiment): the A fragments are requested by inline-asm ds_read_b128 one pair of chunks ahead and awaited with
+// a counted lgkmcnt.  (Left to hipcc, the reads sink behind the 7th MFMA of the pair that precedes their use - the fragment
+// registers are reused - so only one MFMA covers the LDS round trip; sched_barrier does not help, the IR sinks the loads first.)
+// LDS operations return in order, so "at most n outstanding" guarantees everything but the n most recent has landed, whatever
+// else the compiler has in flight; the "+v" ties make every later use depend on the wait.
+#ifdef OARD_LDS_EARLY
+OARD_DEV unsigned lds_addr(const float* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
+OARD_DEV f4 lds_issue(unsigned a) { f4 r; asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(a)); return r; }
+template <int N> OARD_DEV void lds_wait(f4& a0, f4& a1) {
+    if (N >= 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0), "+v"(a1));
+    else if (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a0), "+v"(a1));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
+}
+#endif
 // M-outer: one output tile = sum over KB chunks (slots j0..j0+KB-1) x in[b]; even/odd accumulators
 struct NoHook { OARD_DEV void operator()() const {} };
+#ifdef OARD_LDS_EARLY
+template <int KB, class Hook = NoHook>
+OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hook hook = Hook()) {
+    const unsigned base = lds_addr(sl) + j0 * 1024;
+    f4 c0 = init, c1 = f4zero();
+    f4 a0 = lds_issue(base), a1 = KB > 1 ? lds_issue(base + 1024) : a0;
+#pragma unroll
+    for (int b = 0; b + 1 < KB; b += 2) {
+        f4 n0 = a0, n1 = a1;
+        if (b + 2 < KB) n0 = lds_issue(base + (b + 2) * 1024);
+        if (b + 3 < KB) n1 = lds_issue(base + (b + 3) * 1024);
+        if (b + 3 < KB) lds_wait<2>(a0, a1); else if (b + 2 < KB) lds_wait<1>(a0, a1); else lds_wait<0>(a0, a1);
+        mma_pair(a0, in[b], c0, a1, in[b + 1], c1);
+        hook();
+        a0 = n0; a1 = n1;
+    }
+    if (KB & 1) { lds_wait<0>(a0, a1); c0 = mma_chunk(a0, in[KB - 1], c0); }
+    return c0 + c1;
+}
+#else
 template <int KB, class Hook = NoHook>
 OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hook hook = Hook()) {
     f4 c0 = init, c1 = f4zero();
@@ -95,7 +155,26 @@ OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hoo
     if (KB & 1) c0 = mma_chunk(a0, in[KB - 1], c0);
     return c0 + c1;
 }
+#endif
 // K-outer: acc[t] += chunk(j0 + t) x x for t < MT, pairs of tiles interleaved
+#ifdef OARD_LDS_EARLY
+template <int MT, class Hook = NoHook>
+OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook hook = Hook()) {
+    const unsigned base = lds_addr(sl) + j0 * 1024;
+    f4 a0 = lds_issue(base), a1 = MT > 1 ? lds_issue(base + 1024) : a0;
+#pragma unroll
+    for (int t = 0; t + 1 < MT; t += 2) {
+        f4 n0 = a0, n1 = a1;
+        if (t + 2 < MT) n0 = lds_issue(base + (t + 2) * 1024);
+        if (t + 3 < MT) n1 = lds_issue(base + (t + 3) * 1024);
+        if (t + 3 < MT) lds_wait<2>(a0, a1); else if (t + 2 < MT) lds_wait<1>(a0, a1); else lds_wait<0>(a0, a1);
+        mma_pair(a0, x, acc[t], a1, x, acc[t + 1]);
+        hook();
+        a0 = n0; a1 = n1;
+    }
+    if (MT & 1) { lds_wait<0>(a0, a1); acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]); }
+}
+#else
 template <int MT, class Hook = NoHook>
 OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook hook = Hook()) {
     f4 a0 = lds_a(sl, j0), a1 = MT > 1 ? lds_a(sl, j0 + 1) : f4zero();
@@ -111,6 +190,7 @@ OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook ho
     if (MT & 1) acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]);
 }
 
+#endif
 // ---- the same chains, software-pipelined ACROSS consecutive chains of one phase ---------------------------------------
 // Left alone, every chain opens with two exposed LDS round trips (bias + first pair of A fragments, then the second pair:
 // ~2 x 130 cycles per 52-MFMA tile, observed in the ISA).  Here the fragments of the NEXT chain's first two chunks (and its
@@ -170,12 +250,22 @@ OARD_DEV void chain_kouter_pf(const float* sl, int j0, f4 x, f4 (&acc)[MT], Chai
     }
 }
 
-// The LDS-DMA prefetcher shared by the streamed kernels: the pieces of the NEXT phase's slab are issued one at
-// a time between MFMA pairs (every third pair), staggered between the two waves that share a SIMD - one
-// global_load_lds costs the issuing wave ~100-180 cycles, a burst after the barrier would stall the chain.
+// The LDS-DMA prefetcher shared by the streamed kernels: the pieces of the NEXT phase's slab are issued one at a time between
+// MFMA pairs (a burst after the barrier stalls the chains: +7 % GCL, +37 % Equi time).  In an 8-wave workgroup only waves 0..3
+// issue (OARD_PF_HALF), one piece after every pair (OARD_PF_PERIOD): the SIMD arbiter favours the older wave of a pair, so waves
+// 4..7 are the critical path of every phase (probe build: 93 % of the barrier wait is spent by waves 0..3) - they should neither
+// pay the issue cost nor reach the barrier with a piece still in flight.  Measured (profiles/round2_gcl_phase_study.txt): all
+// waves / every third pair 9.82 ms, waves 0..3 / every pair 9.63 ms, waves 0..3 / every second pair 10.07 ms per step.
+#ifndef OARD_PF_HALF
+#define OARD_PF_HALF 1
+#endif
+#ifndef OARD_PF_PERIOD
+#define OARD_PF_PERIOD 1
+#endif
 template <int WAVES, int SLAB>
 struct SlabPrefetch {
-    static constexpr int KMAX = (SLAB + WAVES - 1) / WAVES;    // pieces per wave per phase (upper bound)
+    static constexpr int IW = (OARD_PF_HALF && WAVES >= 8) ? WAVES / 2 : WAVES;       // issuing waves
+    static constexpr int KMAX = (SLAB + IW - 1) / IW;          // pieces per issuing wave per phase (upper bound)
     const float* src;
     float* dst;
     int n, k, next, wave;
@@ -185,10 +275,14 @@ struct SlabPrefetch {
     OARD_DEV void begin(const float* stream_lane, float* smem, int phase, int first_chunk, int n_chunks) {
         src = stream_lane + (size_t)first_chunk * 256;
         dst = smem + (size_t)(phase & 1) * SLAB * 256;
-        n = n_chunks; k = 0; next = 1 + (wave >= WAVES / 2 ? 1 : 0);
+        n = wave < IW ? n_chunks : 0; k = 0; next = 1 + ((IW == WAVES && wave >= WAVES / 2) ? 1 : 0);
     }
     OARD_DEV void one() {
-        const int j = wave + k * WAVES;
+#ifdef OARD_ABL_NOHOOK       // timing-only ablation (experiment build): no LDS-DMA, no issue logic
+        k = KMAX;
+        return;
+#endif
+        const int j = wave + k * IW;
 #ifdef OARD_PHASE_PROBE
         if (j < n) { const long long a_ = clock64(); glds16(src + (size_t)j * 256, dst + j * 256); dma_cyc += clock64() - a_; ++dma_n; }
 #else
@@ -196,7 +290,15 @@ struct SlabPrefetch {
 #endif
         ++k;
     }
-    OARD_DEV void tick() { if (--next == 0) { one(); next = 3; } }
+#ifdef OARD_ABL_BURST
+    OARD_DEV void tick() {}
+#else
+#ifdef OARD_ABL_NOHOOK
+    OARD_DEV void tick() {}
+#else
+    OARD_DEV void tick() { if (--next == 0) { one(); next = OARD_PF_PERIOD; } }
+#endif
+#endif
     OARD_DEV void flush() { while (k < KMAX) one(); }
 };
 
@@ -259,6 +361,14 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
 
     PROBE_DECL
+    TL_DECL
+    TL(0);
+#ifdef OARD_PRIO_BALANCE
+    // experiment: the SIMD arbiter favours the older wave of a pair (probe: 93 % of the barrier wait is spent by waves 0..3), so the
+    // younger one runs the first prio_k MFMA pairs of every phase at raised priority
+    const int prio_k = __builtin_amdgcn_readfirstlane(g_prio_k);
+    int prio_left = -1;
+#endif
     SlabPrefetch<LOADER ? 1 : WAVES, S::SLAB> pf;
     pf.wave = LOADER ? 0 : wave;
     const float* stream_lane = stream + lane * 4;
@@ -269,8 +379,18 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
         else if (p < S::NP1 + S::NP2) { const int q = p - S::NP1; start = S::C1 + q * GP * G2; n = min(GP, S::NG2 - q * GP) * G2; }
         else if (p < S::NPH && DO_S3) { const int q = p - S::NP1 - S::NP2; start = S::C1 + S::C2 + q * GP * G2; n = min(GP, WB - q * GP) * G2; }
         pf.begin(stream_lane, smem, p, start, n);
+#ifdef OARD_ABL_BURST
+        pf.flush();
+#endif
+#ifdef OARD_PRIO_BALANCE
+        if (wave >= WAVES / 2) { __builtin_amdgcn_s_setprio(1); prio_left = prio_k; }
+#endif
     };
+#ifdef OARD_PRIO_BALANCE
+    auto hook = [&]() { if (!LOADER) pf.tick(); if (--prio_left == 0) __builtin_amdgcn_s_setprio(0); };
+#else
     auto hook = [&]() { if (!LOADER) pf.tick(); };
+#endif
     if (LOADER && wave == WAVES) {                             // the loader wave: one phase ahead of the compute waves
         int p = DO_S1 ? 0 : S::NP1;
         const int p_end = DO_S3 ? S::NPH : S::NP1 + S::NP2;
@@ -296,6 +416,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     const float* erow = ew_in + e * D::WP + 4 * g;
     float* orow = ew_out + e * D::WP + 4 * g;
     f4 h1[HT];
+    const size_t eid = (size_t)tp.row_eid[e];                  // row of the message buffer (loaded here: its latency must not sit in S3)
     {
         const int src = tp.row_src[e], tgt = tp.row_tgt[e];
 #pragma unroll
@@ -316,6 +437,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     int kept = 0;                                              // loads issued after the last DMA piece of the previous phase
     for (int p1 = 0; DO_S1 && p1 < S::NP1; ++p1, ++p) {
         if (PF2) phase_barrier_keep(kept); else PHASE_BARRIER();
+        TL(1);
         f4 x[GP];
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) x[gg] = xn[gg];
@@ -340,8 +462,9 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
         } else {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg)
-                if (p1 * GP + gg < WB) chain_kouter<HT>(SL(p), gg * G1, x[gg], h1, hook);
+                if (p1 * GP + gg < WB) { TL(2); chain_kouter<HT>(SL(p), gg * G1, x[gg], h1, hook); TL(3); }
         }
+        TL(4);
         pf.flush();
         if (PF2) {                                             // blocks of phase p1 + 2, issued after this phase's last DMA piece
             __builtin_amdgcn_sched_barrier(0);
@@ -367,6 +490,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
 #pragma unroll
     for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
         PHASE_BARRIER();
+        TL(1);
         pf_begin(p + 1);
         if (DO_S3 && p2 == S::NP2 - 1) {            // prefetch the old edge-state tiles of S3's first phase
 #pragma unroll
@@ -386,8 +510,10 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
                                   : chain_tile_pf<HT, true>(SL(p), gg * G2 + 1, m, f4zero(), cp2, more ? (gg + 1) * G2 : -1, more ? (gg + 1) * G2 + 1 : -1, hook);
                 } else {
                     const f4 bias = A(p, gg * G2);
+                    TL(2);
                     acc = tg < HT ? chain_tile<HT>(SL(p), gg * G2 + 1, h1, bias, hook)
                                   : chain_tile<HT>(SL(p), gg * G2 + 1, m, bias, hook);
+                    TL(3);
                 }
                 if (tg < HT) {
                     if (TRAIN) st_blk(tape.z2, e, D::HP, tg, lane, acc);
@@ -401,6 +527,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
                 }
             }
         }
+        TL(4);
         pf.flush();
     }
     // ---- S3: ew += SiLU(W3 m + b3), one output tile per group ----------------------------------------
@@ -408,8 +535,9 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     // never waits for a store that was issued a few cycles earlier
     if (!DO_S3) {
 #pragma unroll
-        for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e], D::HP, t, lane, m[t]);
+        for (int t = 0; t < HT; ++t) st_blk(mbuf, eid, D::HP, t, lane, m[t]);
         PROBE_END(pf);
+        TL_END();
         return;
     }
     f4 pend[GP], pendz[TRAIN ? GP : 1];
@@ -417,9 +545,10 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     kept = 0;
     for (int p3 = 0; p3 < S::NP3; ++p3, ++p) {
         if (PF2) phase_barrier_keep(kept); else PHASE_BARRIER();
+        TL(1);
         if (p3 == 0) {
 #pragma unroll
-            for (int t = 0; t < HT; ++t) st_blk(mbuf, (size_t)tp.row_eid[e], D::HP, t, lane, m[t]);
+            for (int t = 0; t < HT; ++t) st_blk(mbuf, eid, D::HP, t, lane, m[t]);
         } else {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {                  // (p3-1)*GP+gg < WB always
@@ -449,13 +578,16 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
             const int t = p3 * GP + gg;
             if (t < WB) {
                 const bool more = gg + 1 < GP && t + 1 < WB;
+                TL(2);
                 const f4 z = CHAIN ? chain_tile_pf<HT, true>(SL(p), gg * G2 + 1, m, f4zero(), cp3, more ? (gg + 1) * G2 : -1,
                                                             more ? (gg + 1) * G2 + 1 : -1, hook)
                                    : chain_tile<HT>(SL(p), gg * G2 + 1, m, A(p, gg * G2), hook);
+                TL(3);
                 if (TRAIN) pendz[gg] = z;
                 pend[gg] = o[gg] + silu4(z);
             }
         }
+        TL(4);
         pf.flush();
         if (PF2) {                                             // old-state tiles of phase p3 + 2, after this phase's last DMA piece
             __builtin_amdgcn_sched_barrier(0);
@@ -477,6 +609,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
         }
     }
     PROBE_END(pf);
+    TL_END();
 }
 
 // =====================================================================================================

@@ -53,7 +53,12 @@ OARD_DEV void st_blk(float* __restrict__ base, size_t row, int ld, int b, int la
     *reinterpret_cast<f4*>(base + row * (size_t)ld + 16 * b + 4 * (lane >> 4)) = v;
 }
 
+#ifdef OARD_ABL_NOEPI        // timing-only ablation (experiment build)
+OARD_DEV float silu1(float x) { return x; }
+OARD_DEV float silu1_real(float x) {
+#else
 OARD_DEV float silu1(float x) {
+#endif
     // x * sigmoid(x);  v_exp_f32 + v_rcp_f32 (both <= 1 ulp)
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }

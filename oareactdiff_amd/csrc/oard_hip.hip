@@ -1324,6 +1324,9 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "auto_small") == 0) { g_auto_small = value; return OARD_OK; }
     if (strcmp(name, "auto_tiny") == 0) { g_auto_tiny = value; return OARD_OK; }
     if (strcmp(name, "npb") == 0) { g_npb = value; return OARD_OK; }
+#ifdef OARD_PRIO_BALANCE
+    if (strcmp(name, "prio_k") == 0) { HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prio_k), &value, sizeof(int))); return OARD_OK; }
+#endif
     return OARD_EINVAL;
 }
 #ifdef OARD_PHASE_PROBE
@@ -1334,6 +1337,14 @@ int oard_debug_probe_read(unsigned long long* out8) {
     HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase_probe), 8 * sizeof(unsigned long long)));
     unsigned long long z[8] = {};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_probe), z, sizeof(z)));
+    return OARD_OK;
+}
+#endif
+#ifdef OARD_TIMELINE
+int oard_debug_timeline_read(long long* out, int waves) {          // experiment build: [waves][TL_MAX] (oard_edge_v1.h)
+    if (!out || waves < 1 || waves > 16) return OARD_EINVAL;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)waves * TL_MAX * sizeof(long long)));
     return OARD_OK;
 }
 #endif

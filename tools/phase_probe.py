@@ -45,8 +45,9 @@ for _ in range(n):
 e1.record()
 torch.cuda.synchronize()
 assert L.oard_debug_probe_read(buf) == 0
-waves, total, wait, bar, dcyc, dn, nph = [int(x) for x in buf[:7]]
+waves, total, wait, bar, dcyc, dn, nph, bar_lo = [int(x) for x in buf[:8]]
 print(f"B={B} parts={parts} sequential={seq} gcl_variant={variant}: {e0.elapsed_time(e1) / n:.3f} ms/step (probe build)")
 print(f"  waves/step {waves / n:.0f}  phases/wave {nph / waves:.1f}  cycles/wave {total / waves:.0f}")
 print(f"  per phase: total {total / nph:.0f}  waitcnt {wait / nph:.0f} ({100 * wait / total:.1f} %)  barrier {bar / nph:.0f} ({100 * bar / total:.1f} %)")
+print(f"  barrier cycles spent by the lower half of the waves of a workgroup (wave < WAVES/2): {100 * bar_lo / max(bar, 1):.1f} %")
 print(f"  LDS-DMA: {dn / waves:.1f} pieces/wave, {dcyc / max(dn, 1):.0f} cycles per issue ({100 * dcyc / total:.1f} % of wave time)")
