@@ -36,18 +36,6 @@ OARD_DEV void phase_barrier() {
 #endif
 }
 
-// Counted form: the `n` most recent vector-memory operations of this wave may stay in flight across the barrier (they are the
-// edge-state loads for the phase AFTER the next one, issued after this phase's last DMA piece; vmcnt retires in issue order,
-// so everything older - every DMA piece, every store - has landed).
-// The barrier is issued from the same asm statement: __syncthreads() is also a workgroup-scope fence, for which hipcc drains
-// vmcnt to 0 whenever a global store is in flight - exactly the wait this form exists to avoid.  Nothing this kernel exchanges
-// between waves goes through global memory (only LDS: lgkmcnt(0) + the DMA's vmcnt), so the fence is not needed.
-OARD_DEV void phase_barrier_keep(int n) {
-    if (n >= 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // Experiment build only (-DOARD_PHASE_PROBE): where the waves of k_gcl_edge_v1 spend their cycles - the s_waitcnt in front of
 // the phase barrier (own DMA pieces / loads / stores not landed), the barrier itself (waiting for the other waves), the issue of
 // one LDS-DMA piece.  Sums over all waves in g_phase_probe (oard_debug_probe_read).
@@ -103,44 +91,14 @@ OARD_DEV void mma_pair(f4 a0, f4 b0, f4& c0, f4 a1, f4 b1, f4& c1) {
 // so the ds_read latency (~100+ cycles) is covered.
 OARD_DEV f4 lds_a(const float* sl, int j) { return *reinterpret_cast<const f4*>(sl + j * 256); }
 
-// -DOARD_LDS_EARLY (experiment): the A fragments are requested by inline-asm ds_read_b128 one pair of chunks ahead and awaited with
-// a counted lgkmcnt.  (Left to hipcc, the reads sink behind the 7th MFMA of the pair that precedes their use - the fragment
-// registers are reused - so only one MFMA covers the LDS round trip; sched_barrier does not help, the IR sinks the loads first.)
-// LDS operations return in order, so "at most n outstanding" guarantees everything but the n most recent has landed, whatever
-// else the compiler has in flight; the "+v" ties make every later use depend on the wait.
-#ifdef OARD_LDS_EARLY
-OARD_DEV unsigned lds_addr(const float* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
-OARD_DEV f4 lds_issue(unsigned a) { f4 r; asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(a)); return r; }
-template <int N> OARD_DEV void lds_wait(f4& a0, f4& a1) {
-    if (N >= 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0), "+v"(a1));
-    else if (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a0), "+v"(a1));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
-}
-#endif
-// M-outer: one output tile = sum over KB chunks (slots j0..j0+KB-1) x in[b]; even/odd accumulators
+// (An inline-asm variant that pins the ds_read_b128 of the next pair in front of the current pair's MFMAs - hipcc sinks them behind
+// the 7th MFMA to reuse the fragment registers - was measured in round 2: no change, profiles/round2_gcl_phase_study.txt.)
+// M-outer: one output tile = sum over KB chunks (slots j0..j0+KB-1) x in[b]; even/odd accumulators.
+// TAIL (KB odd): the last chunk is a compact K tail - one k-step, A fragment in component x, B operand `tail` (see k_gcl_edge_v1).
 struct NoHook { OARD_DEV void operator()() const {} };
-#ifdef OARD_LDS_EARLY
-template <int KB, class Hook = NoHook>
-OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hook hook = Hook()) {
-    const unsigned base = lds_addr(sl) + j0 * 1024;
-    f4 c0 = init, c1 = f4zero();
-    f4 a0 = lds_issue(base), a1 = KB > 1 ? lds_issue(base + 1024) : a0;
-#pragma unroll
-    for (int b = 0; b + 1 < KB; b += 2) {
-        f4 n0 = a0, n1 = a1;
-        if (b + 2 < KB) n0 = lds_issue(base + (b + 2) * 1024);
-        if (b + 3 < KB) n1 = lds_issue(base + (b + 3) * 1024);
-        if (b + 3 < KB) lds_wait<2>(a0, a1); else if (b + 2 < KB) lds_wait<1>(a0, a1); else lds_wait<0>(a0, a1);
-        mma_pair(a0, in[b], c0, a1, in[b + 1], c1);
-        hook();
-        a0 = n0; a1 = n1;
-    }
-    if (KB & 1) { lds_wait<0>(a0, a1); c0 = mma_chunk(a0, in[KB - 1], c0); }
-    return c0 + c1;
-}
-#else
-template <int KB, class Hook = NoHook>
-OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hook hook = Hook()) {
+template <int KB, bool TAIL, class Hook>
+OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, float tail, Hook hook) {
+    static_assert(!TAIL || (KB & 1), "compact tail needs an odd number of chunks");
     f4 c0 = init, c1 = f4zero();
     f4 a0 = lds_a(sl, j0), a1 = KB > 1 ? lds_a(sl, j0 + 1) : f4zero();
 #pragma unroll
@@ -152,29 +110,17 @@ OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hoo
         hook();
         a0 = n0; a1 = n1;
     }
-    if (KB & 1) c0 = mma_chunk(a0, in[KB - 1], c0);
+    if (KB & 1) {
+        if (TAIL) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, tail, c0, 0, 0, 0);
+        else c0 = mma_chunk(a0, in[KB - 1], c0);
+    }
     return c0 + c1;
 }
-#endif
-// K-outer: acc[t] += chunk(j0 + t) x x for t < MT, pairs of tiles interleaved
-#ifdef OARD_LDS_EARLY
-template <int MT, class Hook = NoHook>
-OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook hook = Hook()) {
-    const unsigned base = lds_addr(sl) + j0 * 1024;
-    f4 a0 = lds_issue(base), a1 = MT > 1 ? lds_issue(base + 1024) : a0;
-#pragma unroll
-    for (int t = 0; t + 1 < MT; t += 2) {
-        f4 n0 = a0, n1 = a1;
-        if (t + 2 < MT) n0 = lds_issue(base + (t + 2) * 1024);
-        if (t + 3 < MT) n1 = lds_issue(base + (t + 3) * 1024);
-        if (t + 3 < MT) lds_wait<2>(a0, a1); else if (t + 2 < MT) lds_wait<1>(a0, a1); else lds_wait<0>(a0, a1);
-        mma_pair(a0, x, acc[t], a1, x, acc[t + 1]);
-        hook();
-        a0 = n0; a1 = n1;
-    }
-    if (MT & 1) { lds_wait<0>(a0, a1); acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]); }
+template <int KB, class Hook = NoHook>
+OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hook hook = Hook()) {
+    return chain_tile<KB, false, Hook>(sl, j0, in, init, 0.f, hook);
 }
-#else
+// K-outer: acc[t] += chunk(j0 + t) x x for t < MT, pairs of tiles interleaved
 template <int MT, class Hook = NoHook>
 OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook hook = Hook()) {
     f4 a0 = lds_a(sl, j0), a1 = MT > 1 ? lds_a(sl, j0 + 1) : f4zero();
@@ -188,66 +134,6 @@ OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook ho
         a0 = n0; a1 = n1;
     }
     if (MT & 1) acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]);
-}
-
-#endif
-// ---- the same chains, software-pipelined ACROSS consecutive chains of one phase ---------------------------------------
-// Left alone, every chain opens with two exposed LDS round trips (bias + first pair of A fragments, then the second pair:
-// ~2 x 130 cycles per 52-MFMA tile, observed in the ISA).  Here the fragments of the NEXT chain's first two chunks (and its
-// bias chunk) are requested while the current chain's last MFMAs issue and handed over in `ChainPf`.
-struct ChainPf { f4 a0, a1, bias; };
-OARD_DEV void chain_open(ChainPf& cp, const float* sl, int jbias, int j0) {       // after the phase barrier: exposed once per phase
-    if (jbias >= 0) cp.bias = lds_a(sl, jbias);
-    cp.a0 = lds_a(sl, j0);
-    cp.a1 = lds_a(sl, j0 + 1);
-}
-// one output tile; chunks j0 .. j0+KB-1 (the first two already in cp); init = cp.bias if USE_BIAS else `init`.
-// nb / n0: slots of the next chain's bias chunk / first chunk (n0 < 0: none)
-template <int KB, bool USE_BIAS, class Hook>
-OARD_DEV f4 chain_tile_pf(const float* sl, int j0, const f4 (&in)[KB], f4 init, ChainPf& cp, int nb, int n0, Hook hook) {
-    f4 c0 = USE_BIAS ? cp.bias : init, c1 = f4zero();
-    f4 a0 = cp.a0, a1 = cp.a1;
-#pragma unroll
-    for (int b = 0; b + 1 < KB; b += 2) {
-        f4 x0 = a0, x1 = a1;
-        if (b + 2 < KB) x0 = lds_a(sl, j0 + b + 2);
-        if (b + 3 < KB) x1 = lds_a(sl, j0 + b + 3);
-        if (b + 3 >= KB && n0 >= 0) {                       // last pair: the reads that would be idle open the next chain
-            if (nb >= 0) cp.bias = lds_a(sl, nb);
-            if (!(KB & 1)) { cp.a0 = lds_a(sl, n0); cp.a1 = lds_a(sl, n0 + 1); }
-        }
-        mma_pair(a0, in[b], c0, a1, in[b + 1], c1);
-        hook();
-        a0 = x0; a1 = x1;
-    }
-    if (KB & 1) {
-        if (n0 >= 0) { cp.a0 = lds_a(sl, n0); cp.a1 = lds_a(sl, n0 + 1); }
-        // the odd chunk's four MFMAs alternate between the two accumulators (no back-to-back dependency)
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, in[KB - 1].x, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, in[KB - 1].y, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, in[KB - 1].z, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, in[KB - 1].w, c1, 0, 0, 0);
-    }
-    return c0 + c1;
-}
-// K-outer: acc[t] += chunk(j0 + t) x x; the first two chunks in cp; n0: first chunk of the next group (or < 0)
-template <int MT, class Hook>
-OARD_DEV void chain_kouter_pf(const float* sl, int j0, f4 x, f4 (&acc)[MT], ChainPf& cp, int n0, Hook hook) {
-    f4 a0 = cp.a0, a1 = cp.a1;
-#pragma unroll
-    for (int t = 0; t + 1 < MT; t += 2) {
-        f4 x0 = a0, x1 = a1;
-        if (t + 2 < MT) x0 = lds_a(sl, j0 + t + 2);
-        if (t + 3 < MT) x1 = lds_a(sl, j0 + t + 3);
-        if (t + 3 >= MT && !(MT & 1) && n0 >= 0) { cp.a0 = lds_a(sl, n0); cp.a1 = lds_a(sl, n0 + 1); }
-        mma_pair(a0, x, acc[t], a1, x, acc[t + 1]);
-        hook();
-        a0 = x0; a1 = x1;
-    }
-    if (MT & 1) {
-        if (n0 >= 0) { cp.a0 = lds_a(sl, n0); cp.a1 = lds_a(sl, n0 + 1); }
-        acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]);
-    }
 }
 
 // The LDS-DMA prefetcher shared by the streamed kernels: the pieces of the NEXT phase's slab are issued one at a time between
@@ -317,6 +203,7 @@ OARD_DEV f4 ld_edge(const float* p) { return ld_f4(p); }
 template <class D, int GP>
 struct GclStream {
     static constexpr int HT = D::HT, WB = D::WB, G1 = HT, G2 = HT + 1, NG2 = HT + 1;
+    static constexpr bool TAIL1 = (D::H % 16) >= 1 && (D::H % 16) <= 4 && HT >= 3 && (HT & 1);      // compact K tail (see the kernel)
     static constexpr int SLAB = GP * G2;                       // chunks per slab
     static constexpr int NP1 = (WB + GP - 1) / GP, NP2 = (NG2 + GP - 1) / GP, NP3 = NP1, NPH = NP1 + NP2 + NP3;
     static constexpr int C1 = WB * G1, C2 = NG2 * G2, C3 = WB * G2, CHUNKS = C1 + C2 + C3;
@@ -342,14 +229,18 @@ struct GclTape {
 // TRAIN: the new state goes to `ew_out` (a different buffer: the backward pass needs every layer's input state)
 //   and the pre-activations are stored (GclTape).  In inference ew_out == ew_in (in-place update).
 // Columns are the physical rows [r0, r1).
-// LOADER: a (WAVES+1)-th wave does nothing but issue the LDS-DMA of the next phase's slab (the compute waves then carry no
-//   DMA issue cost); it needs a third wave slot on one SIMD, i.e. the kernel held to 168 registers (MINW = 3).
-// PF2: the edge-state blocks are fetched TWO phases ahead and the phase barrier waits with a counted vmcnt, so an HBM round trip
-//   (several microseconds under load) has two phases to complete instead of one (GP <= 2, inference only).
-// CHAIN: the LDS -> MFMA chains are pipelined across the groups of a phase (chain_*_pf).
-template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2, bool LOADER = false, bool PF2 = false,
-          bool CHAIN = false>
-__global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
+// Compact K tail (GclStream::TAIL1, H % 16 in 1..4, e.g. H = 196): the last 16-feature block of h1 / m holds at most 4 real
+//   features, which the block layout spreads over all four k-steps (one per step, lanes g = 0).  tail_compact() gathers them into
+//   ONE k-step (lane (g, e) <- component g of lane (0, e)), the stream carries the matching A fragment in component x of the
+//   last chunk of every W2 / watt / W3 tile (k_pack_matrix, tail_compact), and the chains end with 1 MFMA instead of 4:
+//   49 instead of 52 MFMAs per tile of S2 and S3 (-3.3 % of the kernel's MFMAs).
+OARD_DEV float tail_compact(f4 v, int lane) {
+    const int e = lane & 15, g = lane >> 4;
+    const float t0 = __shfl(v.x, e, 64), t1 = __shfl(v.y, e, 64), t2 = __shfl(v.z, e, 64), t3 = __shfl(v.w, e, 64);
+    return g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3));
+}
+template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                                const float* __restrict__ P, const float* __restrict__ Q,
                                                                const float* __restrict__ u0, const float* __restrict__ c0,
                                                                long long r0, long long r1, const float* ew_in, float* ew_out,
@@ -357,9 +248,9 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = GclStream<D, GP>;
     constexpr int HT = D::HT, WB = D::WB, G1 = S::G1, G2 = S::G2;
+    constexpr bool TAIL1 = S::TAIL1;
     const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
-
     PROBE_DECL
     TL_DECL
     TL(0);
@@ -369,11 +260,10 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     const int prio_k = __builtin_amdgcn_readfirstlane(g_prio_k);
     int prio_left = -1;
 #endif
-    SlabPrefetch<LOADER ? 1 : WAVES, S::SLAB> pf;
-    pf.wave = LOADER ? 0 : wave;
+    SlabPrefetch<WAVES, S::SLAB> pf;
+    pf.wave = wave;
     const float* stream_lane = stream + lane * 4;
     auto pf_begin = [&](int p) {                               // p = phase to prefetch
-        if (LOADER && wave != WAVES) return;                   // compute waves of a loader build never issue DMA
         int start = 0, n = 0;
         if (p < S::NP1) { start = p * GP * G1; n = min(GP, WB - p * GP) * G1; }
         else if (p < S::NP1 + S::NP2) { const int q = p - S::NP1; start = S::C1 + q * GP * G2; n = min(GP, S::NG2 - q * GP) * G2; }
@@ -387,23 +277,10 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
 #endif
     };
 #ifdef OARD_PRIO_BALANCE
-    auto hook = [&]() { if (!LOADER) pf.tick(); if (--prio_left == 0) __builtin_amdgcn_s_setprio(0); };
+    auto hook = [&]() { pf.tick(); if (--prio_left == 0) __builtin_amdgcn_s_setprio(0); };
 #else
-    auto hook = [&]() { if (!LOADER) pf.tick(); };
+    auto hook = [&]() { pf.tick(); };
 #endif
-    if (LOADER && wave == WAVES) {                             // the loader wave: one phase ahead of the compute waves
-        int p = DO_S1 ? 0 : S::NP1;
-        const int p_end = DO_S3 ? S::NPH : S::NP1 + S::NP2;
-        pf_begin(p);
-        pf.flush();
-        for (; p < p_end; ++p) {
-            phase_barrier();
-            pf_begin(p + 1);
-            pf.flush();
-        }
-        return;
-    }
-    if (LOADER) { pf.n = 0; pf.k = SlabPrefetch<1, S::SLAB>::KMAX; pf.next = 1 << 30; }      // flush() is a no-op in compute waves
     auto A = [&](int p, int j) -> f4 {
         return *reinterpret_cast<const f4*>(smem + ((size_t)(p & 1) * S::SLAB + j) * 256 + lane * 4);
     };
@@ -433,49 +310,25 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     pf.flush();                                                // burst form (prologue only)
 
     // ---- S1: h1 += W1c . ew   (K-outer) -------------------------------------------------------------
-    f4 xnn[GP];
-    int kept = 0;                                              // loads issued after the last DMA piece of the previous phase
     for (int p1 = 0; DO_S1 && p1 < S::NP1; ++p1, ++p) {
-        if (PF2) phase_barrier_keep(kept); else PHASE_BARRIER();
+        PHASE_BARRIER();
         TL(1);
         f4 x[GP];
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) x[gg] = xn[gg];
         pf_begin(p + 1);
-        if (PF2 && p1 > 0) {
-#pragma unroll
-            for (int gg = 0; gg < GP; ++gg) xn[gg] = xnn[gg];
-        } else if (p1 + 1 < S::NP1) {
+        if (p1 + 1 < S::NP1) {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int b = (p1 + 1) * GP + gg;
                 if (b < WB) xn[gg] = ld_edge(erow + 16 * b);
             }
         }
-        if (CHAIN) {
-            ChainPf cp;
-            chain_open(cp, SL(p), -1, 0);
 #pragma unroll
-            for (int gg = 0; gg < GP; ++gg)
-                if (p1 * GP + gg < WB)
-                    chain_kouter_pf<HT>(SL(p), gg * G1, x[gg], h1, cp, (gg + 1 < GP && p1 * GP + gg + 1 < WB) ? (gg + 1) * G1 : -1, hook);
-        } else {
-#pragma unroll
-            for (int gg = 0; gg < GP; ++gg)
-                if (p1 * GP + gg < WB) { TL(2); chain_kouter<HT>(SL(p), gg * G1, x[gg], h1, hook); TL(3); }
-        }
+        for (int gg = 0; gg < GP; ++gg)
+            if (p1 * GP + gg < WB) { TL(2); chain_kouter<HT>(SL(p), gg * G1, x[gg], h1, hook); TL(3); }
         TL(4);
         pf.flush();
-        if (PF2) {                                             // blocks of phase p1 + 2, issued after this phase's last DMA piece
-            __builtin_amdgcn_sched_barrier(0);
-            kept = 0;
-#pragma unroll
-            for (int gg = 0; gg < GP; ++gg) {
-                const int b = (p1 + 2) * GP + gg;
-                if (b < WB) { xnn[gg] = ld_edge(erow + 16 * b); ++kept; }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
     }
     if (TRAIN) {
 #pragma unroll
@@ -483,10 +336,12 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
     }
 #pragma unroll
     for (int t = 0; t < HT; ++t) h1[t] = silu4(h1[t]);
+    const float h1_tail = TAIL1 ? tail_compact(h1[HT - 1], lane) : 0.f;
 
     // ---- S2: m = SiLU(W2 h1 + b2); gate = SiLU(watt . m + batt) (the gate is the last group, fed with m) ----
     f4 m[HT];
     f4 on[GP];
+    float m_tail = 0.f;
 #pragma unroll
     for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
         PHASE_BARRIER();
@@ -497,33 +352,26 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
             for (int gg = 0; gg < GP; ++gg)
                 on[gg] = gg < WB ? (DO_S1 ? ld_edge(erow + 16 * gg) : ld_f4(c0 + 16 * gg + 4 * g)) : f4zero();
         }
-        ChainPf cp2;
-        if (CHAIN) chain_open(cp2, SL(p), 0, 1);
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
             const int tg = p2 * GP + gg;            // compile-time after unrolling
             if (tg < S::NG2) {
-                const bool more = gg + 1 < GP && tg + 1 < S::NG2;
-                f4 acc;
-                if (CHAIN) {
-                    acc = tg < HT ? chain_tile_pf<HT, true>(SL(p), gg * G2 + 1, h1, f4zero(), cp2, more ? (gg + 1) * G2 : -1, more ? (gg + 1) * G2 + 1 : -1, hook)
-                                  : chain_tile_pf<HT, true>(SL(p), gg * G2 + 1, m, f4zero(), cp2, more ? (gg + 1) * G2 : -1, more ? (gg + 1) * G2 + 1 : -1, hook);
-                } else {
-                    const f4 bias = A(p, gg * G2);
-                    TL(2);
-                    acc = tg < HT ? chain_tile<HT>(SL(p), gg * G2 + 1, h1, bias, hook)
-                                  : chain_tile<HT>(SL(p), gg * G2 + 1, m, bias, hook);
-                    TL(3);
-                }
+                const f4 bias = A(p, gg * G2);
+                TL(2);
+                const f4 acc = tg < HT ? chain_tile<HT, TAIL1>(SL(p), gg * G2 + 1, h1, bias, h1_tail, hook)
+                                       : chain_tile<HT, TAIL1>(SL(p), gg * G2 + 1, m, bias, m_tail, hook);
+                TL(3);
                 if (tg < HT) {
                     if (TRAIN) st_blk(tape.z2, e, D::HP, tg, lane, acc);
                     m[tg] = silu4(acc);
+                    if (TAIL1 && tg == HT - 1) m_tail = tail_compact(m[HT - 1], lane);
                 } else {
                     const float a = __shfl(acc.x, lane & 15, 64);
                     if (TRAIN && g == 0) tape.att[e] = a;
                     const float gate = silu1(a);
 #pragma unroll
                     for (int t = 0; t < HT; ++t) m[t] *= gate;
+                    m_tail *= gate;
                 }
             }
         }
@@ -541,10 +389,8 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
         return;
     }
     f4 pend[GP], pendz[TRAIN ? GP : 1];
-    f4 onn[GP];
-    kept = 0;
     for (int p3 = 0; p3 < S::NP3; ++p3, ++p) {
-        if (PF2) phase_barrier_keep(kept); else PHASE_BARRIER();
+        PHASE_BARRIER();
         TL(1);
         if (p3 == 0) {
 #pragma unroll
@@ -560,10 +406,7 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) o[gg] = on[gg];
         pf_begin(p + 1);
-        if (PF2 && p3 > 0) {
-#pragma unroll
-            for (int gg = 0; gg < GP; ++gg) on[gg] = onn[gg];
-        } else if (p3 + 1 < S::NP3) {
+        if (p3 + 1 < S::NP3) {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int t = (p3 + 1) * GP + gg;
@@ -571,17 +414,12 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
                     on[gg] = DO_S1 ? ld_edge(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
             }
         }
-        ChainPf cp3;
-        if (CHAIN) chain_open(cp3, SL(p), 0, 1);
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
             const int t = p3 * GP + gg;
             if (t < WB) {
-                const bool more = gg + 1 < GP && t + 1 < WB;
                 TL(2);
-                const f4 z = CHAIN ? chain_tile_pf<HT, true>(SL(p), gg * G2 + 1, m, f4zero(), cp3, more ? (gg + 1) * G2 : -1,
-                                                            more ? (gg + 1) * G2 + 1 : -1, hook)
-                                   : chain_tile<HT>(SL(p), gg * G2 + 1, m, A(p, gg * G2), hook);
+                const f4 z = chain_tile<HT, TAIL1>(SL(p), gg * G2 + 1, m, A(p, gg * G2), m_tail, hook);
                 TL(3);
                 if (TRAIN) pendz[gg] = z;
                 pend[gg] = o[gg] + silu4(z);
@@ -589,16 +427,6 @@ __global__ __launch_bounds__((WAVES + (LOADER ? 1 : 0)) * 64, MINW) void k_gcl_e
         }
         TL(4);
         pf.flush();
-        if (PF2) {                                             // old-state tiles of phase p3 + 2, after this phase's last DMA piece
-            __builtin_amdgcn_sched_barrier(0);
-            kept = 0;
-#pragma unroll
-            for (int gg = 0; gg < GP; ++gg) {
-                const int t = (p3 + 2) * GP + gg;
-                if (t < WB) { onn[gg] = DO_S1 ? ld_edge(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g); ++kept; }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
     }
 #pragma unroll
     for (int gg = 0; gg < GP; ++gg) {

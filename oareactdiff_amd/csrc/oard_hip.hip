@@ -187,9 +187,9 @@ struct ParamIdx {
 struct Packer {
     const float* const* p; float* blob; hipStream_t st;
     void matrix(int src, int src_ld, int col_off, int msl, int msp, int ms, int ksl, int ksp, int ks, int MT, int KB,
-                size_t dst, size_t tstride = 0, size_t bstride = 256, int perm_ht = 0, int transpose = 0) {
+                size_t dst, size_t tstride = 0, size_t bstride = 256, int perm_ht = 0, int transpose = 0, int tail_compact = 0) {
         if (tstride == 0) tstride = (size_t)KB * 256;
-        PackJob j{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst, tstride, bstride, perm_ht, transpose};
+        PackJob j{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst, tstride, bstride, perm_ht, transpose, tail_compact};
         const size_t total = (size_t)MT * KB * 256;
         hipLaunchKernelGGL(k_pack_matrix, dim3((unsigned)std::min<size_t>(cdiv(total, 256), 4096)), dim3(256), 0, st, j, blob);
     }
@@ -276,16 +276,6 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
                               (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
         case 12: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 4, 1, S1, S3, false, 3>), cdiv(r1 - r0, 16 * 4), 4 * 64,
                               (GclStream<D, 1>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
-        case 13: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, false, 3, true>), cdiv(r1 - r0, 16 * 8), 9 * 64,
-                              (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
-        case 16: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, false, 2, false, false, true>), cdiv(r1 - r0, 16 * 8), 8 * 64,
-                              (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
-        case 17: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 4, S1, S3, false, 2, false, false, true>), cdiv(r1 - r0, 16 * 8), 8 * 64,
-                              (GclStream<D, 4>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
-        case 15: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, false, 2, false, true>), cdiv(r1 - r0, 16 * 8), 8 * 64,
-                              (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
-        case 14: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 11, 2, S1, S3, false, 3, true>), cdiv(r1 - r0, 16 * 11), 12 * 64,
-                              (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
 #endif
         default: return OARD_EINVAL;
     }
@@ -696,11 +686,13 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
             const size_t G2 = (size_t)(d.HT + 1) * 256;
             const size_t s1 = lo.gcl_stream, s2 = s1 + (size_t)d.WB * d.HT * 256, s3 = s2 + (size_t)(d.HT + 1) * G2;
             pk.matrix(g + 0, ld0, 2 * H, H, d.HP, 1, W, d.WP, 1, d.HT, d.WB, s1, 256, (size_t)d.HT * 256);      // W1c, K-outer
-            pk.matrix(g + 2, H, 0, H, d.HP, 1, H, d.HP, 1, d.HT, d.HT, s2 + 256, G2, 256);                       // W2 tiles
+            // compact K tail of the H-wide inputs of S2 / S3 (GclStream::TAIL1, the same condition): last chunk = one k-step
+            const int tc = (H % 16 >= 1 && H % 16 <= 4 && d.HT >= 3 && (d.HT & 1)) ? 1 : 0;
+            pk.matrix(g + 2, H, 0, H, d.HP, 1, H, d.HP, 1, d.HT, d.HT, s2 + 256, G2, 256, 0, 0, tc);             // W2 tiles
             pk.bias_chunks(g + 3, H, d.HP, 1, d.HT, s2, G2);
-            pk.matrix(g + 10, H, 0, 1, 16, 1, H, d.HP, 1, 1, d.HT, s2 + d.HT * G2 + 256, G2, 256);               // watt as a 1-row tile
+            pk.matrix(g + 10, H, 0, 1, 16, 1, H, d.HP, 1, 1, d.HT, s2 + d.HT * G2 + 256, G2, 256, 0, 0, tc);     // watt as a 1-row tile
             pk.bias_chunks(g + 11, 1, 16, 1, 1, s2 + d.HT * G2, G2);
-            pk.matrix(g + 8, H, 0, W, d.WP, 1, H, d.HP, 1, d.WB, d.HT, s3 + 256, G2, 256);                       // W3 tiles
+            pk.matrix(g + 8, H, 0, W, d.WP, 1, H, d.HP, 1, d.WB, d.HT, s3 + 256, G2, 256, 0, 0, tc);             // W3 tiles
             pk.bias_chunks(g + 9, W, d.WP, 1, d.WB, s3, G2);
             const size_t GE = (size_t)(1 + d.D1T + d.RB) * 256;
             const size_t t1 = lo.equi_stream, t2 = t1 + (size_t)d.WB * d.D1T * 256;

@@ -51,6 +51,8 @@ struct PackJob {
     int perm_ht;
     int transpose;                // 1: the chunk rows index the SOURCE columns and the chunk K index the source rows
                                   //    (packs W^T for the backward pass: dX = W^T dY); col_off applies to the row index
+    int tail_compact;             // 1: the last K block (b == KB-1, <= 4 real features) is packed as ONE k-step: component 0 of
+                                  //    lane (g, i) = W[row 16t+i][col 16b+g], components 1..3 = 0 (oard_edge_v1.h, compact K tail)
 };
 
 // matrix -> MFMA chunks: dst[((t*KB + b)*64 + lane)*4 + c] = W[row(16t + (lane&15))][col(16b + 4(lane>>4) + c)]
@@ -60,11 +62,12 @@ __global__ void k_pack_matrix(PackJob j, float* __restrict__ blob) {
         const int c = (int)(i & 3), lane = (int)((i >> 2) & 63);
         const size_t ch = i >> 8;
         const int b = (int)(ch % j.KB), t = (int)(ch / j.KB);
-        const int r = 16 * t + (lane & 15), k = 16 * b + 4 * (lane >> 4) + c;
+        const bool tail = j.tail_compact && b == j.KB - 1;
+        const int r = 16 * t + (lane & 15), k = tail ? 16 * b + (lane >> 4) : 16 * b + 4 * (lane >> 4) + c;
         const int rs = r / j.msect_pad, rw = r % j.msect_pad;
         const int ks = k / j.ksect_pad, kw = k % j.ksect_pad;
         float v = 0.f;
-        if (rs < j.msects && rw < j.msect_len && ks < j.ksects && kw < j.ksect_len)
+        if (rs < j.msects && rw < j.msect_len && ks < j.ksects && kw < j.ksect_len && !(tail && c != 0))
             v = j.transpose ? j.src[(size_t)(ks * j.ksect_len + kw) * j.src_ld + j.col_off + rs * j.msect_len + rw]
                             : j.src[(size_t)(rs * j.msect_len + rw) * j.src_ld + j.col_off + ks * j.ksect_len + kw];
         const int slot = j.perm_ht > 0 ? (t % j.perm_ht) * 3 + t / j.perm_ht : t;
