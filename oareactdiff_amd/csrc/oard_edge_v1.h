@@ -85,6 +85,31 @@ OARD_DEV void mma_pair(f4 a0, f4 b0, f4& c0, f4 a1, f4 b1, f4& c1) {
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, c1, 0, 0, 0);
 }
 
+// ---- 4-row output tiles on v_mfma_f32_4x4x1_16b_f32 ------------------------------------------------------------------------
+// A tile with at most 4 real output rows (the 13th tile of a 196-wide layer, the 1-row gate) wastes 3/4 of a 16x16x4 MFMA.  The
+// 4x4x1 instruction computes 16 independent 4x4 blocks (lane l: block l/4, A row = B column = l%4, D register = row; 2 passes,
+// measured 8.7-10.5 cycles, tools/micro/mfma4x4.hip).  With the column engine's layout, lane (g, e) = block (k-slice g, column
+// group e/4): component s of a B block feeds feature 16b+4g+s of column e, so ONE chunk (4 instructions) covers the 16 features
+// of a block for 4 output rows, each k-slice g accumulating its own partial sum; reduce_g() adds the four slices at the end.
+// The A chunk ("rows4" packing) holds W[row0 + e%4][16b+4g+s] in component s of lane (g, e).
+OARD_DEV void mma4_chunk(f4 a, f4 b, f4& c0, f4& c1) {
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, b.x, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, b.y, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, b.z, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, b.w, c1, 0, 0, 0);
+}
+OARD_DEV f4 reduce_g(f4 v) {            // sum over the four k-slices (lanes e, 16+e, 32+e, 48+e); every lane gets the total
+    f4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float x = v[c];
+        x += __shfl_xor(x, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        r[c] = x;
+    }
+    return r;
+}
+
 // ---- software-pipelined LDS -> MFMA chains ---------------------------------------------------------
 // `sl` = this lane's pointer into the current slab (slab base + lane*4); chunk j is at sl + j*256.
 // The A fragments of the NEXT pair of chunks are read from LDS while the current pair's 8 MFMAs issue,
@@ -120,9 +145,29 @@ template <int KB, class Hook = NoHook>
 OARD_DEV f4 chain_tile(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hook hook = Hook()) {
     return chain_tile<KB, false, Hook>(sl, j0, in, init, 0.f, hook);
 }
-// K-outer: acc[t] += chunk(j0 + t) x x for t < MT, pairs of tiles interleaved
-template <int MT, class Hook = NoHook>
-OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook hook = Hook()) {
+// the same tile on 4x4x1 MFMAs (all KB chunks in rows4 packing): returns the UNREDUCED per-k-slice sums (apply reduce_g)
+template <int KB, class Hook = NoHook>
+OARD_DEV f4 chain_tile4(const float* sl, int j0, const f4 (&in)[KB], f4 init, Hook hook = Hook()) {
+    f4 c0 = init, c1 = f4zero();
+    f4 a0 = lds_a(sl, j0), a1 = KB > 1 ? lds_a(sl, j0 + 1) : f4zero();
+#pragma unroll
+    for (int b = 0; b + 1 < KB; b += 2) {
+        f4 n0 = a0, n1 = a1;
+        if (b + 2 < KB) n0 = lds_a(sl, j0 + b + 2);
+        if (b + 3 < KB) n1 = lds_a(sl, j0 + b + 3);
+        mma4_chunk(a0, in[b], c0, c1);
+        mma4_chunk(a1, in[b + 1], c0, c1);
+        hook();
+        a0 = n0; a1 = n1;
+    }
+    if (KB & 1) mma4_chunk(a0, in[KB - 1], c0, c1);
+    return c0 + c1;
+}
+// K-outer: acc[t] += chunk(j0 + t) x x for t < MT, pairs of tiles interleaved.
+// ROWS4 (MT odd): the last tile has at most 4 real rows and runs on 4x4x1 MFMAs into acc[MT-1] / extra (unreduced k-slice sums)
+template <int MT, bool ROWS4, class Hook>
+OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], f4& extra, Hook hook) {
+    static_assert(!ROWS4 || (MT & 1), "the 4-row tile must be the odd one");
     f4 a0 = lds_a(sl, j0), a1 = MT > 1 ? lds_a(sl, j0 + 1) : f4zero();
 #pragma unroll
     for (int t = 0; t + 1 < MT; t += 2) {
@@ -133,7 +178,15 @@ OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook ho
         hook();
         a0 = n0; a1 = n1;
     }
-    if (MT & 1) acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]);
+    if (MT & 1) {
+        if (ROWS4) mma4_chunk(a0, x, acc[MT - 1], extra);
+        else acc[MT - 1] = mma_chunk(a0, x, acc[MT - 1]);
+    }
+}
+template <int MT, class Hook = NoHook>
+OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook hook = Hook()) {
+    f4 unused = f4zero();
+    chain_kouter<MT, false, Hook>(sl, j0, x, acc, unused, hook);
 }
 
 // The LDS-DMA prefetcher shared by the streamed kernels: the pieces of the NEXT phase's slab are issued one at a time between
@@ -204,6 +257,7 @@ template <class D, int GP>
 struct GclStream {
     static constexpr int HT = D::HT, WB = D::WB, G1 = HT, G2 = HT + 1, NG2 = HT + 1;
     static constexpr bool TAIL1 = (D::H % 16) >= 1 && (D::H % 16) <= 4 && HT >= 3 && (HT & 1);      // compact K tail (see the kernel)
+    static constexpr bool ROWS4 = TAIL1;                       // the 13th output tile of W1c / W2 and the gate on 4x4x1 MFMAs
     static constexpr int SLAB = GP * G2;                       // chunks per slab
     static constexpr int NP1 = (WB + GP - 1) / GP, NP2 = (NG2 + GP - 1) / GP, NP3 = NP1, NPH = NP1 + NP2 + NP3;
     static constexpr int C1 = WB * G1, C2 = NG2 * G2, C3 = WB * G2, CHUNKS = C1 + C2 + C3;
@@ -248,7 +302,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = GclStream<D, GP>;
     constexpr int HT = D::HT, WB = D::WB, G1 = S::G1, G2 = S::G2;
-    constexpr bool TAIL1 = S::TAIL1;
+    constexpr bool TAIL1 = S::TAIL1, ROWS4 = S::ROWS4;
     const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // provably wave-uniform
     PROBE_DECL
@@ -310,6 +364,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
     pf.flush();                                                // burst form (prologue only)
 
     // ---- S1: h1 += W1c . ew   (K-outer) -------------------------------------------------------------
+    f4 h1x = f4zero();                                         // ROWS4: second accumulator of the 4-row tile
     for (int p1 = 0; DO_S1 && p1 < S::NP1; ++p1, ++p) {
         PHASE_BARRIER();
         TL(1);
@@ -326,9 +381,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
         }
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg)
-            if (p1 * GP + gg < WB) { TL(2); chain_kouter<HT>(SL(p), gg * G1, x[gg], h1, hook); TL(3); }
+            if (p1 * GP + gg < WB) { TL(2); chain_kouter<HT, ROWS4>(SL(p), gg * G1, x[gg], h1, h1x, hook); TL(3); }
         TL(4);
         pf.flush();
+    }
+    if (ROWS4 && DO_S1) {                                      // k-slice sums of the 4-row tile -> block layout (real rows in lanes g = 0)
+        const f4 v = reduce_g(h1[HT - 1] + h1x);
+        h1[HT - 1] = g == 0 ? v : f4zero();
     }
     if (TRAIN) {
 #pragma unroll
@@ -358,15 +417,22 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
             if (tg < S::NG2) {
                 const f4 bias = A(p, gg * G2);
                 TL(2);
-                const f4 acc = tg < HT ? chain_tile<HT, TAIL1>(SL(p), gg * G2 + 1, h1, bias, h1_tail, hook)
-                                       : chain_tile<HT, TAIL1>(SL(p), gg * G2 + 1, m, bias, m_tail, hook);
+                f4 acc;
+                if (ROWS4 && tg >= HT - 1) {                   // 13th tile of W2 / the gate: 4 real rows on 4x4x1 MFMAs
+                    acc = reduce_g(tg < HT ? chain_tile4<HT>(SL(p), gg * G2 + 1, h1, bias, hook)
+                                           : chain_tile4<HT>(SL(p), gg * G2 + 1, m, bias, hook));
+                    if (tg < HT && g != 0) acc = f4zero();
+                } else {
+                    acc = tg < HT ? chain_tile<HT, TAIL1>(SL(p), gg * G2 + 1, h1, bias, h1_tail, hook)
+                                  : chain_tile<HT, TAIL1>(SL(p), gg * G2 + 1, m, bias, m_tail, hook);
+                }
                 TL(3);
                 if (tg < HT) {
                     if (TRAIN) st_blk(tape.z2, e, D::HP, tg, lane, acc);
                     m[tg] = silu4(acc);
                     if (TAIL1 && tg == HT - 1) m_tail = tail_compact(m[HT - 1], lane);
                 } else {
-                    const float a = __shfl(acc.x, lane & 15, 64);
+                    const float a = ROWS4 ? acc.x : __shfl(acc.x, lane & 15, 64);
                     if (TRAIN && g == 0) tape.att[e] = a;
                     const float gate = silu1(a);
 #pragma unroll
@@ -449,6 +515,7 @@ template <class D>
 struct EquiStream {
     static constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT;
     static constexpr int G1 = D1T, G2 = 1 + D1T + RB, NG2 = 3 * HT;
+    static constexpr bool ROWS4 = (D::H % 16) >= 1 && (D::H % 16) <= 4;      // 13th tile of every third in rows4 packing (mma4_chunk)
     static constexpr int SLAB = G2 > G1 ? G2 : G1;
     static constexpr int NPH = WB + NG2;
     static constexpr int C1 = WB * G1, CHUNKS = C1 + NG2 * G2;
@@ -522,10 +589,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
             if (TRAIN) st_f4(cdrow + pend_off, pendc);
         }
         pf_begin(p + 1);
-        const f4 cd = chain_tile<D1T>(SL(p), 1, d1, A(p, 0), hook);
-        const f4 cr = chain_tile<RB>(SL(p), 1 + D1T, rb, f4zero(), hook);
-        pf.flush();
         const int tt = i / 3, th = i - 3 * tt;
+        f4 cd, cr;
+        if (S::ROWS4 && tt == HT - 1) {                        // the 13th tile of every third: 4 real rows, 4x4x1 MFMAs
+            cd = reduce_g(chain_tile4<D1T>(SL(p), 1, d1, A(p, 0), hook));
+            cr = reduce_g(chain_tile4<RB>(SL(p), 1 + D1T, rb, f4zero(), hook));
+            if (g != 0) { cd = f4zero(); cr = f4zero(); }
+        } else {
+            cd = chain_tile<D1T>(SL(p), 1, d1, A(p, 0), hook);
+            cr = chain_tile<RB>(SL(p), 1 + D1T, rb, f4zero(), hook);
+        }
+        pf.flush();
         pend = cd * cr;
         if (TRAIN) pendc = cd;
         pend_off = th * D::HP + 16 * tt;

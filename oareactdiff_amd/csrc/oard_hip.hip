@@ -187,9 +187,10 @@ struct ParamIdx {
 struct Packer {
     const float* const* p; float* blob; hipStream_t st;
     void matrix(int src, int src_ld, int col_off, int msl, int msp, int ms, int ksl, int ksp, int ks, int MT, int KB,
-                size_t dst, size_t tstride = 0, size_t bstride = 256, int perm_ht = 0, int transpose = 0, int tail_compact = 0) {
+                size_t dst, size_t tstride = 0, size_t bstride = 256, int perm_ht = 0, int transpose = 0, int tail_compact = 0,
+                int rows4 = 0) {
         if (tstride == 0) tstride = (size_t)KB * 256;
-        PackJob j{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst, tstride, bstride, perm_ht, transpose, tail_compact};
+        PackJob j{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst, tstride, bstride, perm_ht, transpose, rows4, tail_compact};
         const size_t total = (size_t)MT * KB * 256;
         hipLaunchKernelGGL(k_pack_matrix, dim3((unsigned)std::min<size_t>(cdiv(total, 256), 4096)), dim3(256), 0, st, j, blob);
     }
@@ -685,20 +686,22 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
         {
             const size_t G2 = (size_t)(d.HT + 1) * 256;
             const size_t s1 = lo.gcl_stream, s2 = s1 + (size_t)d.WB * d.HT * 256, s3 = s2 + (size_t)(d.HT + 1) * G2;
-            pk.matrix(g + 0, ld0, 2 * H, H, d.HP, 1, W, d.WP, 1, d.HT, d.WB, s1, 256, (size_t)d.HT * 256);      // W1c, K-outer
-            // compact K tail of the H-wide inputs of S2 / S3 (GclStream::TAIL1, the same condition): last chunk = one k-step
+            // GclStream::TAIL1 / ROWS4 (the same condition): compact K tail of the H-wide inputs of S2 / S3, and the 13th output
+            // tile of W1c / W2 and the gate packed for the 4x4x1 MFMA
             const int tc = (H % 16 >= 1 && H % 16 <= 4 && d.HT >= 3 && (d.HT & 1)) ? 1 : 0;
-            pk.matrix(g + 2, H, 0, H, d.HP, 1, H, d.HP, 1, d.HT, d.HT, s2 + 256, G2, 256, 0, 0, tc);             // W2 tiles
+            pk.matrix(g + 0, ld0, 2 * H, H, d.HP, 1, W, d.WP, 1, d.HT, d.WB, s1, 256, (size_t)d.HT * 256, 0, 0, 0, tc * d.HT);   // W1c, K-outer
+            pk.matrix(g + 2, H, 0, H, d.HP, 1, H, d.HP, 1, d.HT, d.HT, s2 + 256, G2, 256, 0, 0, tc, tc * d.HT);  // W2 tiles
             pk.bias_chunks(g + 3, H, d.HP, 1, d.HT, s2, G2);
-            pk.matrix(g + 10, H, 0, 1, 16, 1, H, d.HP, 1, 1, d.HT, s2 + d.HT * G2 + 256, G2, 256, 0, 0, tc);     // watt as a 1-row tile
+            pk.matrix(g + 10, H, 0, 1, 16, 1, H, d.HP, 1, 1, d.HT, s2 + d.HT * G2 + 256, G2, 256, 0, 0, tc, tc); // watt as a 1-row tile
             pk.bias_chunks(g + 11, 1, 16, 1, 1, s2 + d.HT * G2, G2);
             pk.matrix(g + 8, H, 0, W, d.WP, 1, H, d.HP, 1, d.WB, d.HT, s3 + 256, G2, 256, 0, 0, tc);             // W3 tiles
             pk.bias_chunks(g + 9, W, d.WP, 1, d.WB, s3, G2);
             const size_t GE = (size_t)(1 + d.D1T + d.RB) * 256;
             const size_t t1 = lo.equi_stream, t2 = t1 + (size_t)d.WB * d.D1T * 256;
             pk.matrix(m + 0, W, 0, 3 * H, d.D1P, 1, W, d.WP, 1, d.D1T, d.WB, t1, 256, (size_t)d.D1T * 256);       // dir_proj.0, K-outer
-            pk.matrix(m + 2, 3 * H, 0, H, d.HP, 3, 3 * H, d.D1P, 1, 3 * d.HT, d.D1T, t2 + 256, GE, 256, d.HT);    // dir_proj.2 tiles
-            pk.matrix(m + 6, R, 0, H, d.HP, 3, R, d.RP, 1, 3 * d.HT, d.RB, t2 + (size_t)(1 + d.D1T) * 256, GE, 256, d.HT);
+            const int r4 = (H % 16 >= 1 && H % 16 <= 4) ? d.HT : 0;     // EquiStream::ROWS4: the 13th tile of every third
+            pk.matrix(m + 2, 3 * H, 0, H, d.HP, 3, 3 * H, d.D1P, 1, 3 * d.HT, d.D1T, t2 + 256, GE, 256, d.HT, 0, 0, r4);    // dir_proj.2 tiles
+            pk.matrix(m + 6, R, 0, H, d.HP, 3, R, d.RP, 1, 3 * d.HT, d.RB, t2 + (size_t)(1 + d.D1T) * 256, GE, 256, d.HT, 0, 0, r4);
             pk.bias_chunks(m + 3, H, d.HP, 3, 3 * d.HT, t2, GE, d.HT);
         }
     }

@@ -51,6 +51,8 @@ struct PackJob {
     int perm_ht;
     int transpose;                // 1: the chunk rows index the SOURCE columns and the chunk K index the source rows
                                   //    (packs W^T for the backward pass: dX = W^T dY); col_off applies to the row index
+    int rows4;                    // P > 0: every tile t with t % P == P-1 has <= 4 real rows and is packed for the 4x4x1 MFMA: lane (g, i)
+                                  //    holds row 16t + i%4 (oard_edge_v1.h, mma4_chunk); its last K block is never compacted
     int tail_compact;             // 1: the last K block (b == KB-1, <= 4 real features) is packed as ONE k-step: component 0 of
                                   //    lane (g, i) = W[row 16t+i][col 16b+g], components 1..3 = 0 (oard_edge_v1.h, compact K tail)
 };
@@ -62,8 +64,9 @@ __global__ void k_pack_matrix(PackJob j, float* __restrict__ blob) {
         const int c = (int)(i & 3), lane = (int)((i >> 2) & 63);
         const size_t ch = i >> 8;
         const int b = (int)(ch % j.KB), t = (int)(ch / j.KB);
-        const bool tail = j.tail_compact && b == j.KB - 1;
-        const int r = 16 * t + (lane & 15), k = tail ? 16 * b + (lane >> 4) : 16 * b + 4 * (lane >> 4) + c;
+        const bool r4 = j.rows4 > 0 && t % j.rows4 == j.rows4 - 1;
+        const bool tail = j.tail_compact && b == j.KB - 1 && !r4;
+        const int r = 16 * t + (r4 ? (lane & 3) : (lane & 15)), k = tail ? 16 * b + (lane >> 4) : 16 * b + 4 * (lane >> 4) + c;
         const int rs = r / j.msect_pad, rw = r % j.msect_pad;
         const int ks = k / j.ksect_pad, kw = k % j.ksect_pad;
         float v = 0.f;
