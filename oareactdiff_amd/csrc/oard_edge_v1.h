@@ -59,7 +59,7 @@ __device__ int g_prio_k;
 #endif
 
 // experiment build (-DOARD_TIMELINE): timestamps of one workgroup's waves at the phase barriers and around every MFMA chain
-// (tools/timeline.py): code 1 = after the phase barrier, 2 = chain starts, 3 = chain done, 4 = phase work done
+// (tools/wave_timeline.py): code 1 = after the phase barrier, 2 = chain starts, 3 = chain done, 4 = phase work done
 #ifdef OARD_TIMELINE
 #define TL_MAX 1024
 __device__ long long g_timeline[16][TL_MAX];

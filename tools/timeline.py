@@ -1,64 +1,65 @@
-"""Per-wave timeline of one k_gcl_edge_v1 workgroup in an experiment build (-DOARD_EXPERIMENTS -DOARD_TIMELINE):
-    OARD_LIB=.../liboard_tl.so python tools/timeline.py [out.npy]
-prints, per phase kind, when each wave passes the barrier / starts and ends its chains (cycles relative to the phase start)."""
-import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import numpy as np
-import torch
-from oareactdiff_amd import _capi
-from oareactdiff_amd.dynamics import EGNNDynamics
-from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
-from oareactdiff_amd.synthetic import make_inputs, make_topology
+"""Concurrency picture of the default (sub-batch-parallel) schedule from a rocprofv3 --kernel-trace rocpd
+database: for the steady-state forwards, how long k kernels were in flight at once, and per kernel family
+the in-flight time.  Usage: python tools/timeline.py <results.db> [n_forwards_to_skip]"""
+import re
+import sqlite3
+import sys
+from collections import defaultdict
 
-B = int(os.environ.get("PROBE_B", "64"))
-L = _capi.lib()
-for k, v in dict(parts=1, sequential=1).items():
-    assert L.oard_debug_option(k.encode(), v) == 0
-dev = torch.device("cuda:0")
-cfg = dict(PRODUCTION_LEFTNET_CONFIG)
-dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0, condition_nf=1, device=dev)
-dyn.load_state_dict(synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg), strict=True)
-dyn.nan_check = "async"
-cm, nfs, ei, masks = make_topology(B, 23)
-cm, nfs, ei = cm.to(dev), nfs.to(dev), ei.to(dev)
-inp = make_inputs(B, 23, masks, 1234, dev)
-cond = torch.zeros(B, 1, device=dev)
-t = torch.full((B, 1), 0.5, device=dev)
-for _ in range(3):
-    with torch.no_grad():
-        dyn(inp, ei, t, cond, nfs, cm)
-W, TL_MAX = 8, 1024
-buf = np.zeros((W, TL_MAX), dtype=np.int64)
-L.oard_debug_timeline_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
-assert L.oard_debug_timeline_read(buf.ctypes.data, W) == 0
-if len(sys.argv) > 1:
-    np.save(sys.argv[1], buf)
-ev = []
-for w in range(W):
-    n = int(np.argmax(buf[w] == 0)) if (buf[w] == 0).any() else TL_MAX
-    ev.append([(int(x) >> 3, int(x) & 7) for x in buf[w, :n]])
-t0 = min(e[0][0] for e in ev)
-print("events per wave:", [len(e) for e in ev], " kernel span (cycles):", max(e[-1][0] for e in ev) - t0)
-# split into phases at code 1
-phases = [[] for _ in range(W)]
-for w in range(W):
-    cur = None
-    for tt, c in ev[w]:
-        if c == 1:
-            cur = [tt]
-            phases[w].append(cur)
-        elif cur is not None:
-            cur.append(tt)
-for w in range(W):
-    print(f"wave {w}: entry -> first barrier exit {ev[w][1][0] - ev[w][0][0]} cycles; last event -> {ev[w][-1][0] - ev[w][0][0]} (code {ev[w][-1][1]})")
-nph = min(len(p) for p in phases)
-lens = [min(phases[w][ph + 1][0] for w in range(W)) - min(phases[w][ph][0] for w in range(W)) for ph in range(nph - 1)]
-print("phase lengths:", lens, "sum", sum(lens))
-print("phases:", nph)
-for ph in list(range(0, 4)) + list(range(22, 30)) + list(range(nph - 4, nph)):
-    base = min(phases[w][ph][0] for w in range(W))
-    nxt = min(phases[w][ph + 1][0] for w in range(W)) if ph + 1 < nph else None
-    print(f"phase {ph}: length {'' if nxt is None else nxt - base}")
-    for w in range(W):
-        print("   wave", w, " ".join(f"{x - base:6d}" for x in phases[w][ph]))
+
+def main():
+    c = sqlite3.connect(sys.argv[1])
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    cols = [r[1] for r in c.execute(f"pragma table_info({kd})")]
+    scols = [r[1] for r in c.execute(f"pragma table_info({ks})")]
+    namecol = "display_name" if "display_name" in scols else "kernel_name"
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    sel = f"s.{namecol}, d.start, d.end" + (f", d.{qcol}" if qcol else ", 0")
+    rows = list(c.execute(f"select {sel} from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"))
+    rows = [(re.sub(r"^void ", "", re.sub(r"[<(].*$", "", n)), a, b, q) for n, a, b, q in rows]
+    # forwards are delimited by k_prep launches (first kernel of a part); group by gaps between k_post and next k_prep
+    preps = [i for i, r in enumerate(rows) if r[0].startswith("k_prep")]
+    if not preps:
+        print("no k_prep found; columns:", cols)
+        return
+    t_first = rows[preps[len(preps) // 2]][1]     # second half = steady state
+    rows = [r for r in rows if r[1] >= t_first]
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    ev = []
+    for n, a, b, q in rows:
+        ev.append((a, 1, n))
+        ev.append((b, -1, n))
+    ev.sort()
+    hist = defaultdict(float)
+    fam_alone = defaultdict(float)
+    active = defaultdict(int)
+    k = 0
+    last = t0
+    for t, d, n in ev:
+        hist[k] += t - last
+        if k == 1:
+            for name, cnt in active.items():
+                if cnt:
+                    fam_alone[name] += t - last
+        last = t
+        k += d
+        active[n] += d
+    wall = (t1 - t0) / 1e6
+    print(f"window {wall:.3f} ms, {len(rows)} dispatches, queues: {sorted(set(r[3] for r in rows))}")
+    for kk in sorted(hist):
+        print(f"  {kk} kernels in flight: {hist[kk] / 1e6:8.3f} ms ({100 * hist[kk] / (t1 - t0):5.1f} %)")
+    print("time with exactly ONE kernel in flight, by kernel:")
+    for n, v in sorted(fam_alone.items(), key=lambda kv: -kv[1])[:12]:
+        print(f"  {n:40s} {v / 1e6:8.3f} ms")
+    agg = defaultdict(list)
+    for n, a, b, q in rows:
+        agg[n].append((b - a) / 1e3)
+    print("per kernel (under concurrency): calls, avg us, total ms")
+    for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:14]:
+        print(f"  {n:40s} {len(v):6d} {sum(v) / len(v):10.1f} {sum(v) / 1e3:10.3f}")
+
+
+if __name__ == "__main__":
+    main()
