@@ -67,13 +67,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
 
     SlabPrefetch<WAVES, S::SLAB> pf;
     pf.wave = wave;
-    const float* stream_lane = stream + lane * 4;
+    pf.lane_off = (unsigned)lane * 16u;              // LDS-DMA source = uniform chunk address (SGPR pair) + this 32-bit lane offset
     auto pf_begin = [&](int p) {
         int start = 0, n = 0;
         if (p < S::NP3) { start = p * GP * G; n = min(GP, WB - p * GP) * G; }
         else if (p < S::NP3 + S::NP2) { const int q = p - S::NP3; start = S::C3 + q * GP * G; n = min(GP, HT - q * GP) * G; }
         else if (p < S::NPH) { const int q = p - S::NP3 - S::NP2; start = S::C3 + S::C2 + q * GP * G; n = min(GP, WB - q * GP) * G; }
-        pf.begin(stream_lane, smem, p, start, n);
+        pf.begin(stream, smem, p, start, n);
     };
     auto hook = [&]() { pf.tick(); };
     auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_bwd(TopoDev tp, const 
 
     SlabPrefetch<WAVES, S::SLAB> pf;
     pf.wave = wave;
-    const float* stream_lane = stream + lane * 4;
-    auto pf_begin = [&](int p) { pf.begin(stream_lane, smem, p, p * G, p >= S::NPH ? 0 : G); };
+    pf.lane_off = (unsigned)lane * 16u;              // LDS-DMA source = uniform chunk address (SGPR pair) + this 32-bit lane offset
+    auto pf_begin = [&](int p) { pf.begin(stream, smem, p, p * G, p >= S::NPH ? 0 : G); };
     auto hook = [&]() { pf.tick(); };
     auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
 

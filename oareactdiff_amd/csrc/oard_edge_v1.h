@@ -17,6 +17,13 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // one 1-KiB chunk: per-lane global source, wave-uniform LDS destination (+ lane*16 by hardware)
 // timing-only ablations of an experiment build (results are garbage): OARD_ABL_NODMA_INSTR drops the LDS-DMA instruction and keeps
 // the issue logic around it; OARD_ABL_BURST issues a phase's pieces right after the barrier instead of between MFMA pairs
+// the same with the source given as a wave-uniform chunk address plus a 32-bit per-lane byte offset: hipcc selects the SGPR-base
+// form of the instruction and the address costs no VALU work (a v_lshl_add_u64 per piece otherwise - and every VALU instruction
+// takes ~6 cycles of the SIMD's MFMA issue time, tools/micro/mfma_valu.hip)
+OARD_DEV void glds16(const float* gsrc_lane, float* lds_chunk);
+OARD_DEV void glds16u(const float* chunk_uniform, unsigned lane_byte_off, float* lds_chunk) {
+    glds16(reinterpret_cast<const float*>(reinterpret_cast<const char*>(chunk_uniform) + lane_byte_off), lds_chunk);
+}
 OARD_DEV void glds16(const float* gsrc_lane, float* lds_chunk) {
 #ifndef OARD_ABL_NODMA_INSTR
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc_lane, (lds_ptr_t)lds_chunk, 16, 0, 0);
@@ -205,14 +212,15 @@ template <int WAVES, int SLAB>
 struct SlabPrefetch {
     static constexpr int IW = (OARD_PF_HALF && WAVES >= 8) ? WAVES / 2 : WAVES;       // issuing waves
     static constexpr int KMAX = (SLAB + IW - 1) / IW;          // pieces per issuing wave per phase (upper bound)
-    const float* src;
+    const float* src;       // wave-uniform
     float* dst;
+    unsigned lane_off;
     int n, k, next, wave;
 #ifdef OARD_PHASE_PROBE
     long long dma_cyc = 0, dma_n = 0;
 #endif
-    OARD_DEV void begin(const float* stream_lane, float* smem, int phase, int first_chunk, int n_chunks) {
-        src = stream_lane + (size_t)first_chunk * 256;
+    OARD_DEV void begin(const float* stream, float* smem, int phase, int first_chunk, int n_chunks) {
+        src = stream + (size_t)first_chunk * 256;
         dst = smem + (size_t)(phase & 1) * SLAB * 256;
         n = wave < IW ? n_chunks : 0; k = 0; next = 1 + ((IW == WAVES && wave >= WAVES / 2) ? 1 : 0);
     }
@@ -223,9 +231,9 @@ struct SlabPrefetch {
 #endif
         const int j = wave + k * IW;
 #ifdef OARD_PHASE_PROBE
-        if (j < n) { const long long a_ = clock64(); glds16(src + (size_t)j * 256, dst + j * 256); dma_cyc += clock64() - a_; ++dma_n; }
+        if (j < n) { const long long a_ = clock64(); glds16u(src + (size_t)j * 256, lane_off, dst + j * 256); dma_cyc += clock64() - a_; ++dma_n; }
 #else
-        if (j < n) glds16(src + (size_t)j * 256, dst + j * 256);
+        if (j < n) glds16u(src + (size_t)j * 256, lane_off, dst + j * 256);
 #endif
         ++k;
     }
@@ -316,13 +324,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
 #endif
     SlabPrefetch<WAVES, S::SLAB> pf;
     pf.wave = wave;
-    const float* stream_lane = stream + lane * 4;
+    pf.lane_off = (unsigned)lane * 16u;              // LDS-DMA source = uniform chunk address (SGPR pair) + this 32-bit lane offset
     auto pf_begin = [&](int p) {                               // p = phase to prefetch
         int start = 0, n = 0;
         if (p < S::NP1) { start = p * GP * G1; n = min(GP, WB - p * GP) * G1; }
         else if (p < S::NP1 + S::NP2) { const int q = p - S::NP1; start = S::C1 + q * GP * G2; n = min(GP, S::NG2 - q * GP) * G2; }
         else if (p < S::NPH && DO_S3) { const int q = p - S::NP1 - S::NP2; start = S::C1 + S::C2 + q * GP * G2; n = min(GP, WB - q * GP) * G2; }
-        pf.begin(stream_lane, smem, p, start, n);
+        pf.begin(stream, smem, p, start, n);
 #ifdef OARD_ABL_BURST
         pf.flush();
 #endif
@@ -365,18 +373,18 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
 
     // ---- S1: h1 += W1c . ew   (K-outer) -------------------------------------------------------------
     f4 h1x = f4zero();                                         // ROWS4: second accumulator of the 4-row tile
-    for (int p1 = 0; DO_S1 && p1 < S::NP1; ++p1, ++p) {
+    // The phase loops are unrolled by two with the prefetched edge-state blocks in ping-pong register sets: a single loop body
+    // needs a copy "current = next" per block and phase, and every VALU instruction costs MFMA issue time (tools/micro/mfma_valu.hip).
+    f4 xm[GP];
+    auto s1_phase = [&](int p1, const f4 (&x)[GP], f4 (&xnext)[GP]) {
         PHASE_BARRIER();
         TL(1);
-        f4 x[GP];
-#pragma unroll
-        for (int gg = 0; gg < GP; ++gg) x[gg] = xn[gg];
         pf_begin(p + 1);
         if (p1 + 1 < S::NP1) {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int b = (p1 + 1) * GP + gg;
-                if (b < WB) xn[gg] = ld_edge(erow + 16 * b);
+                if (b < WB) xnext[gg] = ld_edge(erow + 16 * b);
             }
         }
 #pragma unroll
@@ -384,6 +392,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
             if (p1 * GP + gg < WB) { TL(2); chain_kouter<HT, ROWS4>(SL(p), gg * G1, x[gg], h1, h1x, hook); TL(3); }
         TL(4);
         pf.flush();
+        ++p;
+    };
+    if (DO_S1) {
+        int p1 = 0;
+        for (; p1 + 1 < S::NP1; p1 += 2) { s1_phase(p1, xn, xm); s1_phase(p1 + 1, xm, xn); }
+        if (p1 < S::NP1) s1_phase(p1, xn, xm);
     }
     if (ROWS4 && DO_S1) {                                      // k-slice sums of the 4-row tile -> block layout (real rows in lanes g = 0)
         const f4 v = reduce_g(h1[HT - 1] + h1x);
@@ -455,7 +469,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
         return;
     }
     f4 pend[GP], pendz[TRAIN ? GP : 1];
-    for (int p3 = 0; p3 < S::NP3; ++p3, ++p) {
+    f4 om[GP];
+    auto s3_phase = [&](int p3, const f4 (&o)[GP], f4 (&onext)[GP]) {
         PHASE_BARRIER();
         TL(1);
         if (p3 == 0) {
@@ -468,16 +483,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
                 if (TRAIN) st_f4(tape.z3 + e * D::WP + 4 * g + 16 * ((p3 - 1) * GP + gg), pendz[gg]);
             }
         }
-        f4 o[GP];
-#pragma unroll
-        for (int gg = 0; gg < GP; ++gg) o[gg] = on[gg];
         pf_begin(p + 1);
         if (p3 + 1 < S::NP3) {
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int t = (p3 + 1) * GP + gg;
                 if (t < WB)      // !DO_S1: the old state of these rows IS the constant row (never materialised)
-                    on[gg] = DO_S1 ? ld_edge(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
+                    onext[gg] = DO_S1 ? ld_edge(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
             }
         }
 #pragma unroll
@@ -493,6 +505,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
         }
         TL(4);
         pf.flush();
+        ++p;
+    };
+    {
+        int p3 = 0;
+        for (; p3 + 1 < S::NP3; p3 += 2) { s3_phase(p3, on, om); s3_phase(p3 + 1, om, on); }
+        if (p3 < S::NP3) s3_phase(p3, on, om);
     }
 #pragma unroll
     for (int gg = 0; gg < GP; ++gg) {
@@ -538,10 +556,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
 
     SlabPrefetch<WAVES, S::SLAB> pf;
     pf.wave = wave;
-    const float* stream_lane = stream + lane * 4;
+    pf.lane_off = (unsigned)lane * 16u;              // LDS-DMA source = uniform chunk address (SGPR pair) + this 32-bit lane offset
     auto pf_begin = [&](int p) {
         const int start = p < WB ? p * G1 : S::C1 + (p - WB) * G2;
-        pf.begin(stream_lane, smem, p, start, p >= S::NPH ? 0 : (p < WB ? G1 : G2));
+        pf.begin(stream, smem, p, start, p >= S::NPH ? 0 : (p < WB ? G1 : G2));
     };
     auto hook = [&]() { pf.tick(); };
     auto A = [&](int p, int j) -> f4 {

@@ -62,7 +62,22 @@ OARD_DEV float silu1(float x) {
     // x * sigmoid(x);  v_exp_f32 + v_rcp_f32 (both <= 1 ulp)
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
-OARD_DEV f4 silu4(f4 v) { return (f4){silu1(v.x), silu1(v.y), silu1(v.z), silu1(v.w)}; }
+// four values: the three non-transcendental steps as packed two-float operations (v_pk_mul_f32 / v_pk_add_f32) - every VALU
+// instruction of an MFMA kernel costs ~6 cycles of the SIMD's MFMA issue time (tools/micro/mfma_valu.hip), transcendental ones ~10
+typedef float f2 __attribute__((ext_vector_type(2)));
+#ifdef OARD_ABL_NOEPI
+OARD_DEV f4 silu4(f4 v) { return v; }
+#else
+OARD_DEV f4 silu4(f4 v) {
+    const f2 a = {v.x, v.y}, b = {v.z, v.w};
+    const f2 ta = a * -1.44269504088896340736f, tb = b * -1.44269504088896340736f;      // exp(-x) = 2^(-x log2 e)
+    const f2 da = (f2){__builtin_amdgcn_exp2f(ta.x), __builtin_amdgcn_exp2f(ta.y)} + 1.0f;
+    const f2 db = (f2){__builtin_amdgcn_exp2f(tb.x), __builtin_amdgcn_exp2f(tb.y)} + 1.0f;
+    const f2 ya = a * (f2){__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y)};
+    const f2 yb = b * (f2){__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y)};
+    return (f4){ya.x, ya.y, yb.x, yb.y};
+}
+#endif
 
 // one output tile of a dense layer: sum_b chunk(t,b) x in[b]   (t may be a runtime value)
 template <int KB>

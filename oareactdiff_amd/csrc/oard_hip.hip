@@ -10,6 +10,9 @@
 
 #include "oard_kernels.h"
 #include "oard_edge_v1.h"
+#ifdef OARD_EXPERIMENTS
+#include "oard_edge_fp.h"     // barrier-free variant of the GCL kernel: measured slower (profiles/round2_gcl_phase_study.txt), experiment builds only
+#endif
 #include "oard_node_v1.h"
 #include "oard_edge_small.h"
 #include "oard_edge_bwd.h"
@@ -269,6 +272,12 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
         GCL_CASE(2, 8, 2)      // 8 waves x 16 edges, two waves per SIMD
         GCL_CASE(3, 4, 2)      // 4 waves x 16 edges (two workgroups per CU): small launches
 #ifdef OARD_EXPERIMENTS        // A/B shapes, only in experiment builds (tools/ab_gcl.sh)
+        case 4: {              // flag pipeline: no workgroup barriers, ring of 4 slabs (oard_edge_fp.h)
+            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_fp<D, 8, 2, S1, S3, false>), cdiv(r1 - r0, 16 * 8), 8 * 64,
+                       (GclRing<D, 2, 4>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
+        case 5: {              // the same with a ring of 3 slabs (waves 0..3 at most one phase ahead)
+            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_fp<D, 8, 2, S1, S3, false, 3>), cdiv(r1 - r0, 16 * 8), 8 * 64,
+                       (GclRing<D, 2, 3>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
         GCL_CASE(8, 8, 3)
         GCL_CASE(9, 8, 4)
         case 10: { LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 12, 1, S1, S3, false, 3>), cdiv(r1 - r0, 16 * 12), 12 * 64,
@@ -1340,6 +1349,15 @@ int oard_debug_timeline_read(long long* out, int waves) {          // experiment
     if (!out || waves < 1 || waves > 16) return OARD_EINVAL;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)waves * TL_MAX * sizeof(long long)));
+    return OARD_OK;
+}
+#endif
+#ifdef OARD_EXPERIMENTS
+// number of bounded waits of the flag-pipelined kernels that ran out (must be 0; not declared in include/oard.h: debugging aid)
+int oard_debug_fp_timeouts(unsigned int* out) {
+    if (!out) return OARD_EINVAL;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fp_timeouts), sizeof(unsigned int)));
     return OARD_OK;
 }
 #endif

@@ -19,3 +19,8 @@ for name in ("g2_prod_b2_n23", "g3p_prod_cutoff", "g2s_prod_b1_n5"):
         out, _ = dyn([x.to(dev) for x in c.xh], c.edge_index.to(dev), c.t.to(dev), c.conditions.to(dev), c.n_frag_switch.to(dev), c.combined_mask.to(dev))
     v, h = c.split([o.cpu() for o in out]); rv, rh = c.split(c.ref64)
     print(f"variant {sys.argv[1:]} {name}: vel {rel(v, rv):.2e} h {rel(h, rh):.2e}", "OK" if max(rel(v, rv), rel(h, rh)) <= 1e-5 else "FAIL")
+if hasattr(L, "oard_debug_fp_timeouts"):
+    import ctypes
+    n = ctypes.c_uint(0)
+    L.oard_debug_fp_timeouts(ctypes.byref(n))
+    print("flag-pipeline wait timeouts:", n.value)

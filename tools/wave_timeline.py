@@ -13,7 +13,7 @@ from oareactdiff_amd.synthetic import make_inputs, make_topology
 
 B = int(os.environ.get("PROBE_B", "64"))
 L = _capi.lib()
-for k, v in dict(parts=1, sequential=1).items():
+for k, v in dict(parts=1, sequential=1, gcl_variant=int(os.environ.get("OARD_GCL_VARIANT", "2"))).items():
     assert L.oard_debug_option(k.encode(), v) == 0
 dev = torch.device("cuda:0")
 cfg = dict(PRODUCTION_LEFTNET_CONFIG)
