@@ -326,29 +326,38 @@ __global__ __launch_bounds__(64) void k_edge_node_sums(TopoDev tp, const float* 
 // psum / qsum (optional): per-chunk column sums of P / Q (the bias gradient is the column sum of dY).
 // =====================================================================================================
 #define OARD_WG_PD 2                 // prefetch distance in 4-row steps (3 spills at the 256-register bound)
+// Addressing (round 2): every load is "wave-uniform base (SGPR pair, advanced by scalar adds) + constant 32-bit lane offset", so the
+// inner loop has no address arithmetic, no predicates and no zero-filling on the VALU: the first version spent 105 VALU instructions
+// (62 v_mov, 22 64-bit adds) and 23 exec branches per 56 MFMAs, and VALU instructions take MFMA issue time on this hardware
+// (tools/micro/mfma_valu.hip).  Lanes of a partial P block read the row's last valid float4 instead, invalid Q tiles of the last
+// group re-read the group's first tile: their accumulators belong to padding outputs that no reduce pass reads.  Rows beyond the
+// chunk are handled by a short masked epilogue.
 template <bool QSILU, int NT>
 __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ P, int ldP, int ncP, const float* __restrict__ Q, int ldQ,
                                                   int ncQ, long long r0, long long r1, long long rows_per_chunk, int nPB, int nQG,
                                                   float* __restrict__ partial, float* __restrict__ psum, float* __restrict__ qsum) {
     const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // grid.x = chunk * gy + task group (4 consecutive (P block, Q group) tasks per workgroup, Q group fastest): the workgroups
     // that stream the same row chunk are dispatched back to back.  Measured alternatives (profiles/round2_wgrad_notes.txt):
     // XCD-aware placement of a chunk's workgroups -15 %, 8-wave workgroups owning 4 P blocks x 2 Q groups -23 %.
     const int gy = (nPB * nQG + 3) / 4;
     const int chunk = blockIdx.x / gy;
-    const int task = (blockIdx.x % gy) * 4 + (threadIdx.x >> 6);
+    const int task = (blockIdx.x % gy) * 4 + wave;
     const long long rb = r0 + (long long)chunk * rows_per_chunk;
     if (task >= nPB * nQG || rb >= r1) return;
     const int pb = task / nQG, qg = task - pb * nQG;
     const int PP = nPB * 64, QP = nQG * NT * 16;
     const long long re = rb + rows_per_chunk < r1 ? rb + rows_per_chunk : r1;
     const int cp = 64 * pb + 4 * i;
-    const bool okp = cp < ncP;
-    const float* pp = P + cp;
-    const float* pq = Q + 16 * qg * NT + i;
-    bool okq[NT];
+    const unsigned voffP = (unsigned)(g * ldP + (cp < ncP ? cp : ncP - 4)) * 4u;      // constant per lane (bytes)
+    const unsigned voffQ = (unsigned)(g * ldQ + 16 * qg * NT + i) * 4u;
+    int qtile[NT];                                                                    // wave-uniform: tile u, or 0 if it lies beyond ncQ
 #pragma unroll
-    for (int u = 0; u < NT; ++u) okq[u] = 16 * (qg * NT + u) + i < ncQ;
+    for (int u = 0; u < NT; ++u) qtile[u] = 16 * (qg * NT + u) < ncQ ? 64 * u : 0;
+    const char* bp = reinterpret_cast<const char*>(P + (size_t)rb * ldP);             // wave-uniform bases, advanced per step
+    const char* bq = reinterpret_cast<const char*>(Q + (size_t)rb * ldQ);
+    const size_t stepP = (size_t)16 * ldP, stepQ = (size_t)16 * ldQ;                 // 4 rows, bytes
 
     f4 acc[4][NT];
 #pragma unroll
@@ -359,35 +368,69 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ P, i
     float qs[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) qs[u] = 0.f;
+    const bool sums = (psum != nullptr && qg == 0) || (qsum != nullptr && pb == 0);        // wave-uniform
+    const long long nrows = re - rb, nfull = nrows / 4;        // nfull: steps whose 4 rows are all inside the chunk
     f4 ra[OARD_WG_PD];
     float rq[OARD_WG_PD][NT];
-    auto load = [&](int slot, long long row) {
-        const bool v = row < re;
-        ra[slot] = (v && okp) ? ld_f4(pp + (size_t)row * ldP) : f4zero();
+    auto load = [&](int slot) {                               // unconditional: the caller guarantees that the 4 rows exist
+        ra[slot] = *reinterpret_cast<const f4*>(bp + voffP);
 #pragma unroll
-        for (int u = 0; u < NT; ++u) rq[slot][u] = (v && okq[u]) ? pq[(size_t)row * ldQ + 16 * u] : 0.f;
+        for (int u = 0; u < NT; ++u) rq[slot][u] = *reinterpret_cast<const float*>(bq + qtile[u] + voffQ);
+        bp += stepP; bq += stepQ;
     };
-#pragma unroll
-    for (int u = 0; u < OARD_WG_PD; ++u) load(u, rb + 4 * u + g);
-    for (long long r = rb; r < re; r += 4 * OARD_WG_PD) {
-#pragma unroll
-        for (int s = 0; s < OARD_WG_PD; ++s) {
-            const f4 a = ra[s];
-            float b[NT];
-#pragma unroll
-            for (int u = 0; u < NT; ++u) b[u] = QSILU ? silu1(rq[s][u]) : rq[s][u];
-            load(s, r + 4 * (s + OARD_WG_PD) + g);
+    auto mma_step = [&](const f4 a, const float (&b)[NT], bool with_sums) {
+        if (with_sums) {
             ps += a;
 #pragma unroll
             for (int u = 0; u < NT; ++u) qs[u] += b[u];
+        }
 #pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[u], acc[0][u], 0, 0, 0);
-                acc[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[u], acc[1][u], 0, 0, 0);
-                acc[2][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[u], acc[2][u], 0, 0, 0);
-                acc[3][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u], acc[3][u], 0, 0, 0);
+        for (int u = 0; u < NT; ++u) {
+            acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[u], acc[0][u], 0, 0, 0);
+            acc[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[u], acc[1][u], 0, 0, 0);
+            acc[2][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[u], acc[2][u], 0, 0, 0);
+            acc[3][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u], acc[3][u], 0, 0, 0);
+        }
+    };
+    long long st = 0;                                         // steps consumed
+    if (nfull >= OARD_WG_PD) {
+#pragma unroll
+        for (int u = 0; u < OARD_WG_PD; ++u) load(u);
+        // main loop: the step loaded in place of a consumed one (OARD_WG_PD steps ahead) is a full step as well
+        for (; st + 2 * OARD_WG_PD <= nfull; st += OARD_WG_PD) {
+#pragma unroll
+            for (int sl = 0; sl < OARD_WG_PD; ++sl) {
+                const f4 a = ra[sl];
+                float b[NT];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) b[u] = QSILU ? silu1(rq[sl][u]) : rq[sl][u];
+                load(sl);
+                mma_step(a, b, sums);
             }
         }
+#pragma unroll
+        for (int sl = 0; sl < OARD_WG_PD; ++sl) {              // drain the loaded steps
+            float b[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) b[u] = QSILU ? silu1(rq[sl][u]) : rq[sl][u];
+            mma_step(ra[sl], b, sums);
+        }
+        st += OARD_WG_PD;
+    }
+    // what is left (fewer than 2 OARD_WG_PD full steps and the partial one): rows beyond the chunk read row re - 1 and count as zero
+    for (; st * 4 < nrows; ++st) {
+        const long long row = rb + 4 * st + g;
+        const bool v = row < re;
+        const size_t rr = (size_t)((v ? row : re - 1) - rb - g);        // row offset relative to the lane's row rb + g
+        f4 a = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(P + (size_t)rb * ldP) + rr * ldP * 4 + voffP);
+        float b[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Q + (size_t)rb * ldQ) + rr * ldQ * 4 + qtile[u] + voffQ);
+            b[u] = v ? (QSILU ? silu1(x) : x) : 0.f;
+        }
+        if (!v) a = f4zero();
+        mma_step(a, b, sums);
     }
     // accumulator (c, u), component q of lane (g, j):  out[64 pb + 4 (4g + q) + c][16 (qg NT + u) + j]
     float* out = partial + (size_t)chunk * PP * QP;
@@ -445,13 +488,23 @@ __global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ d
     for (int q = 0; q < 4; ++q)
         if (tid + 256 * q < nout) partial[(size_t)blockIdx.x * nout + tid + 256 * q] = acc[q];
 }
-// dW [MO][MI] and db [MO] from the small kernel's partials, chunks in ascending order
-__global__ void k_wgrad_small_reduce(const float* __restrict__ partial, int n_chunks, int MO, int MI, float* __restrict__ dW,
-                                     float* __restrict__ db) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x, nout = MO * (MI + 1);
-    if (idx >= nout) return;
+// Fixed-order sum of one value over the chunks by ONE WAVE: lane l adds chunks l, l + 64, ... in ascending order, then the 64
+// lane sums are combined by a fixed butterfly - deterministic, and ~n_chunks / 64 dependent loads per thread instead of n_chunks
+// (a single thread walking 1024 partials took 200 us per call: 18 + 24 such calls per training step).
+OARD_DEV float chunk_sum_wave(const float* __restrict__ p, size_t stride, int n_chunks, int lane) {
     float s = 0.f;
-    for (int ch = 0; ch < n_chunks; ++ch) s += partial[(size_t)ch * nout + idx];
+    for (int ch = lane; ch < n_chunks; ch += 64) s += p[(size_t)ch * stride];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    return s;
+}
+// dW [MO][MI] and db [MO] from the small kernel's partials: one wave per output
+__global__ __launch_bounds__(256) void k_wgrad_small_reduce(const float* __restrict__ partial, int n_chunks, int MO, int MI,
+                                                            float* __restrict__ dW, float* __restrict__ db) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), nout = MO * (MI + 1);
+    if (idx >= nout) return;
+    const float s = chunk_sum_wave(partial + idx, (size_t)nout, n_chunks, threadIdx.x & 63);
+    if ((threadIdx.x & 63) != 0) return;
     const int o = idx / (MI + 1), i = idx % (MI + 1);
     if (i < MI) dW[o * MI + i] = s;
     else if (db != nullptr) db[o] = s;
@@ -471,12 +524,11 @@ __global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, 
     for (int ch = 0; ch < n_chunks; ++ch) s += p[(size_t)ch * PP * QP];
     out[idx] = s;
 }
-__global__ void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int stride, int o_len, int o_pad, int MO,
-                               float* __restrict__ out) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int stride, int o_len, int o_pad,
+                                                      int MO, float* __restrict__ out) {          // one wave per output
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= MO) return;
     const int op = (o / o_len) * o_pad + o % o_len;
-    float s = 0.f;
-    for (int ch = 0; ch < n_chunks; ++ch) s += bpartial[(size_t)ch * stride + op];
-    out[o] = s;
+    const float s = chunk_sum_wave(bpartial + op, (size_t)stride, n_chunks, threadIdx.x & 63);
+    if ((threadIdx.x & 63) == 0) out[o] = s;
 }

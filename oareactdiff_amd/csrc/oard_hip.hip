@@ -1251,7 +1251,7 @@ int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, 
         const int nch = (int)cdiv(std::max<long long>(rows, 1), rpc);
         ScopedLaunch sl_(F_WGRAD, st);
         hipLaunchKernelGGL(k_wgrad_small, dim3(nch), dim3(256), 0, st, dY, ldY, MO, X, ldX, MI, x_silu, (long long)rows, rpc, partial);
-        hipLaunchKernelGGL(k_wgrad_small_reduce, dim3((unsigned)cdiv(MO * (MI + 1), 256)), dim3(256), 0, st, partial, nch, MO, MI, dW, db);
+        hipLaunchKernelGGL(k_wgrad_small_reduce, dim3((unsigned)cdiv(MO * (MI + 1), 4)), dim3(256), 0, st, partial, nch, MO, MI, dW, db);
         HIP_TRY(hipGetLastError());
         return OARD_OK;
     }
@@ -1272,7 +1272,7 @@ int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, 
         hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 256)), dim3(256), 0, st, partial, p.n_chunks, p.PP,
                            p.QP, p.transposed, o_len, o_pad, MO, i_len, i_pad, MI, dW);
         if (db)
-            hipLaunchKernelGGL(k_bgrad_reduce, dim3((unsigned)cdiv(MO, 256)), dim3(256), 0, st, bpartial, p.n_chunks,
+            hipLaunchKernelGGL(k_bgrad_reduce, dim3((unsigned)cdiv(MO, 4)), dim3(256), 0, st, bpartial, p.n_chunks,
                                p.transposed ? p.QP : p.PP, o_len, o_pad, MO, db);
     }
     HIP_TRY(hipGetLastError());
