@@ -372,6 +372,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
     constexpr int TPW = (HT + WAVES - 1) / WAVES;            // tiles owned per wave (upper bound)
     __shared__ __attribute__((aligned(16))) float sm[6 * HT * 256 + 48 * 12];
     float* l3s = sm + 6 * HT * 256;        // frame-scalar MLP weights (lin3u_stage)
+#ifdef OARD_TIMELINE
+    const bool tl_on_ = blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0; int tl_n_ = 0;
+#endif
+    TL(1);
     lin3u_stage(wb + lo.l3u, l3s, threadIdx.x, WAVES * 64);        // visible after the first barrier below
     float* vx = sm;                        // [3][HT] updated vec
     float* in = sm + 3 * HT * 256;         // [2 HT]: s_mid | scal
@@ -439,7 +443,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
             st_blk(va_out, (size_t)n * 3 + 2, D::HP, t, nb.lane, v2);
         }
     }
+    TL(2);
     __syncthreads();
+    TL(3);
 
     // 2. vec_proj for owned tile pairs (t, HT + t), frame scalar, vdot; keep vec2 / vdot in registers
     const float fx = x1[n * 3], fy = x1[n * 3 + 1], fz = x1[n * 3 + 2];
@@ -482,7 +488,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
             }
         }
     }
+    TL(4);
     __syncthreads();
+    TL(5);
 
     // 3. xvec_proj hidden
     {
@@ -495,7 +503,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         for (int i = 0; i < TPW; ++i)
             if (nb.wave + i * WAVES < HT) lds_st(hx, nb.wave + i * WAVES, nb.lane, silu4(acc[i]));
     }
+    TL(6);
     __syncthreads();
+    TL(7);
 
     // 4. outputs for owned tiles
     {
@@ -521,6 +531,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
             }
         }
     }
+    TL(0);
+    TL_END();
 }
 
 // =====================================================================================================
