@@ -172,7 +172,8 @@ int oard_debug_stop_after(int code);
  *   "parts" [0]         sub-batches per topology (0 = 4 for B >= 32, 2 for B >= 16, else 1); read by
  *                       oard_topology_create;  "sequential" [0] = 1 runs them one after the other
  *   "poison" [0]        1 fills the workspace with NaN bit patterns before every forward (the tests use it to
- *                       prove that nothing depends on workspace contents) */
+ *                       prove that nothing depends on workspace contents)
+ *   "wgrad_wgs" [512]   workgroups per weight-gradient GEMM (oard_wgrad): row chunks x task groups */
 int oard_debug_option(const char* name, int value);
 
 /* Average duration (ms) and launch count per kernel family since the last reset, measured with
