@@ -63,6 +63,8 @@ int g_auto_small = 4;       // 1: small launches use the 4-wave workgroups (one 
 int g_npb = 0;              // nodes per workgroup of the node stages (0 = auto, see oard_topology_create)
 int g_poison = 0;           // 1: fill the workspace with NaN bit patterns before every forward (tests: nothing may depend on its contents)
 int g_parts = 0;            // sub-batches per topology (0 = auto: 4 for B >= 32, 2 for B >= 16, else 1)
+int g_small_split = 128;     // EquiMessage latency kernel: launches of <= this many 16-edge tiles run one launch per dense stage
+                            // (a workgroup = 16 edges x 8 output tiles); 0 = never
 int g_wgrad_wgs = 512;       // workgroups per weight-gradient GEMM (row chunks x task groups): one round of 2 x 4 waves per CU
                             // (measured per training step: 384 -> 38.1 ms, 512 -> 30.7, 768 -> 36.0, 1024 -> 33.2, 2048 -> 38.1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
@@ -216,6 +218,10 @@ struct Packer {
         hipLaunchKernelGGL(k_copy_raw, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, p[src], blob + dst, n);
     }
 };
+// scratch of the stage-split latency path (activations between the stage launches), set per forward call / sub-batch
+#define OARD_SMALL_MAX_EDGES (512 * 16 * 16)      // topologies up to 131 072 edges get the scratch buffer
+struct SmallScratch { float* a; float* b; };
+static thread_local SmallScratch t_small = {nullptr, nullptr};
 static WsOff make_ws(const oard_config* c, const TopoDev& td) {
     const RDims d(c->hidden, c->num_radial);
     const size_t N = td.N, E = td.E + 1, A = td.A + 1;   // + the spare row of the padding columns
@@ -232,6 +238,12 @@ static WsOff make_ws(const oard_config* c, const TopoDev& td) {
     w.ew = take(E * d.WP * 4); w.mbuf = take(E * d.HP * 4);
     w.xmsg = take(A * d.HP * 4); w.vmsg = take(A * 3 * d.HP * 4);
     w.dpos = take(N * 3 * 4); w.hout = take(N * 16 * 4);
+    // scratch of the stage-split latency edge kernels: only topologies small enough to ever take that path (the launch-shape
+    // thresholds are run-time options, so the launch re-checks that the buffers exist)
+    w.small_a = w.small_b = 0;
+    if (E <= (size_t)OARD_SMALL_MAX_EDGES) {
+        w.small_a = take(A * d.D1P * 4);
+    }
     w.total = cur;
     return w;
 }
@@ -243,6 +255,7 @@ int set_lds(K kernel, size_t bytes) {
     HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return OARD_OK;
 }
+
 // the dynamic-LDS limit is a per-device function attribute: track it per (call site, device)
 #define LAUNCH_LDS(fam, kern, grid, block, lds, stream, ...) do { \
     static bool attr_done_[64] = {}; \
@@ -321,6 +334,14 @@ int launch_equi_v1(int variant, int conc, const TopoDev& tp, const float* wb, co
     if (variant == 2 && cdiv(tp.A, 16) * conc <= 512LL * g_auto_small) variant = 1;
     if ((variant == 2 || variant == 1) && cdiv(tp.A, 16) * conc <= 512LL * g_auto_tiny) variant = 4;
     if (variant == 4) {          // latency kernel: 8 waves share 16 edges
+        if (t_small.a && cdiv(tp.A, 16) * conc <= g_small_split) {   // stage-split latency path: 2 launches, few tiles only
+            const long long tiles = cdiv(tp.A, 16);
+            LAUNCH_LDS(F_EQUI_EDGE, (k_equi_small_s1<D, 8>), tiles * cdiv(D::D1T, 8), 512, (size_t)D::WB * 1024, st,
+                       tp, wb, lo, ew, t_small.a);
+            LAUNCH_LDS(F_EQUI_EDGE, (k_equi_small_s2<D, 8>), tiles * cdiv(3 * D::HT, 8), 512, (size_t)(D::D1T + D::RB) * 1024, st,
+                       tp, wb, lo, (const float*)t_small.a, rbuf, qbuf);
+            return OARD_OK;
+        }
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_small<D, 8>), cdiv(tp.A, 16), 512, (EquiSmall<D>::LDS_BYTES), st,
                    tp, wb, lo, ew, rbuf, qbuf);
         return OARD_OK;
@@ -388,6 +409,7 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     float* geo = (float*)(ws + w.geo); double* d64 = (double*)(ws + w.d64); float* rbuf = (float*)(ws + w.rbuf);
     float* mbuf = (float*)(ws + w.mbuf); float* xmsg = (float*)(ws + w.xmsg);
     float* vmsg = (float*)(ws + w.vmsg); float* dpos = (float*)(ws + w.dpos); float* hout = (float*)(ws + w.hout);
+    t_small = (w.small_a && !train) ? SmallScratch{(float*)(ws + w.small_a), (float*)(ws + w.small_b)} : SmallScratch{nullptr, nullptr};
     // edge state entering layer l (inference: one buffer updated in place)
     auto ew_at = [&](int l) -> float* { return train ? (float*)(tape + to.ew[l]) : (float*)(ws + w.ew); };
     float* ew = ew_at(0);
@@ -1331,6 +1353,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "auto_tiny") == 0) { g_auto_tiny = value; return OARD_OK; }
     if (strcmp(name, "npb") == 0) { g_npb = value; return OARD_OK; }
     if (strcmp(name, "wgrad_wgs") == 0) { g_wgrad_wgs = value; return OARD_OK; }
+    if (strcmp(name, "small_split") == 0) { g_small_split = value; return OARD_OK; }
 #ifdef OARD_PRIO_BALANCE
     if (strcmp(name, "prio_k") == 0) { HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prio_k), &value, sizeof(int))); return OARD_OK; }
 #endif

@@ -99,4 +99,5 @@ struct oard_topology {
 struct WsOff {
     size_t pos, pf64, pf32, x1, pp0, labels, hin, zemb, nb, s, s1, ne1, xh, P, Q, xq, vec, vec2, v2buf, sc0, vdot,
         geo, d64, rbuf, ew, mbuf, xmsg, vmsg, dpos, hout, total;   // xmsg..vmsg double as qbuf [A][3][HP] (v1)
+    size_t small_a, small_b;       // stage-split EquiMessage latency path: d1 [A+1][D1P]; 0 = not allocated (large topologies)
 };

@@ -56,34 +56,67 @@ OARD_DEV TileJob tile_job(const float* __restrict__ wp, int t, const float* in) 
     return TileJob{wp + (size_t)t * KB * 256, in};
 }
 #ifndef OARD_NODE_SEQ_G
-#define OARD_NODE_SEQ_G 7       // chunks per pipeline step (2 x 7 x 4 VGPRs of weights in flight)
+#define OARD_NODE_SEQ_G 7       // chunks per pipeline step
 #endif
-template <int KB, int N>
+// R = ring depth: the chunks of steps s+1 .. s+R-1 are in flight while step s issues its MFMAs ((R-1) x G x 4 VGPRs in flight,
+// R x G x 4 held).  R = 2 is the node kernels' shape (register budget of 13-wave workgroups); the latency edge kernels use R = 4:
+// with 7 chunks per step one step's MFMAs take ~0.4 us and an L2 round trip ~1.5 us, so three steps have to be in flight.
+template <int KB, int N, int G = OARD_NODE_SEQ_G, int R = 2>
 OARD_DEV void dense_seq(const TileJob (&job)[N], int lane, f4 (&acc)[N]) {
-    constexpr int G = OARD_NODE_SEQ_G, NG = (KB + G - 1) / G, S = N * NG;
-    f4 a[2][G];
+    constexpr int NG = (KB + G - 1) / G, S = N * NG;
+    f4 a[R][G];
     f4 c1 = f4zero();
+    auto fetch = [&](int st) {                                // st is a compile-time constant after unrolling
+        const int j1 = st / NG, q1 = st % NG;
 #pragma unroll
-    for (int i = 0; i < G; ++i)
-        if (i < KB) a[0][i] = ld_f4(job[0].w + (size_t)i * 256 + lane * 4);
+        for (int i = 0; i < G; ++i)
+            if (q1 * G + i < KB) a[st % R][i] = ld_f4(job[j1].w + (size_t)(q1 * G + i) * 256 + lane * 4);
+    };
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st)
+        if (st < S) fetch(st);
 #pragma unroll
     for (int st = 0; st < S; ++st) {
         const int j = st / NG, q = st % NG;
-        if (st + 1 < S) {
-            const int j1 = (st + 1) / NG, q1 = (st + 1) % NG;
-#pragma unroll
-            for (int i = 0; i < G; ++i)
-                if (q1 * G + i < KB) a[(st + 1) & 1][i] = ld_f4(job[j1].w + (size_t)(q1 * G + i) * 256 + lane * 4);
-        }
+        if (st + R - 1 < S) fetch(st + R - 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < G; ++i)
             if (q * G + i < KB) {
                 const f4 x = lds_blk(job[j].in, q * G + i, lane);
-                if (i & 1) c1 = mma_chunk(a[st & 1][i], x, c1);
-                else acc[j] = mma_chunk(a[st & 1][i], x, acc[j]);
+                if (i & 1) c1 = mma_chunk(a[st % R][i], x, c1);
+                else acc[j] = mma_chunk(a[st % R][i], x, acc[j]);
             }
         if (q == NG - 1) { acc[j] += c1; c1 = f4zero(); }
+    }
+}
+// The same for C column tiles (16 C columns) that share every weight chunk: the activations of column tile c live `cstride` floats
+// behind those of tile 0 (latency edge kernels, oard_edge_small.h).
+template <int KB, int N, int C, int G = OARD_NODE_SEQ_G, int R = 2>
+OARD_DEV void dense_seq_cols(const TileJob (&job)[N], int cstride, int lane, f4 (&acc)[N][C]) {
+    constexpr int NG = (KB + G - 1) / G, S = N * NG;
+    f4 a[R][G];
+    auto fetch = [&](int st) {
+        const int j1 = st / NG, q1 = st % NG;
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (q1 * G + i < KB) a[st % R][i] = ld_f4(job[j1].w + (size_t)(q1 * G + i) * 256 + lane * 4);
+    };
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st)
+        if (st < S) fetch(st);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+        const int j = st / NG, q = st % NG;
+        if (st + R - 1 < S) fetch(st + R - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (q * G + i < KB) {
+#pragma unroll
+                for (int c = 0; c < C; ++c)            // C independent accumulators: consecutive MFMAs never depend on each other
+                    acc[j][c] = mma_chunk(a[st % R][i], lds_blk(job[j].in + c * cstride, q * G + i, lane), acc[j][c]);
+            }
     }
 }
 
