@@ -167,6 +167,32 @@ OARD_DEV NodeBlk node_blk(int N, int npb) {
     return b;
 }
 
+// Small batches (npb <= 4 real nodes per workgroup): the 16 MFMA columns of a wave are mostly padding, and a gather that walks a
+// node's rows two or eight at a time is a chain of dependent L2 / HBM round trips (B = 1: eleven steps of ~1.8 us in
+// k_equi_node_v1).  There the 16 columns are dealt to the ROWS instead: node i of the workgroup owns the L = 16 >> ceil(log2 npb)
+// lanes e = i L .. i L + L - 1 of every 16-lane group, lane slot e % L takes rows slot, slot + L, ... of its node, a butterfly
+// adds the L partial sums and column i fetches the total from lane i L.  22 rows then take one or two steps instead of eleven.
+struct RowLanes {
+    int L, npb, node, slot; // lanes per node, nodes per workgroup, node (column) this lane works for, its slot among the node's lanes
+    bool live;              // this lane's node exists
+};
+OARD_DEV RowLanes row_lanes(int N, int npb, int lane) {
+    RowLanes r;
+    r.L = npb == 1 ? 16 : (npb == 2 ? 8 : 4); r.npb = npb;
+    const int e = lane & 15;
+    r.node = e / r.L; r.slot = e % r.L;
+    r.live = r.node < npb && blockIdx.x * npb + r.node < N;
+    return r;
+}
+OARD_DEV float rows_total(float x, const RowLanes& r, int lane) {          // sum over the node's lanes, delivered to column `node`
+    for (int d = 1; d < r.L; d <<= 1) x += __shfl_xor(x, d, 64);
+    const int e = lane & 15;
+    return __shfl(x, (lane & 48) | ((e < r.npb ? e : 0) * r.L), 64);        // column e < npb reads lane e L of its 16-lane group
+}
+OARD_DEV f4 rows_total4(f4 v, const RowLanes& r, int lane) {
+    return (f4){rows_total(v.x, r, lane), rows_total(v.y, r, lane), rows_total(v.z, r, lane), rows_total(v.w, r, lane)};
+}
+
 // =====================================================================================================
 // s += pos_expansion(pos_prjt);  xh = LN_gcl(s);  P = W1a xh + b1;  Q = W1b xh      (see k_node_pre)
 // =====================================================================================================
@@ -258,9 +284,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
     for (int t = nb.wave; t < D::HT; t += WAVES) {
         lds_st(in, t, nb.lane, ld_blk(xh, nb.n, D::HP, t, nb.lane));
         f4 a0 = f4zero(), a1 = f4zero();
+        if (tp.npb <= 4) {                                      // small batches: the wave's columns walk the rows (row_lanes)
+            const RowLanes rl = row_lanes(tp.N, tp.npb, nb.lane);
+            const int nn = min(blockIdx.x * tp.npb + rl.node, tp.N - 1);
+            const int smp2 = tp.node_sample[nn];
+            const int deg2 = rl.live ? tp.sample_ptr[smp2 + 1] - tp.sample_ptr[smp2] - 1 : 0;
+            const size_t e2 = (size_t)tp.edge_ptr[nn];
+            const int mx2 = wave_max(deg2), last2 = max(deg2 - 1, 0);
+            for (int k = 0; k < mx2; k += 2 * rl.L) {
+                const int k0 = k + rl.slot, k1 = k0 + rl.L;
+                const f4 r0 = ld_blk(mbuf, e2 + min(k0, last2), D::HP, t, nb.lane), r1 = ld_blk(mbuf, e2 + min(k1, last2), D::HP, t, nb.lane);
+                if (k0 < deg2) a0 += r0;
+                if (k1 < deg2) a1 += r1;
+            }
+            a0 = rows_total4(a0 + a1, rl, nb.lane);
+            a1 = f4zero();
+        }
         // 8 message rows in flight per step (branch-free: out-of-range slots re-read the last row with weight 0)
         const int last = max(deg - 1, 0);
-        for (int k = 0; k < mx; k += 8) {
+        for (int k = 0; tp.npb > 4 && k < mx; k += 8) {
             f4 r[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) r[i] = ld_blk(mbuf, e0 + min(k + i, last), D::HP, t, nb.lane);
@@ -424,12 +466,43 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         f4 dx = f4zero(), v0 = f4zero(), v1 = f4zero(), v2 = f4zero();
         const f4 xn0 = ld_blk(xq, n, 3 * D::HP, t, nb.lane), xn1 = ld_blk(xq, n, 3 * D::HP, HT + t, nb.lane),
                  xn2 = ld_blk(xq, n, 3 * D::HP, 2 * HT + t, nb.lane);
-        // two edges in flight per step, branch-free (out-of-range slots re-read a valid edge and are discarded)
         const long long a_hi = max(tp.A - 1, 0LL);
+        if (tp.npb <= 4) {                                      // small batches: the wave's columns walk the edges (row_lanes)
+            const RowLanes rl = row_lanes(tp.N, tp.npb, nb.lane);
+            const int nn = min(blockIdx.x * tp.npb + rl.node, tp.N - 1);
+            const int b0 = tp.act_ptr[nn], cnt2 = rl.live ? tp.act_ptr[nn + 1] - b0 : 0;
+            const int mx2 = wave_max(cnt2);
+            const f4 zn0 = ld_blk(xq, nn, 3 * D::HP, t, nb.lane), zn1 = ld_blk(xq, nn, 3 * D::HP, HT + t, nb.lane),
+                     zn2 = ld_blk(xq, nn, 3 * D::HP, 2 * HT + t, nb.lane);
+            for (int k = 0; k < mx2; k += rl.L) {
+                const int kk = k + rl.slot;
+                const size_t a = (size_t)min((long long)b0 + min(kk, max(cnt2 - 1, 0)), a_hi);
+                const int m = tp.act_src[a];
+                const float* gp = geo + a * GEO_STRIDE;
+                const float gx = gp[2], gy = gp[3], gz = gp[4];
+                const f4 q0 = ld_blk(qbuf, a, 3 * D::HP, t, nb.lane), q1 = ld_blk(qbuf, a, 3 * D::HP, HT + t, nb.lane),
+                         q2 = ld_blk(qbuf, a, 3 * D::HP, 2 * HT + t, nb.lane);
+                const f4 y0 = ld_blk(xq, m, 3 * D::HP, t, nb.lane), y1 = ld_blk(xq, m, 3 * D::HP, HT + t, nb.lane),
+                         y2 = ld_blk(xq, m, 3 * D::HP, 2 * HT + t, nb.lane);
+                const f4 w0 = ld_blk(vec_in, (size_t)m * 3 + 0, D::HP, t, nb.lane), w1 = ld_blk(vec_in, (size_t)m * 3 + 1, D::HP, t, nb.lane),
+                         w2 = ld_blk(vec_in, (size_t)m * 3 + 2, D::HP, t, nb.lane);
+                if (kk < cnt2) {
+                    dx += (y0 + zn0) * q0;
+                    const f4 a2 = (y1 + zn1) * q1 * inv_sqrt3;
+                    const f4 a3 = (y2 + zn2) * q2;
+                    v0 += (w0 * a2 + a3 * gx) * inv_sqrt_h;
+                    v1 += (w1 * a2 + a3 * gy) * inv_sqrt_h;
+                    v2 += (w2 * a2 + a3 * gz) * inv_sqrt_h;
+                }
+            }
+            dx = rows_total4(dx, rl, nb.lane); v0 = rows_total4(v0, rl, nb.lane);
+            v1 = rows_total4(v1, rl, nb.lane); v2 = rows_total4(v2, rl, nb.lane);
+        }
+        // two edges in flight per step, branch-free (out-of-range slots re-read a valid edge and are discarded)
         int mnext[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) mnext[i] = tp.act_src[(size_t)min((long long)a0 + min(i, max(cnt - 1, 0)), a_hi)];
-        for (int k = 0; k < mx; k += 2) {
+        for (int k = 0; tp.npb > 4 && k < mx; k += 2) {
             f4 q0[2], q1[2], q2[2], y0[2], y1[2], y2[2], w0[2], w1[2], w2[2];
             float gx[2], gy[2], gz[2];
             const int mc[2] = {mnext[0], mnext[1]};
