@@ -12,210 +12,105 @@
 #pragma once
 #include "oard_node_v1.h"
 
-// C = column tiles per workgroup (16 C edges sharing every weight chunk).  Only C = 1 is instantiated: C = 2 was measured slower
-// (B = 1: 1.70 -> 2.08 ms per call) - these launches are bound by the MFMA time of the CUs that hold a tile (one 16-edge tile =
-// ~17 us of a CU for GCL, ~43 us for EquiMessage, and B = 1 has 294 / 95 tiles for 256 CUs), not by the weight traffic, and a
-// deeper weight prefetch (ring of 3-4 steps in dense_seq_cols) changes nothing either.
-template <class D, int C = 1>
+// Measured and dropped in round 2 (B = 1): 32 edges per workgroup sharing every weight chunk (1.70 -> 2.08 ms per call) and a
+// deeper weight prefetch (ring of 3-4 steps: GCL 50 -> 56 us per layer, EquiMessage unchanged): these launches are bound by the
+// MFMA time of the CUs that hold a tile (one 16-edge tile = ~17 us of a CU for GCL, ~43 us for EquiMessage, and B = 1 has 294 / 95
+// tiles for 256 CUs), not by the weight traffic or its latency.
+template <class D>
 struct GclSmall {
-    static constexpr int REGION = (D::WB + 2 * D::HT) * 256;          // floats of LDS per column tile
-    static constexpr size_t LDS_BYTES = (size_t)C * REGION * 4;
+    static constexpr size_t LDS_BYTES = (size_t)(D::WB + 2 * D::HT) * 1024;
 };
 
 // GCLMessage edge part on physical rows [r0, r1):  h1 = SiLU(W1c ew + P[src] + Q[tgt]);  m = SiLU(W2 h1 + b2);
 // m *= SiLU(watt.m + batt);  mbuf[eid] = m;  ew += SiLU(W3 m + b3).     DO_S1 = false: rows whose state is the
 // constant row c0 (W1c c0 = u0 precomputed);  DO_S3 = false: the updated state is never read (last layer).
-template <class D, int WAVES, bool DO_S1, bool DO_S3, int C = 1>
+template <class D, int WAVES, bool DO_S1, bool DO_S3>
 __global__ __launch_bounds__(WAVES * 64) void k_gcl_edge_small(TopoDev tp, const float* __restrict__ wb, LayerOff lo,
                                                                const float* __restrict__ P, const float* __restrict__ Q,
                                                                const float* __restrict__ u0, const float* __restrict__ c0,
                                                                long long r0, long long r1, float* __restrict__ ew,
                                                                float* __restrict__ mbuf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WB = D::WB, HT = D::HT, REGION = GclSmall<D, C>::REGION;
-    float* ewv = smem;                      // [WB] edge state of the 16 rows of column tile 0 (tile c: + c * REGION)
+    constexpr int WB = D::WB, HT = D::HT;
+    float* ewv = smem;                      // [WB] edge state of the 16 rows
     float* h1v = smem + WB * 256;           // [HT] h1, later the gated message
     float* h2v = h1v + HT * 256;            // [HT]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    bool valid[C];
-    size_t row[C];
-    int src[C], tgt[C];
-    float* erow[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const long long r = r0 + ((long long)blockIdx.x * C + c) * 16 + (lane & 15);
-        valid[c] = r < r1;
-        row[c] = (size_t)(valid[c] ? r : tp.E);             // padding columns use the spare row
-        src[c] = tp.row_src[row[c]]; tgt[c] = tp.row_tgt[row[c]];
-        erow[c] = ew + row[c] * D::WP + 4 * g;
-    }
+    const long long r = r0 + (long long)blockIdx.x * 16 + (lane & 15);
+    const bool valid = r < r1;
+    const size_t row = (size_t)(valid ? r : tp.E);          // padding columns use the spare row
+    const int src = tp.row_src[row], tgt = tp.row_tgt[row];
+    float* erow = ew + row * D::WP + 4 * g;
 
     if (DO_S1) {
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-            for (int b = wave; b < WB; b += WAVES) lds_st(ewv + c * REGION, b, lane, ld_f4(erow[c] + 16 * b));
+        for (int b = wave; b < WB; b += WAVES) lds_st(ewv, b, lane, ld_f4(erow + 16 * b));
         __syncthreads();
     }
-    // every stage: the output tiles wave, wave + WAVES, ... of this wave as ONE software-pipelined chunk sequence (dense_seq_cols,
-    // SR steps of SG chunks in flight, weights straight from L2); tiles beyond the layer are clamped to its last tile and dropped
-    constexpr int SG = 7, SR = 3;
-    constexpr int T1 = (HT + WAVES - 1) / WAVES, T3 = (WB + WAVES - 1) / WAVES;
-    {
-        TileJob job[T1];
-        f4 acc[T1][C];
-#pragma unroll
-        for (int i = 0; i < T1; ++i) {
-            const int t = min(wave + i * WAVES, HT - 1);
-            job[i] = tile_job<WB>(wb + lo.W1c, t, ewv);
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                acc[i][c] = ld_blk(P, src[c], D::HP, t, lane) + ld_blk(Q, tgt[c], D::HP, t, lane);
-                if (!DO_S1) acc[i][c] += ld_vec(u0, t, lane);
-            }
-        }
-        if (DO_S1) dense_seq_cols<WB, T1, C, SG, SR>(job, REGION, lane, acc);
-#pragma unroll
-        for (int i = 0; i < T1; ++i)
-            if (wave + i * WAVES < HT)
-#pragma unroll
-                for (int c = 0; c < C; ++c) lds_st(h1v + c * REGION, wave + i * WAVES, lane, silu4(acc[i][c]));
+    for (int t = wave; t < HT; t += WAVES) {
+        const f4 pq = ld_blk(P, src, D::HP, t, lane) + ld_blk(Q, tgt, D::HP, t, lane);
+        const f4 acc = DO_S1 ? dense_tile_lds<WB>(wb + lo.W1c, t, ewv, lane, pq) : pq + ld_vec(u0, t, lane);
+        lds_st(h1v, t, lane, silu4(acc));
     }
     __syncthreads();
-    {
-        TileJob job[T1];
-        f4 acc[T1][C];
-#pragma unroll
-        for (int i = 0; i < T1; ++i) {
-            const int t = min(wave + i * WAVES, HT - 1);
-            job[i] = tile_job<HT>(wb + lo.W2, t, h1v);
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[i][c] = ld_vec(wb + lo.b2, t, lane);
-        }
-        dense_seq_cols<HT, T1, C, SG, SR>(job, REGION, lane, acc);
-#pragma unroll
-        for (int i = 0; i < T1; ++i)
-            if (wave + i * WAVES < HT)
-#pragma unroll
-                for (int c = 0; c < C; ++c) lds_st(h2v + c * REGION, wave + i * WAVES, lane, silu4(acc[i][c]));
-    }
+    for (int t = wave; t < HT; t += WAVES)
+        lds_st(h2v, t, lane, silu4(dense_tile_lds<HT>(wb + lo.W2, t, h1v, lane, ld_vec(wb + lo.b2, t, lane))));
     __syncthreads();
+    float part = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        float part = 0.f;
-#pragma unroll
-        for (int t = 0; t < HT; ++t) {
-            const f4 m = lds_blk(h2v + c * REGION, t, lane), w = ld_vec(wb + lo.watt, t, lane);
-            part += m.x * w.x + m.y * w.y + m.z * w.z + m.w * w.w;
-        }
-        const float gate = silu1(col_reduce(part) + wb[lo.batt]);
-        const size_t eid = (size_t)tp.row_eid[row[c]];
-        for (int t = wave; t < HT; t += WAVES) {
-            const f4 m = lds_blk(h2v + c * REGION, t, lane) * gate;
-            lds_st(h1v + c * REGION, t, lane, m);                  // h1 is dead since the barrier above
-            if (valid[c]) st_blk(mbuf, eid, D::HP, t, lane, m);
-        }
+    for (int t = 0; t < HT; ++t) {
+        const f4 m = lds_blk(h2v, t, lane), w = ld_vec(wb + lo.watt, t, lane);
+        part += m.x * w.x + m.y * w.y + m.z * w.z + m.w * w.w;
+    }
+    const float gate = silu1(col_reduce(part) + wb[lo.batt]);
+    const size_t eid = (size_t)tp.row_eid[row];
+    for (int t = wave; t < HT; t += WAVES) {
+        const f4 m = lds_blk(h2v, t, lane) * gate;
+        lds_st(h1v, t, lane, m);                                   // h1 is dead since the barrier above
+        if (valid) st_blk(mbuf, eid, D::HP, t, lane, m);
     }
     if (!DO_S3) return;
     __syncthreads();
-    {
-        TileJob job[T3];
-        f4 acc[T3][C];
-#pragma unroll
-        for (int i = 0; i < T3; ++i) {
-            const int t = min(wave + i * WAVES, WB - 1);
-            job[i] = tile_job<HT>(wb + lo.W3, t, h1v);
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[i][c] = ld_vec(wb + lo.b3, t, lane);
-        }
-        dense_seq_cols<HT, T3, C, SG, SR>(job, REGION, lane, acc);
-#pragma unroll
-        for (int i = 0; i < T3; ++i) {
-            const int t = wave + i * WAVES;
-            if (t < WB)
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const f4 old = DO_S1 ? lds_blk(ewv + c * REGION, t, lane) : ld_vec(c0, t, lane);
-                    if (valid[c]) st_f4(erow[c] + 16 * t, old + silu4(acc[i][c]));
-                }
-        }
+    for (int t = wave; t < WB; t += WAVES) {
+        const f4 acc = dense_tile_lds<HT>(wb + lo.W3, t, h1v, lane, ld_vec(wb + lo.b3, t, lane));
+        const f4 old = DO_S1 ? lds_blk(ewv, t, lane) : ld_vec(c0, t, lane);
+        if (valid) st_f4(erow + 16 * t, old + silu4(acc));
     }
 }
 
-template <class D, int C = 1>
+template <class D>
 struct EquiSmall {
-    // d1 overwrites the edge state after a barrier (the stage-1 outputs wait in registers), so that two column tiles fit in LDS
-    static constexpr int REGION = (D::WB + D::RB) * 256;
-    static constexpr size_t LDS_BYTES = (size_t)C * REGION * 4;
+    static constexpr size_t LDS_BYTES = (size_t)(D::WB + D::D1T + D::RB) * 1024;
 };
 
 // EquiMessage edge part on inner edges:  d1 = SiLU(dir_proj.0 ew);  q = (dir_proj.2 d1 + b) * (rbf_proj rbf)
 // -> qbuf[a][3][HP]  (what k_equi_node_v1 consumes)
-template <class D, int WAVES, int C = 1>
+template <class D, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_small(TopoDev tp, const float* __restrict__ wb, LayerOff lo,
                                                                 const float* __restrict__ ew,
                                                                 const float* __restrict__ rbuf, float* __restrict__ qbuf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT, REGION = EquiSmall<D, C>::REGION;
-    static_assert(D1T <= WB, "d1 reuses the edge-state blocks");
-    float* ewv = smem;                      // [WB] edge state, then [D1T] d1 (column tile c: + c * REGION)
-    float* rbv = smem + WB * 256;           // [RB]
+    constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT;
+    float* ewv = smem;                      // [WB]
+    float* d1v = smem + WB * 256;           // [D1T]
+    float* rbv = d1v + D1T * 256;           // [RB]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    bool valid[C];
-    size_t a[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const long long col = ((long long)blockIdx.x * C + c) * 16 + (lane & 15);
-        valid[c] = col < tp.A;
-        a[c] = (size_t)(valid[c] ? col : tp.A);                        // spare entry A for the padding columns
-        const float* erow = ew + (valid[c] ? a[c] : (size_t)tp.E) * D::WP + 4 * g;  // inner entry a == physical row a
-        for (int b = wave; b < WB + RB; b += WAVES) {
-            if (b < WB) lds_st(ewv + c * REGION, b, lane, ld_f4(erow + 16 * b));
-            else lds_st(rbv + c * REGION, b - WB, lane, ld_blk(rbuf, a[c], D::RP, b - WB, lane));
-        }
+    const long long c = (long long)blockIdx.x * 16 + (lane & 15);
+    const bool valid = c < tp.A;
+    const size_t a = (size_t)(valid ? c : tp.A);                       // spare entry A for the padding columns
+    const float* erow = ew + (valid ? a : (size_t)tp.E) * D::WP + 4 * g;  // inner entry a == physical row a
+    for (int b = wave; b < WB + RB; b += WAVES) {
+        if (b < WB) lds_st(ewv, b, lane, ld_f4(erow + 16 * b));
+        else lds_st(rbv, b - WB, lane, ld_blk(rbuf, a, D::RP, b - WB, lane));
     }
     __syncthreads();
-    constexpr int SG = 7, SR = 3;
-    constexpr int T1 = (D1T + WAVES - 1) / WAVES, T2 = (3 * HT + WAVES - 1) / WAVES;
-    {
-        TileJob job[T1];
-        f4 acc[T1][C];
-#pragma unroll
-        for (int i = 0; i < T1; ++i) {
-            const int t = min(wave + i * WAVES, D1T - 1);
-            job[i] = tile_job<WB>(wb + lo.dp0, t, ewv);
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[i][c] = ld_vec(wb + lo.dp0b, t, lane);
-        }
-        dense_seq_cols<WB, T1, C, SG, SR>(job, REGION, lane, acc);
-        __syncthreads();                                               // every wave has read the edge state: d1 may overwrite it
-#pragma unroll
-        for (int i = 0; i < T1; ++i)
-            if (wave + i * WAVES < D1T)
-#pragma unroll
-                for (int c = 0; c < C; ++c) lds_st(ewv + c * REGION, wave + i * WAVES, lane, silu4(acc[i][c]));
-    }
+    for (int t = wave; t < D1T; t += WAVES)
+        lds_st(d1v, t, lane, silu4(dense_tile_lds<WB>(wb + lo.dp0, t, ewv, lane, ld_vec(wb + lo.dp0b, t, lane))));
     __syncthreads();
-    {
-        TileJob jd[T2], jr[T2];
-        f4 cd[T2][C], cr[T2][C];
-#pragma unroll
-        for (int i = 0; i < T2; ++i) {
-            const int t = min(wave + i * WAVES, 3 * HT - 1);
-            jd[i] = tile_job<D1T>(wb + lo.dp2, t, ewv);
-            jr[i] = tile_job<RB>(wb + lo.rbfp, t, rbv);
-#pragma unroll
-            for (int c = 0; c < C; ++c) { cd[i][c] = ld_vec(wb + lo.dp2b, t, lane); cr[i][c] = f4zero(); }
-        }
-        dense_seq_cols<D1T, T2, C, SG, SR>(jd, REGION, lane, cd);
-        dense_seq_cols<RB, T2, C, SG, SR>(jr, REGION, lane, cr);
-#pragma unroll
-        for (int i = 0; i < T2; ++i) {
-            const int t = wave + i * WAVES;
-            if (t < 3 * HT)
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    if (valid[c]) st_f4(qbuf + a[c] * (size_t)(3 * D::HP) + 4 * g + 16 * t, cd[i][c] * cr[i][c]);   // t = th * HT + tt
-        }
+    float* qrow = qbuf + a * (size_t)(3 * D::HP) + 4 * g;
+    for (int t = wave; t < 3 * HT; t += WAVES) {
+        const f4 cd = dense_tile_lds<D1T>(wb + lo.dp2, t, d1v, lane, ld_vec(wb + lo.dp2b, t, lane));
+        const f4 cr = dense_tile_lds<RB>(wb + lo.rbfp, t, rbv, lane, f4zero());
+        if (valid) st_f4(qrow + 16 * t, cd * cr);                       // t = th * HT + tt  ->  offset th * HP + 16 tt
     }
 }
 

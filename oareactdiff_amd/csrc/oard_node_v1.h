@@ -90,36 +90,6 @@ OARD_DEV void dense_seq(const TileJob (&job)[N], int lane, f4 (&acc)[N]) {
         if (q == NG - 1) { acc[j] += c1; c1 = f4zero(); }
     }
 }
-// The same for C column tiles (16 C columns) that share every weight chunk: the activations of column tile c live `cstride` floats
-// behind those of tile 0 (latency edge kernels, oard_edge_small.h).
-template <int KB, int N, int C, int G = OARD_NODE_SEQ_G, int R = 2>
-OARD_DEV void dense_seq_cols(const TileJob (&job)[N], int cstride, int lane, f4 (&acc)[N][C]) {
-    constexpr int NG = (KB + G - 1) / G, S = N * NG;
-    f4 a[R][G];
-    auto fetch = [&](int st) {
-        const int j1 = st / NG, q1 = st % NG;
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-            if (q1 * G + i < KB) a[st % R][i] = ld_f4(job[j1].w + (size_t)(q1 * G + i) * 256 + lane * 4);
-    };
-#pragma unroll
-    for (int st = 0; st < R - 1; ++st)
-        if (st < S) fetch(st);
-#pragma unroll
-    for (int st = 0; st < S; ++st) {
-        const int j = st / NG, q = st % NG;
-        if (st + R - 1 < S) fetch(st + R - 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < G; ++i)
-            if (q * G + i < KB) {
-#pragma unroll
-                for (int c = 0; c < C; ++c)            // C independent accumulators: consecutive MFMAs never depend on each other
-                    acc[j][c] = mma_chunk(a[st % R][i], lds_blk(job[j].in + c * cstride, q * G + i, lane), acc[j][c]);
-            }
-    }
-}
-
 // LayerNorm statistics of an LDS vector (every wave computes them redundantly)
 template <int HT, int H>
 OARD_DEV void ln_stats_lds(const float* v, int lane, float& mean, float& rstd) {
