@@ -173,7 +173,9 @@ int oard_debug_stop_after(int code);
  *                       oard_topology_create;  "sequential" [0] = 1 runs them one after the other
  *   "poison" [0]        1 fills the workspace with NaN bit patterns before every forward (the tests use it to
  *                       prove that nothing depends on workspace contents)
- *   "wgrad_wgs" [512]   workgroups per weight-gradient GEMM (oard_wgrad): row chunks x task groups */
+ *   "wgrad_wgs" [512]   workgroups per weight-gradient GEMM (oard_wgrad): row chunks x task groups
+ *   "small_split" [128] EquiMessage latency kernel: launches of <= this many 16-edge tiles run one launch per dense stage
+ *                       (k_equi_small_s1 / _s2, a tile spread over several CUs); 0 = never */
 int oard_debug_option(const char* name, int value);
 
 /* Average duration (ms) and launch count per kernel family since the last reset, measured with
