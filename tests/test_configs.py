@@ -11,7 +11,7 @@ import torch
 
 import leftnet_oracle as oracle
 import sampler_oracle as so
-from _cases import Case, debug_options, rel
+from _cases import LIB_AUTO, Case, debug_options, rel
 from oareactdiff_amd.graph_tools import get_edges_index, get_mask_for_frag, get_n_frag_switch
 from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
 from oareactdiff_amd.synthetic import make_inputs, make_topology
@@ -172,3 +172,32 @@ def test_topology_cache_entries_pin_their_key_tensors():
         want = run(fresh, sizes, 3)
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("npb", [1, 2, 3, 4, 16])
+def test_small_batch_node_shapes_reproduce_the_golden_reactions(npb):
+    """The per-layer node kernels gather with the wave's 16 columns walking the ROWS when a workgroup holds <= 4 nodes
+    (row_lanes: 16 / 8 / 4 lanes per node for npb = 1 / 2 / 3-4) and with one column per node otherwise.  B = 8 reactions
+    under the library's launch heuristics (latency edge kernels) and every such npb, with the two reactions of golden g2
+    (reference float64 outputs) in slots 0, 1 and 6, 7."""
+    dev = torch.device("cuda:0")
+    c = Case("g2_prod_b2_n23")
+    B, nf = 8, 23
+    with debug_options(**dict(LIB_AUTO, npb=npb)):
+        dyn, _, _ = _prod_dynamics(dev, c.cfg)
+        cm, nfs, ei, masks = make_topology(B, nf)
+        xh = make_inputs(B, nf, masks, 5, "cpu")
+        g = torch.Generator().manual_seed(2)
+        t, cond = torch.rand(B, 1, generator=g), torch.rand(B, 1, generator=g)
+        for slot0 in (0, 6):
+            for k in range(3):
+                xh[k][slot0 * nf:(slot0 + 2) * nf] = c.xh[k]
+            t[slot0:slot0 + 2], cond[slot0:slot0 + 2] = c.t, c.conditions
+        with torch.no_grad():
+            out, _ = dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+    rv, rh = c.split(c.ref64)
+    for slot0 in (0, 6):
+        got = [o[slot0 * nf:(slot0 + 2) * nf].cpu() for o in out]
+        v, h = c.split(got)
+        print(f"npb={npb} slots {slot0},{slot0 + 1}: vel {rel(v, rv):.2e} h {rel(h, rh):.2e}")
+        assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
