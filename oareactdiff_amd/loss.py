@@ -164,7 +164,11 @@ class DiffusionLoss:
 
     # ---- DDPMModule.compute_loss -------------------------------------------------------------------------------
     def compute_loss(self, representations: List[Dict[str, Tensor]], conditions: Tensor, training: bool = False,
-                     t_int: Optional[Tensor] = None, draw: Optional[Callable] = None) -> Tuple[Tensor, Dict[str, float]]:
+                     t_int: Optional[Tensor] = None, draw: Optional[Callable] = None,
+                     lazy_info: bool = False) -> Tuple[Tensor, Dict[str, float]]:
+        """lazy_info: keep the logged means as 0-dim device tensors instead of calling .item() here - the reference's .item()
+        (pl_trainer.py:268-277) is a host sync between the forward and the backward pass, during which the GPU runs dry while
+        the host enqueues the first backward kernels; DDPMTrainer.training_step converts them after the optimiser step."""
         lt = self.loss_terms(representations, conditions, training=training, t_int=t_int, draw=draw)
         K = len(representations)
         width = [self.pos_dim if self.pos_only else self.pos_dim + self.node_nfs[k] for k in range(K)]
@@ -183,8 +187,9 @@ class DiffusionLoss:
         nll = loss_t + loss_0 + lt["kl_prior"]
         info = {}
         for k in range(K):
-            info[f"error_t_{k}"] = err_n[k].mean().item() / (self.scales[k] + 1e-4)
-            info[f"unorm_error_t_{k}"] = lt["error_t"][k].mean().item()
+            e_n, e_u = err_n[k].detach().mean() / (self.scales[k] + 1e-4), lt["error_t"][k].detach().mean()
+            info[f"error_t_{k}"] = e_n if lazy_info else e_n.item()
+            info[f"unorm_error_t_{k}"] = e_u if lazy_info else e_u.item()
         if not plain_l2:
             nll = nll - lt["delta_log_px"] - lt["log_pN"]
         return nll, info

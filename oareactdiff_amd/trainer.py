@@ -114,7 +114,7 @@ class DDPMTrainer:
     def training_step(self, batch, **kw) -> Dict[str, float]:
         """`kw` (t_int=, draw=) injects the step's randomness for tests; by default it is drawn like the reference does."""
         self.flat_grad.zero_()
-        nll, info = self.compute_loss(batch, training=True, **kw)
+        nll, info = self.compute_loss(batch, training=True, lazy_info=True, **kw)   # logged means stay on the device until the end
         loss = nll.mean(0)                             # pl_trainer.py:329
         loss.backward()
         self.all_reduce_gradients()
@@ -122,4 +122,4 @@ class DDPMTrainer:
             info["grad_norm"], info["max_grad_norm"] = self.clip_gradients()
         self.optimizer.step()
         info["loss"] = float(loss.detach())
-        return info
+        return {k: (float(v) if isinstance(v, Tensor) else v) for k, v in info.items()}

@@ -269,6 +269,15 @@ class TrainTopology:
         self.inner_src = table(_capi.TOPO_INNER_SRC, self.A)
         self.inner_tgt = table(_capi.TOPO_INNER_TGT, self.A)
         self.node_group = self.node_sample * cfg.n_obj + self.node_obj
+        # rows of every object and the size of every (sample, object) group, built once here: a nonzero() in the backward sweep
+        # would be a host sync right after the forward pass
+        order = torch.argsort(self.node_obj, stable=True)
+        starts = [0]
+        for k in range(cfg.n_obj):
+            starts.append(starts[-1] + self.obj_counts[k])
+        self.obj_rows = [order[starts[k]:starts[k + 1]] for k in range(cfg.n_obj)]
+        self.group_count = torch.zeros(self.B * cfg.n_obj, 1, device=dev).index_add_(
+            0, self.node_group, torch.ones(self.N, 1, device=dev)).clamp(min=1)
         if edge_index is not None:       # the kernels assume the complete-per-sample graph in the reference's edge order: verify
             ei = edge_index.detach()
             if ei.dim() != 2 or ei.shape[0] != 2 or ei.dtype != torch.int64 or ei.device != dev:
@@ -418,12 +427,11 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
     # ---- output block + wrapper epilogue (k_out_v1, k_post; egnn_dynamics.py:137-160) ------------------------------
     s_L = tape.get(_capi.TAPE_S_IN, NL)[:, :H]
     vec_L = tape.get(_capi.TAPE_VEC_IN, NL).view(N, 3, HP)[:, :, :H]
-    obj_rows = [(topo.node_obj == k).nonzero(as_tuple=True)[0] for k in range(n_obj)]
+    obj_rows = topo.obj_rows
 
     def tail(s, vec):
         dpos, hout = stage_out(P, s, vec)
-        vel = dpos - (_seg_sum(dpos, topo.node_group, topo.B * n_obj) /
-                      _seg_sum(torch.ones_like(dpos[:, :1]), topo.node_group, topo.B * n_obj).clamp(min=1))[topo.node_group]
+        vel = dpos - (_seg_sum(dpos, topo.node_group, topo.B * n_obj) / topo.group_count)[topo.node_group]
         outs = []
         for k in range(n_obj):
             rows = obj_rows[k]
