@@ -22,7 +22,16 @@ OARD_DEV float dsilu1(float x) {           // d/dx [x sigmoid(x)] = s (1 + x (1 
     const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
     return s * (1.0f + x * (1.0f - s));
 }
-OARD_DEV f4 dsilu4(f4 v) { return (f4){dsilu1(v.x), dsilu1(v.y), dsilu1(v.z), dsilu1(v.w)}; }
+// four values with the plain arithmetic as packed two-float operations (as silu4: VALU instructions take MFMA issue time)
+OARD_DEV f4 dsilu4(f4 v) {
+    const f2 a = {v.x, v.y}, b = {v.z, v.w};
+    const f2 ta = a * -1.44269504088896340736f, tb = b * -1.44269504088896340736f;
+    const f2 da = (f2){__builtin_amdgcn_exp2f(ta.x), __builtin_amdgcn_exp2f(ta.y)} + 1.0f;
+    const f2 db = (f2){__builtin_amdgcn_exp2f(tb.x), __builtin_amdgcn_exp2f(tb.y)} + 1.0f;
+    const f2 sa = {__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y)}, sb = {__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y)};
+    const f2 ra = sa * (a * (1.0f - sa) + 1.0f), rb = sb * (b * (1.0f - sb) + 1.0f);       // s (1 + x (1 - s))
+    return (f4){ra.x, ra.y, rb.x, rb.y};
+}
 
 // =====================================================================================================
 // GCLMessage edge part, backward.  Stream (chunks, all groups HT wide, no bias chunks):
