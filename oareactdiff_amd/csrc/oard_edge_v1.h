@@ -166,6 +166,7 @@ OARD_DEV f4 chain_tile4(const float* sl, int j0, const f4 (&in)[KB], f4 init, Ho
         mma4_chunk(a1, in[b + 1], c0, c1);
         hook();
         a0 = n0; a1 = n1;
+        __builtin_amdgcn_sched_barrier(0);          // 4x4x1 MFMAs are short: left alone, hipcc hoists the LDS reads of many pairs (spills)
     }
     if (KB & 1) mma4_chunk(a0, in[KB - 1], c0, c1);
     return c0 + c1;
@@ -208,9 +209,11 @@ OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook ho
 #ifndef OARD_PF_PERIOD
 #define OARD_PF_PERIOD 1
 #endif
-template <int WAVES, int SLAB>
+// HALF / PERIOD are per kernel: the EquiMessage kernel (37 live accumulators) spills 330 bytes per lane with the GCL kernel's policy
+// and runs equally fast with all waves issuing every third pair, so it keeps that.
+template <int WAVES, int SLAB, int HALF = OARD_PF_HALF, int PERIOD = OARD_PF_PERIOD>
 struct SlabPrefetch {
-    static constexpr int IW = (OARD_PF_HALF && WAVES >= 8) ? WAVES / 2 : WAVES;       // issuing waves
+    static constexpr int IW = (HALF && WAVES >= 8) ? WAVES / 2 : WAVES;               // issuing waves
     static constexpr int KMAX = (SLAB + IW - 1) / IW;          // pieces per issuing wave per phase (upper bound)
     const float* src;       // wave-uniform
     float* dst;
@@ -243,7 +246,7 @@ struct SlabPrefetch {
 #ifdef OARD_ABL_NOHOOK
     OARD_DEV void tick() {}
 #else
-    OARD_DEV void tick() { if (--next == 0) { one(); next = OARD_PF_PERIOD; } }
+    OARD_DEV void tick() { if (--next == 0) { one(); next = PERIOD; } }
 #endif
 #endif
     OARD_DEV void flush() { while (k < KMAX) one(); }
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
     const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    SlabPrefetch<WAVES, S::SLAB> pf;
+    SlabPrefetch<WAVES, S::SLAB, 0, 3> pf;
     pf.wave = wave;
     pf.lane_off = (unsigned)lane * 16u;              // LDS-DMA source = uniform chunk address (SGPR pair) + this 32-bit lane offset
     auto pf_begin = [&](int p) {
@@ -600,7 +603,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
     float* cdrow = TRAIN ? cdbuf + a * (size_t)(3 * D::HP) + 4 * g : nullptr;
     f4 pend = f4zero(), pendc = f4zero();
     int pend_off = 0;
-    for (int i = 0; i < S::NG2; ++i, ++p) {
+    // slots are tile-major (slot i = 3 tt + th): the 4-row tiles (tt = HT - 1) are the last three slots and get their own loop,
+    // so that each loop body holds ONE chain variant (both in one body cost 320 bytes of scratch per lane)
+    auto t2_phase = [&](int i, auto rows4) {
         phase_barrier();
         if (i > 0) {                                           // stores of the previous phase, issued one phase late
             st_f4(qrow + pend_off, pend);
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
         pf_begin(p + 1);
         const int tt = i / 3, th = i - 3 * tt;
         f4 cd, cr;
-        if (S::ROWS4 && tt == HT - 1) {                        // the 13th tile of every third: 4 real rows, 4x4x1 MFMAs
+        if (decltype(rows4)::value) {                          // the 13th tile of every third: 4 real rows, 4x4x1 MFMAs
             cd = reduce_g(chain_tile4<D1T>(SL(p), 1, d1, A(p, 0), hook));
             cr = reduce_g(chain_tile4<RB>(SL(p), 1 + D1T, rb, f4zero(), hook));
             if (g != 0) { cd = f4zero(); cr = f4zero(); }
@@ -621,7 +626,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
         pend = cd * cr;
         if (TRAIN) pendc = cd;
         pend_off = th * D::HP + 16 * tt;
-    }
+        ++p;
+    };
+    constexpr int N_FULL = S::ROWS4 ? S::NG2 - 3 : S::NG2;
+    for (int i = 0; i < N_FULL; ++i) t2_phase(i, std::false_type{});
+    for (int i = N_FULL; i < S::NG2; ++i) t2_phase(i, std::true_type{});
     st_f4(qrow + pend_off, pend);
     if (TRAIN) st_f4(cdrow + pend_off, pendc);
 }

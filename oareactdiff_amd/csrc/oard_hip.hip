@@ -495,8 +495,11 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                 if (rc != OARD_OK) return rc;
             }
         }
-        if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW>), gN16, NW * 64, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq,
-                        train ? (float*)(tape + to.agg[l]) : nullptr);
+        const bool rows = tp.npb <= 4;                       // small batches: gathers walk the rows with the wave's columns (row_lanes)
+        if (nv1 && rows) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW, true>), gN16, NW * 64, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq,
+                                train ? (float*)(tape + to.agg[l]) : nullptr);
+        else if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW, false>), gN16, NW * 64, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq,
+                             train ? (float*)(tape + to.agg[l]) : nullptr);
         else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
         if (train) HIP_TRY(copy(to.s_mid[l], s, (size_t)N * D::HP * 4));
         if (stop_after == 100 + 10 * l + 1) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
@@ -511,8 +514,12 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                                            train ? (float*)(tape + to.zd1[l]) : nullptr, train ? (float*)(tape + to.cd[l]) : nullptr, st);
                 if (rc != OARD_OK) return rc;
             }
-            if (nv1) {
-                LAUNCH(F_NODE, (k_equi_node_v1<D, NW>), gN16, NW * 64, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
+            if (nv1 && rows) {
+                LAUNCH(F_NODE, (k_equi_node_v1<D, NW, true>), gN16, NW * 64, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
+                       (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext,
+                       train ? (float*)(tape + to.s_a[l]) : nullptr, train ? (float*)(tape + to.vec_a[l]) : nullptr);
+            } else if (nv1) {
+                LAUNCH(F_NODE, (k_equi_node_v1<D, NW, false>), gN16, NW * 64, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
                        (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext,
                        train ? (float*)(tape + to.s_a[l]) : nullptr, train ? (float*)(tape + to.vec_a[l]) : nullptr);
             } else {

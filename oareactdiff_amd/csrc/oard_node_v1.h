@@ -236,7 +236,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_node_pre_v1(TopoDev tp, const fl
 // =====================================================================================================
 // agg = mean_e m_e;  s = xh + node_mlp([xh, agg]);  xq = x_proj(LN_msg(s))           (see k_gcl_node)
 // =====================================================================================================
-template <class D, int WAVES>
+// ROWS: the small-batch gather (row_lanes, <= 4 nodes per workgroup) - its own instantiation, chosen at launch
+template <class D, int WAVES, bool ROWS = false>
 __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const float* __restrict__ wb, LayerOff lo,
                                                             const float* __restrict__ xh, const float* __restrict__ mbuf,
                                                             float* __restrict__ s, float* __restrict__ xq,
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
     for (int t = nb.wave; t < D::HT; t += WAVES) {
         lds_st(in, t, nb.lane, ld_blk(xh, nb.n, D::HP, t, nb.lane));
         f4 a0 = f4zero(), a1 = f4zero();
-        if (tp.npb <= 4) {                                      // small batches: the wave's columns walk the rows (row_lanes)
+        if (ROWS) {                                             // small batches: the wave's columns walk the rows (row_lanes)
             const RowLanes rl = row_lanes(tp.N, tp.npb, nb.lane);
             const int nn = min(blockIdx.x * tp.npb + rl.node, tp.N - 1);
             const int smp2 = tp.node_sample[nn];
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
         }
         // 8 message rows in flight per step (branch-free: out-of-range slots re-read the last row with weight 0)
         const int last = max(deg - 1, 0);
-        for (int k = 0; tp.npb > 4 && k < mx; k += 8) {
+        for (int k = 0; !ROWS && k < mx; k += 8) {
             f4 r[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) r[i] = ld_blk(mbuf, e0 + min(k + i, last), D::HP, t, nb.lane);
@@ -406,7 +407,7 @@ OARD_DEV float lin3u1(const float* l3s, const float* __restrict__ p, float x) {
 //   messages from q, aggregation, s = (s + dx)/sqrt2, vec += dvec, vec_proj, frame scalar MLP,
 //   xvec_proj, s += (a + b + vdot)/sqrt2, vec += c * vec2.        vec_in != vec_out.
 // =====================================================================================================
-template <class D, int WAVES>
+template <class D, int WAVES, bool ROWS = false>
 __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const float* __restrict__ wb, LayerOff lo,
                                                              const float* __restrict__ qbuf, const float* __restrict__ xq,
                                                              const float* __restrict__ geo, const float* __restrict__ x1,
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         const f4 xn0 = ld_blk(xq, n, 3 * D::HP, t, nb.lane), xn1 = ld_blk(xq, n, 3 * D::HP, HT + t, nb.lane),
                  xn2 = ld_blk(xq, n, 3 * D::HP, 2 * HT + t, nb.lane);
         const long long a_hi = max(tp.A - 1, 0LL);
-        if (tp.npb <= 4) {                                      // small batches: the wave's columns walk the edges (row_lanes)
+        if (ROWS) {                                             // small batches: the wave's columns walk the edges (row_lanes)
             const RowLanes rl = row_lanes(tp.N, tp.npb, nb.lane);
             const int nn = min(blockIdx.x * tp.npb + rl.node, tp.N - 1);
             const int b0 = tp.act_ptr[nn], cnt2 = rl.live ? tp.act_ptr[nn + 1] - b0 : 0;
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         int mnext[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) mnext[i] = tp.act_src[(size_t)min((long long)a0 + min(i, max(cnt - 1, 0)), a_hi)];
-        for (int k = 0; tp.npb > 4 && k < mx; k += 2) {
+        for (int k = 0; !ROWS && k < mx; k += 2) {
             f4 q0[2], q1[2], q2[2], y0[2], y1[2], y2[2], w0[2], w1[2], w2[2];
             float gx[2], gy[2], gz[2];
             const int mc[2] = {mnext[0], mnext[1]};
