@@ -540,7 +540,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                 job[2 * x + 1] = tile_job<HT>(wb + lo.vp, HT + t, vx + x * HT * 256);
                 acc[2 * x] = f4zero(); acc[2 * x + 1] = f4zero();
             }
-            dense_seq<HT, 6>(job, nb.lane, acc);
+            dense_seq<HT, 6, (ROWS ? 5 : OARD_NODE_SEQ_G)>(job, nb.lane, acc);      // 5: no scratch in the small-batch instantiation
             const f4 v1[3] = {acc[0], acc[2], acc[4]}, v2[3] = {acc[1], acc[3], acc[5]};
 #pragma unroll
             for (int x = 0; x < 3; ++x) v2k[i][x] = v2[x];
