@@ -1,0 +1,141 @@
+"""Row N4: reading the reference's Lightning checkpoint FILE on a box that has neither `oa_reactdiff` nor
+`pytorch_lightning` (the GPU box).  `DDPMModule.save_hyperparameters()` pickles the class object `model=LEFTNet`
+(oa_reactdiff/trainer/pl_trainer.py:77,147; restored by demo.py:269), so plain `torch.load` needs the package.
+
+The file is written here with stand-in classes registered under the reference's module paths in throw-away modules,
+which are removed again before loading."""
+import os
+import pickle
+import sys
+import types
+
+import pytest
+import torch
+
+from _cases import Case, rel
+
+
+def _write_reference_style_ckpt(path, c, pos_only=True):
+    """A file as Lightning's `trainer.save_checkpoint` leaves it for `DDPMModule` (keys of lightning 2.x `dump_checkpoint`)."""
+    created = []
+
+    def module(name):
+        parts = name.split(".")
+        for i in range(1, len(parts) + 1):
+            n = ".".join(parts[:i])
+            if n not in sys.modules:
+                sys.modules[n] = types.ModuleType(n)
+                created.append(n)
+        return sys.modules[name]
+
+    leftnet = module("oa_reactdiff.model.leftnet")
+
+    class LEFTNet(torch.nn.Module):                     # what `hyper_parameters["model"]` holds: the CLASS (pl_trainer.py:77)
+        pass
+    LEFTNet.__module__, LEFTNet.__qualname__ = "oa_reactdiff.model.leftnet", "LEFTNet"
+    leftnet.LEFTNet = LEFTNet
+    parsing = module("pytorch_lightning.utilities.parsing")
+
+    class AttributeDict(dict):                          # Lightning wraps nested hyper-parameter dicts in this
+        pass
+    AttributeDict.__module__, AttributeDict.__qualname__ = "pytorch_lightning.utilities.parsing", "AttributeDict"
+    parsing.AttributeDict = AttributeDict
+    cb = module("pytorch_lightning.callbacks.model_checkpoint")
+
+    class ModelCheckpoint:                              # an arbitrary object with state inside `callbacks`
+        def __init__(self):
+            self.best_k = {"a.ckpt": torch.tensor(0.25)}
+    ModelCheckpoint.__module__, ModelCheckpoint.__qualname__ = "pytorch_lightning.callbacks.model_checkpoint", "ModelCheckpoint"
+    cb.ModelCheckpoint = ModelCheckpoint
+
+    sd = c.state_dict()
+    state = {"ddpm.dynamics." + k: v for k, v in sd.items()}
+    state["ddpm.schedule.gamma_module.gamma"] = torch.linspace(-5, 5, 1001)
+    ckpt = {
+        "epoch": 1999, "global_step": 123456, "pytorch-lightning_version": "2.0.4",
+        "state_dict": state,
+        "loops": {"fit_loop": {"state_dict": {}, "epoch_progress": AttributeDict(total=AttributeDict(ready=3))}},
+        "callbacks": {"ModelCheckpoint{'monitor': 'val-totloss'}": {"best_model_score": torch.tensor(1.5), "obj": ModelCheckpoint()}},
+        "optimizer_states": [{"state": {0: {"step": torch.tensor(7.0), "exp_avg": torch.zeros(3)}}, "param_groups": [{"lr": 2.5e-4}]}],
+        "lr_schedulers": [],
+        "hparams_name": "kwargs",
+        "hyper_parameters": dict(
+            model_config=AttributeDict(c.cfg), optimizer_config=dict(lr=2.5e-4, betas=[0.9, 0.999], weight_decay=0, amsgrad=True),
+            training_config=dict(remove_h=False, clip_grad=True, bz=14), node_nfs=list(c.node_nfs), edge_nf=0,
+            condition_nf=c.cnf, fragment_names=["R", "TS", "P"], pos_dim=3, update_pocket_coords=True, condition_time=True,
+            edge_cutoff=None, norm_values=[1.0, 4.0, 10.0], norm_biases=(0.0, 0.0, 0.0), noise_schedule="polynomial_2",
+            timesteps=5000, precision=1e-5, loss_type="l2", pos_only=pos_only, process_type="TS1x", model=LEFTNet,
+            enforce_same_encoding=None, scales=[1.0, 2.0, 1.0], eval_epochs=10, source=None, fixed_idx=None),
+    }
+    torch.save(ckpt, path)
+    for n in created:                                   # the reference / Lightning packages do not exist on the loading side
+        del sys.modules[n]
+
+
+def test_checkpoint_file_loads_without_the_reference_package(tmp_path):
+    from oareactdiff_amd.checkpoint import Placeholder, load_checkpoint, read_checkpoint
+    c = Case("g2_prod_b2_n23")
+    path = os.path.join(tmp_path, "pretrained-like.ckpt")
+    _write_reference_style_ckpt(path, c)
+    assert "oa_reactdiff" not in sys.modules
+    # what INTEGRATION.md used to recommend cannot work here: the default loader refuses the class global,
+    # the unrestricted one needs `oa_reactdiff` importable
+    with pytest.raises(pickle.UnpicklingError):
+        torch.load(path, map_location="cpu")
+    with pytest.raises(ModuleNotFoundError):
+        torch.load(path, map_location="cpu", weights_only=False)
+    raw = read_checkpoint(path)
+    model = raw["hyper_parameters"]["model"]
+    assert isinstance(model, type) and issubclass(model, Placeholder)
+    assert (model.__module__, model.__name__) == ("oa_reactdiff.model.leftnet", "LEFTNet")
+    assert float(raw["callbacks"]["ModelCheckpoint{'monitor': 'val-totloss'}"]["best_model_score"]) == 1.5
+    assert torch.equal(raw["optimizer_states"][0]["state"][0]["exp_avg"], torch.zeros(3))
+    dyn, hp = load_checkpoint(path, device=torch.device("cpu"))
+    sd, got = c.state_dict(), dyn.state_dict()
+    assert list(got.keys()) == list(sd.keys()) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert isinstance(hp["model_config"], dict) and hp["model_config"]["hidden_channels"] == c.cfg["hidden_channels"]
+    assert hp["timesteps"] == 5000 and hp["pos_only"] is True and hp["norm_values"] == [1.0, 4.0, 10.0]
+    assert "oa_reactdiff" not in sys.modules and "pytorch_lightning" not in sys.modules     # nothing was imported
+
+
+def test_restricted_unpickler_executes_nothing(tmp_path):
+    """A pickle that would run code under a plain `pickle.load` (`os.system` via __reduce__) yields an inert placeholder."""
+    from oareactdiff_amd.checkpoint import Placeholder, read_checkpoint
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("touch " + os.path.join(tmp_path, "pwned"),))
+    path = os.path.join(tmp_path, "evil.ckpt")
+    torch.save({"state_dict": {"w": torch.ones(2)}, "hyper_parameters": {"x": Evil()}}, path)
+    raw = read_checkpoint(path)
+    assert isinstance(raw["hyper_parameters"]["x"], Placeholder)
+    assert not os.path.exists(os.path.join(tmp_path, "pwned"))
+
+
+def test_checkpoint_of_another_model_is_rejected(tmp_path):
+    from oareactdiff_amd.checkpoint import dynamics_from_checkpoint
+    c = Case("g3_cutoff_ragged")
+
+    class EGNN:
+        pass
+    with pytest.raises(NotImplementedError):
+        dynamics_from_checkpoint({"state_dict": {}, "hyper_parameters": dict(model_config=dict(c.cfg), node_nfs=c.node_nfs,
+                                                                             model=EGNN)}, device=torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_checkpoint_file_to_hip_forward_matches_reference_f64(tmp_path):
+    """ckpt file -> restricted load -> HIP forward == the reference's float64 output on the production-dims golden."""
+    from oareactdiff_amd.checkpoint import load_checkpoint
+    dev = torch.device("cuda:0")
+    c = Case("g2_prod_b2_n23")
+    path = os.path.join(tmp_path, "pretrained-like.ckpt")
+    _write_reference_style_ckpt(path, c)
+    dyn, hp = load_checkpoint(path, device=dev)
+    with torch.no_grad():
+        out, _ = dyn([x.to(dev) for x in c.xh], c.edge_index.to(dev), c.t.to(dev), c.conditions.to(dev),
+                     c.n_frag_switch.to(dev), c.combined_mask.to(dev))
+    v, h = c.split([o.cpu() for o in out])
+    rv, rh = c.split(c.ref64)
+    print(f"ckpt -> HIP forward: vel {rel(v, rv):.2e} h {rel(h, rh):.2e}")
+    assert rel(v, rv) <= 1e-5 and rel(h, rh) <= 1e-5
