@@ -1,7 +1,10 @@
 """bench.py — denoising-step throughput of the HIP path on synthetic 23-atom R/TS/P triples.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1, either form (one process per GPU, backend nccl = RCCL):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...      (no WORLD_SIZE in the environment: bench.py starts that launcher itself as a CHILD
+                                       process before touching the GPU, relays rank 0's JSON line and exits with its code)
 
 A "step" is one EGNNDynamics.forward call (= one denoising step of the T=1000 sampler) on a batch of
 64 reactions per GPU (BASELINE.json configs[1]); reactions are independent, so ranks run replicas with
@@ -211,8 +214,15 @@ def dry_run(args, rank, world, dist, backend):
     from oareactdiff_amd.shard import max_over_ranks
     B = args.batch
 
+    train = args.mode == "train"
+    bucket = torch.full((1024,), float(rank + 1)) if train else None
+
     def step(i):
         time.sleep(0.002 * (rank + 1))                        # ranks differ on purpose: the MAX must pick the slowest
+        if train and dist is not None:                        # the training step holds ONE collective: every rank must reach it
+            bucket.fill_(float(rank + 1))
+            dist.all_reduce(bucket)
+            assert float(bucket[0]) == world * (world + 1) / 2
     for i in range(args.warmup):
         step(i)
     if dist is not None:
@@ -224,15 +234,40 @@ def dry_run(args, rank, world, dist, backend):
         dist.barrier()
     dt = max_over_ranks(time.perf_counter() - t0, dist)
     if rank == 0:
-        print(json.dumps({"metric": "denoising_steps_per_sec", "value": world * B * args.steps / dt, "unit": "reaction-steps/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        print(json.dumps({"metric": "training_steps_per_sec" if train else "denoising_steps_per_sec",
+                          "value": world * B * args.steps / dt, "unit": "reaction-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "dry run (no GPU work)", "batch_per_gpu": B,
-                                     "parallelism": f"replica x{world} (no collective)"}, "dry_run": True,
+                                     "parallelism": f"dp{world} (one all-reduce per step)" if train
+                                     else f"replica x{world} (no collective)"}, "dry_run": True,
                           "backend": backend}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run as a child process.
+    Called before this process has made any HIP call (it never will: the child does the work), so no GPU-initialised
+    process is ever replaced or forked."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)), file=sys.stderr)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=dict(os.environ, OARD_BENCH_SELF_LAUNCHED="1"))
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1])                                       # rank 0's single JSON line
+    sys.stdout.flush()
+    return proc.returncode if proc.returncode != 0 or lines else 1
 
 
 def main():
@@ -251,9 +286,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong job size")
     dist = None
     backend = os.environ.get("OARD_BENCH_BACKEND", "nccl")    # "gloo" only to exercise the N>1 code path on a 1-GPU box
     if backend != "nccl":
@@ -409,7 +446,7 @@ def main():
     # the real sampling loop (row N1): a genuine ancestral sampling run of T steps (T+1 network calls + fused sampler
     # kernel + RNG), timed end to end: the BASELINE metric's reactions/s, MEASURED (T = 1000 unless --quick)
     sampler_leg = train = None
-    if rank == 0 and not os.environ.get("OARD_BENCH_ALLOW_NAN"):
+    if rank == 0 and world == 1 and not os.environ.get("OARD_BENCH_ALLOW_NAN"):      # N > 1: the other ranks wait in a barrier meanwhile
         from oareactdiff_amd.sampler import DiffusionSampler
         frag = [torch.full((B,), nf, dtype=torch.long) for _ in range(3)]
         h0 = [x[:, 3:].clone() for x in inputs[0]]

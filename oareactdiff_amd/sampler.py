@@ -40,6 +40,8 @@ class DiffusionSampler:
         self.norm_values = tuple(norm_values)
         self.norm_biases = tuple(norm_biases)
         self._layout_cache = {}
+        #: upper bound on the pre-drawn noise of the hipGraph-replayed loop (`sample(graph=True)` / small batches)
+        self.noise_block_bytes = 64 << 20
 
     def _layout(self, fragments_nodes: List[Tensor], dev):
         """Batch-layout tensors (masks, combined_mask, edge_index, n_frag_switch) on the device, cached by the
@@ -99,33 +101,56 @@ class DiffusionSampler:
         coef_tab = torch.tensor([[c.alpha_ts, c.c_eps, c.sigma] for c in coefs], dtype=torch.float32, device=dev)      # [T,3]
         # the eager loop's t values, bit for bit: (arange(T + 1) / T)[s + 1]
         t_tab = (torch.arange(timesteps + 1, device=dev, dtype=torch.float32) / timesteps)[torch.tensor([s + 1 for s in steps], device=dev)]
-        draws = [draw(i + 1) for i in range(timesteps)]                  # the eager loop's draw order: call 1 .. T
-        noise_tab = [torch.stack([d[k] for d in draws]) for k in range(n_obj)]                                           # [T, n_k, nf_k]
-        counter = torch.zeros(1, dtype=torch.long, device=dev)
+        # The noise of the steps is drawn in BLOCKS (not all T draws up front: that would be T x the eager loop's memory -
+        # a [T, n, nf] table per object): at most `noise_block_bytes` of draws exist at a time, refilled between replays in
+        # the eager loop's draw order (call 1 .. T), so a seeded run consumes the generator exactly like the eager loop.
+        per_step = 4 * sum(int(x.numel()) for x in za)
+        block = max(1, min(timesteps, self.noise_block_bytes // max(per_step, 1)))
+        noise_tab = [torch.empty((block,) + tuple(x.shape), dtype=torch.float32, device=dev) for x in za]              # [block, n_k, nf_k]
+        counter = torch.zeros(1, dtype=torch.long, device=dev)           # step index (t / coefficient tables)
+        slot = torch.zeros(1, dtype=torch.long, device=dev)              # row of the current block's noise table
         z = [x.clone() for x in za]
         z_new = [torch.empty_like(x) for x in za]
+        next_call = [1]
+
+        def refill(n_rows):
+            for r in range(n_rows):
+                d = draw(next_call[0])
+                next_call[0] += 1
+                for k in range(n_obj):
+                    noise_tab[k][r].copy_(d[k])
+            slot.zero_()
 
         def one_step():
             t_cur = t_tab.index_select(0, counter)                       # [1]: a 1-D t = one value for every node
             coef = coef_tab.index_select(0, counter).view(3)
-            noise = [nt.index_select(0, counter)[0] for nt in noise_tab]
+            noise = [nt.index_select(0, slot)[0] for nt in noise_tab]
             eps_hat, _ = dyn(z, edge_index, t_cur, conditions, n_frag_switch, combined_mask)
             stream = torch.cuda.current_stream(dev).cuda_stream
             self._step_kernel_dev(topo, 0, z, eps_hat, noise, h0d if self.pos_only else None, coef, z_new, stream)
             for a, b in zip(z, z_new):
                 a.copy_(b)
             counter.add_(1)
+            slot.add_(1)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        done = 0
         with torch.cuda.stream(side):                                    # eager warm-up on the capture stream (step 0)
+            refill(min(block, timesteps))
             one_step()
+            done, in_block = 1, 1
+            if timesteps > 1:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    one_step()
+                while done < timesteps:
+                    if in_block == block:
+                        refill(min(block, timesteps - done))
+                        in_block = 0
+                    g.replay()
+                    done += 1
+                    in_block += 1
         torch.cuda.current_stream(dev).wait_stream(side)
-        if timesteps > 1:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                one_step()
-            for _ in range(timesteps - 1):
-                g.replay()
         return z
 
     @torch.no_grad()
@@ -134,8 +159,9 @@ class DiffusionSampler:
                noise_fn: Optional[Callable[[int], List[Tensor]]] = None, graph: Optional[bool] = None) -> Tuple[list, List[Tensor]]:
         """`noise_fn(i)` (tests) supplies the i-th set of raw N(0,1) draws, one [n_k, node_nf_k] tensor per
         object (i = 0 initial state, 1..T the steps, T+1 the final draw); default: torch.randn on the device.
-        `graph`: replay the step as a captured hipGraph (`_graphed_steps`); None = automatically for launch-bound batches
-        (n_samples <= 8, one returned frame)."""
+        `graph`: replay the step as a captured hipGraph (`_graphed_steps`; bit-identical to the eager loop, noise drawn in
+        blocks of at most `self.noise_block_bytes`); None = automatically for launch-bound batches (n_samples <= 8, one returned
+        frame) unless the caller's stream is itself being captured (then the eager loop runs, which is capturable)."""
         timesteps = self.T if timesteps is None else timesteps
         assert 0 < return_frames <= timesteps and timesteps % return_frames == 0       # en_diffusion.py:473-475
         assert h0 is not None if self.pos_only else True
@@ -170,7 +196,8 @@ class DiffusionSampler:
                 t_table = torch.arange(timesteps + 1, device=dev, dtype=torch.float32) / timesteps
                 out_samples = [None] * return_frames
                 call = 1
-                use_graph = (n_samples <= 8 and return_frames == 1) if graph is None else bool(graph)
+                use_graph = ((n_samples <= 8 and return_frames == 1 and not torch.cuda.is_current_stream_capturing())
+                             if graph is None else bool(graph))
                 if use_graph:
                     assert return_frames == 1, "intermediate frames need the eager loop"
                     za = self._graphed_steps(dyn, topo, timesteps, za, draw, h0d, edge_index, conditions, n_frag_switch,

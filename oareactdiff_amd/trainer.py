@@ -20,6 +20,7 @@ left out of the bucket and never get a gradient, as in the reference.
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -76,7 +77,13 @@ class DDPMTrainer:
                 self.params.append(p)
                 self.names.append(name)
         n = sum(p.numel() for p in self.params)
-        self.flat_grad = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
+        # one bucket: [gradients (n) | non-finite flag (1)]; the flag rides in the same all-reduce so that every rank takes the
+        # same skip / step decision after the collective (a rank that bails out BEFORE it would leave the others hanging)
+        self._bucket = torch.zeros(n + 1, dtype=self.params[0].dtype, device=self.params[0].device)
+        self.flat_grad = self._bucket[:n]
+        self.skipped_steps = 0
+        if self.world > 1:
+            self.sync_replicas()
         off = 0
         for p in self.params:                          # p.grad = view into the bucket: backward accumulates in place
             p.grad = self.flat_grad[off: off + p.numel()].view_as(p)
@@ -92,17 +99,50 @@ class DDPMTrainer:
         representations, conditions = batch
         return self.loss.compute_loss(representations, conditions, training=training, **kw)
 
+    def sync_replicas(self, check: bool = True) -> None:
+        """What torch DDP does when it wraps a module (Lightning `DDPStrategy`, train_ts1x.py:197-203): rank 0's parameters
+        and buffers are broadcast to every rank, so replicas built from different RNG states - or with a checkpoint loaded
+        on rank 0 only - start identical.  One flat broadcast for the parameters, one for the floating-point buffers."""
+        if self.world <= 1:
+            return
+        with torch.no_grad():
+            for tensors in (list(self.dynamics.parameters()),
+                            [b for b in self.dynamics.buffers() if b.is_floating_point()]):
+                uniq, seen = [], set()
+                for t in tensors:                          # shared encoders appear once
+                    if id(t) not in seen:
+                        seen.add(id(t))
+                        uniq.append(t)
+                if not uniq:
+                    continue
+                flat = torch.cat([t.reshape(-1).to(torch.float64 if t.dtype == torch.float64 else torch.float32) for t in uniq])
+                dist.broadcast(flat, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                off = 0
+                for t in uniq:
+                    t.copy_(flat[off: off + t.numel()].view_as(t))      # in place: bumps the version -> weights are repacked
+                    off += t.numel()
+                if check:                                  # cheap invariant: every rank now holds the same bytes
+                    cs = flat.double().abs().sum().reshape(1)
+                    lo, hi = cs.clone(), cs.clone()
+                    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+                    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+                    assert float(lo) == float(hi), "replicas differ after the initial broadcast"
+
     def all_reduce_gradients(self) -> None:
-        """DDP's gradient averaging as one collective over the flat bucket (sum, then / world)."""
+        """DDP's gradient averaging as one collective over the flat bucket (sum, then / world).  The last element of the
+        bucket is the step's non-finite flag: summed with the gradients, > 0 on every rank if any rank raised it."""
         if self.world > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad.div_(self.world)
 
-    def clip_gradients(self) -> Tuple[float, float]:
+    def clip_gradients(self, grad_norm: Optional[float] = None) -> Tuple[float, float]:
         """pl_trainer.py:391-418: allow 150 % of the recent mean norm + 3 standard deviations."""
         max_grad_norm = 1.5 * self.gradnorm_queue.mean() + 3 * self.gradnorm_queue.std()
         # get_grad_norm (training_tools.py:29-55): 2-norm of the per-parameter 2-norms == 2-norm of the flat bucket
-        grad_norm = float(torch.linalg.vector_norm(self.flat_grad, 2.0))
+        if grad_norm is None:
+            grad_norm = float(torch.linalg.vector_norm(self.flat_grad, 2.0))
+        if not math.isfinite(grad_norm):                # never poison the history of norms (nan > max is False: clipping would stay off)
+            return grad_norm, max_grad_norm
         if grad_norm > max_grad_norm:                  # clip_grad_norm_: g *= max_norm / (norm + 1e-6)
             self.flat_grad.mul_(max_grad_norm / (grad_norm + 1e-6))
             self.gradnorm_queue.add(float(max_grad_norm))
@@ -112,14 +152,49 @@ class DDPMTrainer:
         return grad_norm, max_grad_norm
 
     def training_step(self, batch, **kw) -> Dict[str, float]:
-        """`kw` (t_int=, draw=) injects the step's randomness for tests; by default it is drawn like the reference does."""
-        self.flat_grad.zero_()
-        nll, info = self.compute_loss(batch, training=True, lazy_info=True, **kw)   # logged means stay on the device until the end
-        loss = nll.mean(0)                             # pl_trainer.py:329
-        loss.backward()
+        """`kw` (t_int=, draw=) injects the step's randomness for tests; by default it is drawn like the reference does.
+
+        Non-finite values (the reference replaces a NaN network output by randn and trains on, egnn_dynamics.py:138-143 - every
+        DDP rank in lock-step): here the network's device-side NaN flag and the finiteness of the local loss / gradient travel
+        in the gradient bucket's last element through the SAME all-reduce; if any rank raised it, every rank skips the
+        optimiser step (weights, AdamW state and the clipping history untouched), counts it in `skipped_steps` and reports
+        `info["skipped"] = 1`.  No rank leaves the step before the collective, and the only host sync is the one read of
+        [gradient norm, flag, loss] after it."""
+        dyn = self.dynamics
+        prev = getattr(dyn, "nan_check", None)
+        if prev is not None:
+            dyn.nan_check = "async"                    # no host sync between forward and backward; the flag is read below
+            if hasattr(dyn, "reset_nan_seen"):
+                dyn.reset_nan_seen()
+        self._bucket.zero_()
+        try:
+            nll, info = self.compute_loss(batch, training=True, lazy_info=True, **kw)   # logged means stay on the device until the end
+            loss = nll.mean(0)                         # pl_trainer.py:329
+            loss.backward()
+        finally:
+            if prev is not None:
+                dyn.nan_check = prev
+        bad = (~torch.isfinite(loss.detach())).to(self._bucket.dtype).reshape(())
+        seen = getattr(dyn, "nan_seen", None)
+        if seen is not None:
+            bad = bad + (seen[0] != 0).to(self._bucket.dtype)
+        # a non-finite local gradient must not reach the sum as NaN only (the flag element would survive, but be explicit)
+        self._bucket[-1] = bad + (~torch.isfinite(self.flat_grad.sum())).to(self._bucket.dtype)
         self.all_reduce_gradients()
-        if self.clip_grad:
-            info["grad_norm"], info["max_grad_norm"] = self.clip_gradients()
-        self.optimizer.step()
-        info["loss"] = float(loss.detach())
+        stats = torch.stack([torch.linalg.vector_norm(self.flat_grad, 2.0).to(torch.float64), self._bucket[-1].to(torch.float64),
+                             loss.detach().to(torch.float64)]).tolist()            # the step's one host sync
+        grad_norm, flag, loss_value = stats
+        skipped = flag != 0 or not math.isfinite(grad_norm)
+        if skipped:
+            self.skipped_steps += 1
+            print(f"Warning: non-finite loss / gradient / network output on some rank: step skipped on all ranks "
+                  f"({self.skipped_steps} so far)")
+            if self.clip_grad:
+                info["grad_norm"], info["max_grad_norm"] = grad_norm, float("nan")
+        else:
+            if self.clip_grad:
+                info["grad_norm"], info["max_grad_norm"] = self.clip_gradients(grad_norm)
+            self.optimizer.step()
+        info["loss"] = loss_value
+        info["skipped"] = int(skipped)
         return {k: (float(v) if isinstance(v, Tensor) else v) for k, v in info.items()}

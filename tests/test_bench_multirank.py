@@ -34,6 +34,47 @@ def test_bench_two_ranks_gloo_dry_run():
     assert abs(d["value"] - 2 * 64 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-6     # whole-job aggregate
 
 
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", ["sample", "train"])
+def test_bench_bare_form_launches_its_own_ranks(mode):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts torch.distributed.run itself (as a
+    child, before any GPU call), relays rank 0's single JSON line and exits with the workers' code.  `--mode train`: every
+    rank reaches the step's collective."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OARD_BENCH_BACKEND="gloo", OARD_BENCH_DRY="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--mode", mode], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout       # stdout is exactly the one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["dry_run"]
+    assert d["metric"] == ("training_steps_per_sec" if mode == "train" else "denoising_steps_per_sec")
+    assert d["ms_per_step"] >= 3.9
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, OARD_BENCH_DRY="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_train_mode_two_ranks_under_the_launcher():
+    env = dict(os.environ, OARD_BENCH_BACKEND="gloo", OARD_BENCH_DRY="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--mode", "train"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["metric"] == "training_steps_per_sec" and "all-reduce" in d["config"]["parallelism"]
+
+
 def test_bench_single_process_dry_run():
     env = dict(os.environ, OARD_BENCH_DRY="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0"], capture_output=True,

@@ -64,26 +64,48 @@ def _batch(sizes, lo, hi):
     return (reps, torch.zeros(hi - lo, 1, dtype=torch.float64)), t_int, (lambda shape: next(it))
 
 
-def _step(rank, world):
+def _step(rank, world, perturb=False, poison_rank=None):
     from oareactdiff_amd.shard import shard_range
     from oareactdiff_amd.trainer import DDPMTrainer
     lo, hi = shard_range(len(SIZES), rank, world)
-    tr = DDPMTrainer(_oracle_dynamics(), timesteps=T, norm_values=(1.0, 4.0, 10.0), scales=(1.0, 2.0, 1.0))
+    dyn = _oracle_dynamics()
+    if perturb and rank > 0:                 # replicas that were NOT built identically (different RNG state / only rank 0 loaded)
+        with torch.no_grad():
+            for p in dyn.parameters():
+                p.add_(0.1 * (rank + 1))
+    tr = DDPMTrainer(dyn, timesteps=T, norm_values=(1.0, 4.0, 10.0), scales=(1.0, 2.0, 1.0))
     batch, t_int, draw = _batch(SIZES, lo, hi)
+    if poison_rank == rank:                  # this rank's noise is NaN: its loss and gradients are not finite
+        inner = draw
+        draw = lambda shape: inner(shape) * float("nan")      # noqa: E731
     info = tr.training_step(batch, t_int=t_int, draw=draw)
     return tr, info
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, perturb=False, poison_rank=None):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        tr, info = _step(rank, world)
+        tr, info = _step(rank, world, perturb, poison_rank)
         q.put((rank, tr.flat_grad.numpy().copy(), torch.cat([p.detach().reshape(-1) for p in tr.params]).numpy().copy(),
-               info["loss"], info["grad_norm"]))        # numpy: torch tensors would travel as shared-memory handles
+               info["loss"], info["grad_norm"], info["skipped"], len(tr.gradnorm_queue)))   # numpy: tensors would travel as shm handles
     finally:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _run_two_ranks(**kw):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q), kwargs=kw) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=300) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return [(r, torch.from_numpy(g), torch.from_numpy(w), l, n, sk, ql) for r, g, w, l, n, sk, ql in out]
 
 
 def test_two_rank_training_step_equals_single_process():
@@ -92,23 +114,39 @@ def test_two_rank_training_step_equals_single_process():
     assert not any(n.startswith(("model.distance_embedding.", "model.last_layer.")) for n in single.names)
     assert float(single.flat_grad.abs().max()) > 0 and info1["grad_norm"] > 0
     w1 = torch.cat([p.detach().reshape(-1) for p in single.params])
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    out = sorted((q.get(timeout=300) for _ in range(world)), key=lambda x: x[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    (_, g0, w0, l0, n0), (_, g1, wr1, l1, n1) = [(r, torch.from_numpy(g), torch.from_numpy(w), l, n) for r, g, w, l, n in out]
+    (_, g0, w0, l0, n0, s0, _), (_, g1, wr1, l1, n1, s1, _) = _run_two_ranks()
+    assert s0 == 0 and s1 == 0
     assert torch.equal(g0, g1) and torch.equal(w0, wr1)            # the all-reduce leaves the replicas identical
     assert abs(n0 - info1["grad_norm"]) <= 1e-9 * info1["grad_norm"]
     scale = float(single.flat_grad.abs().max())
     assert float((g0 - single.flat_grad).abs().max()) <= 1e-10 * scale   # mean of the shard means == mean over the batch
     assert float((w0 - w1).abs().max()) <= 1e-12
     assert abs(0.5 * (l0 + l1) - info1["loss"]) <= 1e-10 * abs(info1["loss"])
+
+
+def test_replicas_built_differently_are_synchronised_at_construction():
+    """torch DDP broadcasts rank 0's parameters and buffers when it wraps the module; `DDPMTrainer.__init__` does the same.
+    Rank 1 starts from perturbed weights: after construction + one step both ranks hold what a single process computes."""
+    single, info1 = _step(0, 1)
+    w1 = torch.cat([p.detach().reshape(-1) for p in single.params])
+    (_, g0, w0, _, _, _, _), (_, g1, wr1, _, _, _, _) = _run_two_ranks(perturb=True)
+    assert torch.equal(g0, g1) and torch.equal(w0, wr1)
+    assert float((w0 - w1).abs().max()) <= 1e-12
+    assert float((g0 - single.flat_grad).abs().max()) <= 1e-10 * float(single.flat_grad.abs().max())
+
+
+def test_non_finite_step_is_skipped_on_every_rank():
+    """One rank sees NaN: no rank leaves before the collective (nobody hangs), every rank skips the optimiser step, the
+    weights stay what they were and nothing non-finite enters the clipping history."""
+    fresh = torch.cat([p.detach().reshape(-1) for p in _oracle_dynamics().parameters() if p.requires_grad])
+    (_, g0, w0, l0, n0, s0, q0), (_, g1, wr1, l1, n1, s1, q1) = _run_two_ranks(poison_rank=1)
+    assert s0 == 1 and s1 == 1
+    assert q0 == 1 and q1 == 1                                   # only the initial 3000 (pl_trainer.py:143-146)
+    assert torch.equal(w0, wr1) and bool(torch.isfinite(w0).all())
+    from oareactdiff_amd.trainer import DDPMTrainer
+    tr = DDPMTrainer(_oracle_dynamics(), timesteps=T)
+    assert torch.equal(w0, torch.cat([p.detach().reshape(-1) for p in tr.params]))      # untouched weights
+    assert fresh.numel() >= w0.numel()
 
 
 def test_gradient_clipping_follows_the_reference_rule():
