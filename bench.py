@@ -43,39 +43,67 @@ def cpu_model() -> str:
 
 
 def cpu_baseline(n_atoms: int):
-    """Times the CPU oracle (dense reference formulation, float32) on bounded samples: B in {1, 4, 8} reactions,
-    ~6 s each.  `value` is the best of the three (reaction-steps/s); all three are listed."""
+    """Times the CPU oracle (dense reference formulation, float32) on the host's cores, SURVEY.md section 8d: B in {1, 8}
+    reactions at two thread counts - 16 and every core of the host (`torch.set_num_threads(os.cpu_count())`) - with >= 3
+    timed calls each after one warm-up, then B = 64 (the benched batch) at the better thread count with ONE timed call if
+    its projected duration fits the budget (no extrapolation to T = 1000).  `value` = the best reaction-steps/s of all
+    runs, `cores` = the threads that run used; every run is listed with its thread count."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import leftnet_oracle as oracle
     from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
     from oareactdiff_amd.synthetic import make_inputs, make_topology
     host_cores = os.cpu_count() or 1
-    threads = max(1, min(host_cores, 16))   # the eager formulation stops scaling (and thrashes) beyond ~16 threads
-    torch.set_num_threads(threads)
     cfg = dict(PRODUCTION_LEFTNET_CONFIG)
     sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg)
+    budget = float(os.environ.get("OARD_CPU_BASELINE_SECONDS", "6"))
     runs = []
-    for B in (1, 4, 8):
+
+    def case(B):
         cm, nfs, ei, masks = make_topology(B, n_atoms)
         xh = make_inputs(B, n_atoms, masks, 7, "cpu")
-        t = torch.full((B, 1), 0.5)
-        cond = torch.zeros(B, 1)
-        with torch.no_grad():                                   # warm-up
-            oracle.dynamics_forward(sd, cfg, xh, ei, t, cond, nfs, cm, 1, nodeframe="literal")
-        calls, t0 = 0, time.perf_counter()
-        while calls < 2 or (time.perf_counter() - t0 < 6.0 and calls < 40):
-            with torch.no_grad():
-                oracle.dynamics_forward(sd, cfg, xh, ei, t, cond, nfs, cm, 1, nodeframe="literal")
-            calls += 1
+        return lambda: oracle.dynamics_forward(sd, cfg, xh, ei, torch.full((B, 1), 0.5), torch.zeros(B, 1), nfs, cm, 1,
+                                               nodeframe="literal")
+
+    def timed(B, threads, call, min_calls, seconds, warm=True):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            if warm:
+                call()
+            calls, t0 = 0, time.perf_counter()
+            while calls < min_calls or (time.perf_counter() - t0 < seconds and calls < 40):
+                call()
+                calls += 1
         dt = time.perf_counter() - t0
-        runs.append({"batch": B, "calls": calls, "seconds": round(dt, 2), "s_per_call": dt / calls,
+        runs.append({"batch": B, "threads": threads, "calls": calls, "seconds": round(dt, 2), "s_per_call": dt / calls,
                      "reaction_steps_per_s": B * calls / dt})
+        return runs[-1]
+
+    thread_sets = sorted({max(1, min(host_cores, 16)), host_cores})
+    for B in (1, 8):
+        call = case(B)
+        for th in thread_sets:
+            timed(B, th, call, 3, budget)
+    best8 = max((r for r in runs if r["batch"] == 8), key=lambda r: r["reaction_steps_per_s"])
+    projected = 64 * best8["s_per_call"] / 8
+    note64 = f"B=64 skipped: one call projected at {projected:.0f} s"
+    avail_gb = 0.0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail_gb = int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    if avail_gb < 24.0:                                        # the dense formulation peaks at ~15 GB of host memory at B = 64
+        note64 = f"B=64 skipped: {avail_gb:.0f} GB of host memory available, the dense formulation needs ~15 GB"
+    elif projected <= float(os.environ.get("OARD_CPU_BASELINE_B64_MAX_SECONDS", "60")):
+        timed(64, best8["threads"], case(64), 1, 0.0, warm=False)
+        note64 = "B=64: ONE timed call, no warm-up, at the better thread count of the B=8 runs"
     best = max(runs, key=lambda r: r["reaction_steps_per_s"])
-    return {"value": best["reaction_steps_per_s"], "unit": "reaction-steps/s", "cores": threads, "kind": "port",
+    return {"value": best["reaction_steps_per_s"], "unit": "reaction-steps/s", "cores": best["threads"], "kind": "port",
             "host_cores": host_cores, "cpu_model": cpu_model(), "runs": runs,
-            "sample": f"oracle/leftnet_oracle.py (dense reference formulation), float32, {n_atoms}-atom triples, "
-                      f"B in (1, 4, 8), >= 2 calls / ~6 s each after 1 warm-up, {threads} torch threads on a "
-                      f"{host_cores}-core host; value = best of the three (B={best['batch']})"}
+            "sample": f"oracle/leftnet_oracle.py (dense reference formulation), float32, {n_atoms}-atom triples; B in (1, 8) at "
+                      f"{' and '.join(str(t) for t in thread_sets)} torch threads ({host_cores}-core host), >= 3 calls / ~{budget:.0f} s "
+                      f"each after 1 warm-up; {note64}; value = best of all runs (B={best['batch']}, {best['threads']} threads)"}
 
 
 def source_stamp() -> str:
