@@ -22,14 +22,35 @@ def _stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + _headers())
 
 
+DEFAULT_DIMS = "196x96,32x8,32x32"
+
+
+def dims_define(spec: str) -> str:
+    """OARD_DIMS="196x96,32x8" -> -DOARD_DIMS_LIST=X(196,96)X(32,8): the (hidden_channels, num_radial) pairs to instantiate."""
+    pairs = []
+    for item in spec.replace(" ", "").split(","):
+        if not item:
+            continue
+        h, r = item.lower().split("x")
+        h, r = int(h), int(r)
+        if h % 4 or r % 4 or h < 16 or r < 4:
+            raise ValueError(f"OARD_DIMS entry {item!r}: widths must be multiples of 4 (hidden >= 16)")
+        if (h, r) not in pairs:
+            pairs.append((h, r))
+    if not pairs:
+        raise ValueError("OARD_DIMS is empty")
+    return "-DOARD_DIMS_LIST=" + "".join(f"X({h},{r})" for h, r in pairs)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+    dims = os.environ.get("OARD_DIMS", DEFAULT_DIMS)
+    if not force and not _stale() and dims == DEFAULT_DIMS:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-result"] + SOURCES + ["-o", LIB]
+           "-Wno-unused-result", dims_define(dims)] + SOURCES + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, cwd=CSRC, check=True)

@@ -84,13 +84,19 @@ struct ScopedLaunch {
 #define LAUNCH2(fam, kern, gx, gy, block, stream, ...) do { ScopedLaunch sl_(fam, stream); \
     hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy)), dim3(block), 0, stream, __VA_ARGS__); } while (0)
 
+#ifndef OARD_DIMS_LIST      // production (train_ts1x.py:43-56) + the two test widths of the reference's unit tests / goldens
+#define OARD_DIMS_LIST X(196, 96) X(32, 8) X(32, 32)
+#endif
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
 bool config_ok(const oard_config* c) {
     if (!c) return false;
-    const bool dims = (c->hidden == 196 && c->num_radial == 96) || (c->hidden == 32 && c->num_radial == 8) ||
-                      (c->hidden == 32 && c->num_radial == 32);
+    bool dims = false;                      // (hidden_channels, num_radial) pairs this build instantiates (OARD_DIMS_LIST)
+#define X(h, r) dims = dims || (c->hidden == (h) && c->num_radial == (r));
+    OARD_DIMS_LIST
+#undef X
     if (!dims) return false;
     if (c->num_layers < 1 || c->num_layers > OARD_MAX_LAYERS) return false;
     if (c->in_hidden < 1 || c->in_hidden > 16) return false;
@@ -546,12 +552,17 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     return OARD_OK;
 }
 
-#define DISPATCH_DIMS(c, CALL)                                                             \
-    do {                                                                                   \
-        if ((c)->hidden == 196 && (c)->num_radial == 96) { using D = Dims<196, 96>; CALL; } \
-        else if ((c)->hidden == 32 && (c)->num_radial == 8) { using D = Dims<32, 8>; CALL; } \
-        else if ((c)->hidden == 32 && (c)->num_radial == 32) { using D = Dims<32, 32>; CALL; } \
-        else return OARD_EINVAL;                                                           \
+// One instantiation of every kernel per (hidden_channels, num_radial) pair of OARD_DIMS_LIST (oareactdiff_amd/build.py:
+// environment OARD_DIMS="196x96,32x8,32x32,..."; a checkpoint with other widths is a rebuild, not a code change).
+template <class F> static int dispatch_dims(const oard_config* c, F&& f) {
+#define X(h, r) if (c->hidden == (h) && c->num_radial == (r)) { f(Dims<(h), (r)>{}); return 0; }
+    OARD_DIMS_LIST
+#undef X
+    return OARD_EINVAL;
+}
+#define DISPATCH_DIMS(c, CALL)                                                                         \
+    do {                                                                                               \
+        if (dispatch_dims((c), [&](auto d_) { using D = decltype(d_); CALL; }) != 0) return OARD_EINVAL; \
     } while (0)
 
 // ---- transposed weight streams of the backward edge kernels -----------------------------------------------------

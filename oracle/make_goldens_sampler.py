@@ -184,6 +184,14 @@ def run_inpaint(name, T, sizes, cfg, resamplings, jump_length, frag_fixed, sched
 
 
 if __name__ == "__main__":
+    if "--prod" in sys.argv:
+        # production dims (H=196, R=96, L=6; train_ts1x.py:43-56) on small reactions: the device loops at the kernel
+        # instantiations the bench runs.  pos_only=False exercises the feature half of the sampler step as well.
+        from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG
+        pcfg = dict(PRODUCTION_LEFTNET_CONFIG)
+        run("g4_sampler_full_prod", False, 8, [10, 12], pcfg)
+        run_inpaint("g5_inpaint_prod", 8, [10, 11], pcfg, resamplings=2, jump_length=2, frag_fixed=[0, 2])
+        sys.exit(0)
     cfg = dict(pos_require_grad=False, cutoff=10.0, num_layers=2, hidden_channels=32, num_radial=8, in_hidden_channels=8)
     run("g4_sampler_posonly", True, 20, [4, 6], cfg)
     run("g4_sampler_full", False, 12, [5, 3], cfg)

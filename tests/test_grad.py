@@ -75,6 +75,59 @@ def test_hip_training_step_gradients_match_reference_f64(name):
 
 
 @pytest.mark.gpu
+def test_benched_training_launch_reproduces_the_reference_gradients():
+    """The launch `bench.py --mode train` times - B = 64 reactions x 3 x 23 atoms, all 6 layers, the 8-wave throughput
+    shapes, 512-workgroup weight-gradient GEMMs - with the two fixture reactions (reference float64 autograd,
+    oracle/make_goldens_grad.py --n23) in slots (0, 1) and then in slots (62, 63) of the batch; the other 62 reactions
+    are random and get a zero cotangent (loss = mean of the two occupied slots' nll), so the parameter gradients that
+    come out of the B = 64 launch must be the fixture's.  Also: the training-mode forward (out-of-place edge state,
+    tape written) returns what the inference forward returns on the same inputs."""
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.loss import DiffusionLoss
+    c = GradCase("g9_grad_prod_n23")
+    dev = torch.device("cuda:0")
+    B = 64
+    dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=NODE_NFS, edge_nf=0,
+                       condition_nf=CNF, device=dev)
+    dyn.load_state_dict(c.state_dict(), strict=True)
+    ref_nll = torch.from_numpy(c.z["f64_nll"])
+    gap = c.meta["ref_f32_vs_f64"]
+    for slots in ((0, 1), (62, 63)):
+        dyn.zero_grad(set_to_none=True)
+        reps, cond, t_int, draw = c.embedded(B, list(slots), torch.float32, dev)
+        dl = DiffusionLoss(dyn, "polynomial_2", c.meta["T"], 1e-5, norm_values=c.meta["norm_values"], node_nfs=NODE_NFS,
+                           pos_only=c.meta["pos_only"])
+        nll, _ = dl.compute_loss(reps, cond, training=True, t_int=t_int, draw=draw)
+        assert nll.shape == (B,)
+        sub = nll[list(slots)]
+        e_nll = float(((sub.detach().double().cpu() - ref_nll).abs() / ref_nll.abs()).max())
+        sub.mean(0).backward()
+        grads = {n: p.grad for n, p in dyn.named_parameters() if p.grad is not None}
+        errs, flat = c.compare(grads)
+        bad = [n for n in errs if errs[n] > (1e-5 if gap[n] < 1e-3 else 0.1 * gap[n])]
+        worst = max(errs, key=lambda k: errs[k])
+        print(f"\nB=64 launch, fixture in slots {slots}: per-reaction nll error {e_nll:.2e}; flat gradient error {flat:.2e}; "
+              f"worst tensor {worst} {errs[worst]:.2e} (reference f32: {gap[worst]:.2e})")
+        assert e_nll <= 2e-5 and flat <= 2e-5 and not bad, (e_nll, flat, [(n, errs[n], gap[n]) for n in bad])
+    # training-mode forward == inference forward on the same B = 64 inputs
+    from oareactdiff_amd.graph_tools import get_edges_index, get_n_frag_switch
+    reps, cond, t_int, _ = c.embedded(B, [0, 1], torch.float32, dev)
+    masks, sizes = [r["mask"] for r in reps], [r["size"] for r in reps]
+    cm = torch.cat(masks)
+    ei, nfs = get_edges_index(cm, remove_self_edge=True), get_n_frag_switch(sizes)
+    g = torch.Generator().manual_seed(3)
+    xh = [torch.cat([r["pos"].cpu(), torch.randn(r["pos"].shape[0], 6, generator=g)], dim=1).to(dev) for r in reps]
+    t = (t_int / c.meta["T"]).to(dev)
+    out_t, _ = dyn(xh, ei, t, cond, nfs, cm)
+    assert out_t[0].requires_grad
+    with torch.no_grad():
+        out_i, _ = dyn(xh, ei, t, cond, nfs, cm)
+    for a, b in zip(out_t, out_i):
+        e = float((a.detach() - b).abs().max() / b.abs().max())
+        assert e <= 3e-6, e
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pos_only,alias", [(True, None), (False, [1, 2])])
 def test_hip_gradients_pos_only_and_shared_encoders(pos_only, alias):
     """The production training switches the goldens do not cover: `pos_only=True` (train_ts1x.py:107: feature outputs are zeroed

@@ -15,7 +15,8 @@ from oareactdiff_amd.graph_tools import get_edges_index, get_mask_for_frag, get_
 from oareactdiff_amd.schedule import Schedule
 from oareactdiff_amd.spec import state_spec, synthetic_state_dict
 
-CASES = ["g4_sampler_posonly", "g4_sampler_full"]
+CASES = ["g4_sampler_posonly", "g4_sampler_full", "g4_sampler_full_prod"]     # _prod: H=196, R=96, L=6
+ICASES = ["g5_inpaint", "g5_inpaint_prod"]
 
 
 class SCase:
@@ -150,9 +151,10 @@ class ICase(SCase):
         self.res, self.jump = self.meta["resamplings"], self.meta["jump_length"]
 
 
-def test_oracle_inpaint_replays_reference_bitwise():
+@pytest.mark.parametrize("name", ICASES)
+def test_oracle_inpaint_replays_reference_bitwise(name):
     from oareactdiff_amd.schedule import get_repaint_schedule
-    c = ICase()
+    c = ICase(name)
 
     def dyn(zt, t):
         return oracle.dynamics_forward(c.sd, c.cfg, zt, c.ei, t, c.cond, c.nfs, c.cm, 1, nodeframe="literal",
@@ -170,10 +172,11 @@ def test_oracle_inpaint_replays_reference_bitwise():
 
 
 @pytest.mark.gpu
-def test_device_inpaint_tracks_f64_replay():
+@pytest.mark.parametrize("name", ICASES)
+def test_device_inpaint_tracks_f64_replay(name):
     from oareactdiff_amd import DiffusionSampler, EGNNDynamics
     dev = torch.device("cuda:0")
-    c = ICase()
+    c = ICase(name)
     dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
                        condition_nf=1, device=dev)
     dyn.load_state_dict(c.sd, strict=True)
@@ -195,6 +198,6 @@ def test_device_inpaint_tracks_f64_replay():
     got = torch.cat([smp.last_x[k][:, :3].cpu().double().reshape(-1) for k in range(3)])
     want = torch.cat([x64[k][:, :3].reshape(-1) for k in range(3)])
     e = rel(got, want)
-    print(f"g5_inpaint: device inpaint vs float64 replay, positions rel = {e:.2e} ({c.meta['ncalls']} noise draws)")
+    print(f"{name}: device inpaint vs float64 replay, positions rel = {e:.2e} ({c.meta['ncalls']} noise draws)")
     assert e <= 5e-5
     assert out[0][1].shape == (sum(c.sizes), 9)
