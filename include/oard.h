@@ -306,6 +306,51 @@ int oard_wgrad(const float* dY_dev, int ldY, int ncY, int o_len, int o_pad, int 
                const float* X_dev, int ldX, int ncX, int x_silu, int i_len, int i_pad, int MI, int64_t rows,
                float* dW_dev, float* db_dev, void* scratch_dev, size_t scratch_bytes, oard_stream_t stream);
 
+/* ---- The whole reverse sweep on the device (round 3) -------------------------------------------------------------------------
+ * Replaces torch autograd through the node-side / init / output stages of LEFTNet.forward (oa_reactdiff/model/leftnet.py:
+ * EquiUpdate :325-346, GCL node update :172-183, x_proj :245, pos_expansion + LayerNorm + edge_mlp.0 node halves :840-841,158,168,
+ * output block :566-576,878-891, init head :744,781-809) and of the wrapper (egnn_dynamics.py:91-119 encoders, :137-160 velocity /
+ * CoM / decoders).  Every entry reads the tape of oard_forward_train and ACCUMULATES parameter gradients into `grads_dev`:
+ * a table of device pointers in the canonical parameter order of oard_pack_weights (nn.Linear shapes; NULL entries are skipped;
+ * encoders / decoders shared by several objects simply appear several times).  `params_dev` is the same table for the weights
+ * themselves.  Node cotangents are [N][HP] / [3N][HP] float32 with zero pads, the edge-state cotangent is [E+1][WP].  All scratch
+ * is the caller's (`oard_train_scratch_bytes`); nothing allocates or synchronises.  `packed_bwd_dev` = oard_pack_weights_bwd.
+ *   oard_train_tail_backward   grad_out[k] ([n_k][node_nf_k], reference rows; NULL = zero) -> ds, dvec of the final node state
+ *   oard_train_layer_backward  one layer: ds / dvec / dew in place (cotangents of the layer's outputs -> of its inputs)
+ *   oard_train_init_backward   ds0, dew (cotangents of the state entering layer 0) -> init-head and encoder gradients
+ *   oard_train_stage_backward  one stage of a layer in isolation (teacher-forced tests); RECOMPUTE first */
+#define OARD_STAGE_RECOMPUTE 0
+#define OARD_STAGE_UPDATE 1      /* in: ds, dvec          out: gs_a, gvec_a       */
+#define OARD_STAGE_MESSAGE 2     /* in: gs_a, gvec_a      out: gx, dxq, dvec_in   */
+#define OARD_STAGE_GCL_NODE 3    /* in: gx, dxq           out: dxh, dagg          */
+#define OARD_STAGE_NODE_PRE 4    /* in: dxh, dP, dQ       out: ds_in              */
+#define OARD_SCRATCH_XH 1
+#define OARD_SCRATCH_XQ 2
+#define OARD_SCRATCH_CR 3
+#define OARD_SCRATCH_DCD 4
+#define OARD_SCRATCH_DCR 5
+size_t oard_train_scratch_bytes(const oard_config* cfg, const oard_topology* topo);
+int oard_train_scratch_poison(const oard_config* cfg, const oard_topology* topo, void* scratch_dev, size_t scratch_bytes,
+                              oard_stream_t stream);
+int oard_train_scratch_entry(const oard_config* cfg, const oard_topology* topo, int which, size_t* offset_bytes, int64_t* rows,
+                             int64_t* row_floats);
+int oard_train_tail_backward(const oard_config* cfg, const oard_topology* topo, const void* packed_dev, const void* packed_bwd_dev,
+                             const void* tape_dev, const float* const* grad_out_dev, float* ds_dev, float* dvec_dev,
+                             const float* const* params_dev, float* const* grads_dev, void* scratch_dev, size_t scratch_bytes,
+                             oard_stream_t stream);
+int oard_train_layer_backward(const oard_config* cfg, const oard_topology* topo, const void* packed_dev, const void* packed_bwd_dev,
+                              const void* tape_dev, int layer, float* ds_dev, float* dvec_dev, float* dew_dev,
+                              const float* const* params_dev, float* const* grads_dev, void* scratch_dev, size_t scratch_bytes,
+                              oard_stream_t stream);
+int oard_train_init_backward(const oard_config* cfg, const oard_topology* topo, const void* packed_dev, const void* packed_bwd_dev,
+                             const void* tape_dev, const float* const* xh_dev, const float* ds0_dev, const float* dew_dev,
+                             const float* const* params_dev, float* const* grads_dev, void* scratch_dev, size_t scratch_bytes,
+                             oard_stream_t stream);
+int oard_train_stage_backward(const oard_config* cfg, const oard_topology* topo, const void* packed_dev, const void* packed_bwd_dev,
+                              const void* tape_dev, int layer, int stage, const float* in0, const float* in1, const float* in2,
+                              float* out0, float* out1, float* out2, const float* const* params_dev, float* const* grads_dev,
+                              void* scratch_dev, size_t scratch_bytes, oard_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

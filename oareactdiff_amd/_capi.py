@@ -21,7 +21,11 @@ EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_by
            "oard_timing_get",
            "oard_topology_create_parts", "oard_topology_export", "oard_tape_bytes", "oard_tape_entry", "oard_forward_train",
            "oard_packed_bwd_bytes", "oard_pack_weights_bwd", "oard_gcl_backward_dx", "oard_edge_node_sums",
-           "oard_equi_backward_dx", "oard_scalarize_backward", "oard_equi_msg_backward", "oard_lin3u_forward", "oard_lin3u_backward", "oard_wgrad_scratch_bytes", "oard_wgrad"]
+           "oard_equi_backward_dx", "oard_scalarize_backward", "oard_equi_msg_backward", "oard_lin3u_forward", "oard_lin3u_backward", "oard_wgrad_scratch_bytes", "oard_wgrad",
+           "oard_train_scratch_bytes", "oard_train_scratch_poison", "oard_train_scratch_entry", "oard_train_tail_backward",
+           "oard_train_layer_backward", "oard_train_init_backward", "oard_train_stage_backward"]
+STAGE_RECOMPUTE, STAGE_UPDATE, STAGE_MESSAGE, STAGE_GCL_NODE, STAGE_NODE_PRE = range(5)
+SCRATCH_XH, SCRATCH_XQ, SCRATCH_CR, SCRATCH_DCD, SCRATCH_DCR = range(1, 6)
 
 # oard_topology_export tables / oard_tape_entry tensors (include/oard.h)
 TOPO_NODE_REF, TOPO_NODE_OBJ, TOPO_NODE_ROW, TOPO_NODE_SAMPLE, TOPO_NODE_TIDX, TOPO_SAMPLE_PTR, TOPO_GROUP_PTR, \
@@ -103,6 +107,15 @@ def lib() -> C.CDLL:
     L.oard_lin3u_backward.argtypes = [cfgp, vp, ci, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]; L.oard_lin3u_backward.restype = ci
     L.oard_wgrad_scratch_bytes.argtypes = [ci, ci, i64]; L.oard_wgrad_scratch_bytes.restype = sz
     L.oard_wgrad.argtypes = [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, i64, vp, vp, vp, sz, vp]; L.oard_wgrad.restype = ci
+    pvp = C.POINTER(vp)
+    L.oard_train_scratch_bytes.argtypes = [cfgp, vp]; L.oard_train_scratch_bytes.restype = sz
+    L.oard_train_scratch_poison.argtypes = [cfgp, vp, vp, sz, vp]; L.oard_train_scratch_poison.restype = ci
+    L.oard_train_scratch_entry.argtypes = [cfgp, vp, ci, C.POINTER(sz), C.POINTER(i64), C.POINTER(i64)]; L.oard_train_scratch_entry.restype = ci
+    L.oard_train_tail_backward.argtypes = [cfgp, vp, vp, vp, vp, pvp, vp, vp, pvp, pvp, vp, sz, vp]; L.oard_train_tail_backward.restype = ci
+    L.oard_train_layer_backward.argtypes = [cfgp, vp, vp, vp, vp, ci, vp, vp, vp, pvp, pvp, vp, sz, vp]; L.oard_train_layer_backward.restype = ci
+    L.oard_train_init_backward.argtypes = [cfgp, vp, vp, vp, vp, pvp, vp, vp, pvp, pvp, vp, sz, vp]; L.oard_train_init_backward.restype = ci
+    L.oard_train_stage_backward.argtypes = [cfgp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, pvp, pvp, vp, sz, vp]
+    L.oard_train_stage_backward.restype = ci
     L.oard_debug_stop_after.argtypes = [C.c_int]; L.oard_debug_stop_after.restype = C.c_int
     L.oard_debug_option.argtypes = [C.c_char_p, C.c_int]; L.oard_debug_option.restype = C.c_int
     L.oard_timing_enable.argtypes = [C.c_int]; L.oard_timing_enable.restype = C.c_int

@@ -508,22 +508,23 @@ OARD_DEV float chunk_sum_wave(const float* __restrict__ p, size_t stride, int n_
     return s;
 }
 // dW [MO][MI] and db [MO] from the small kernel's partials: one wave per output
+// ldW: row stride of the destination (a column slice of a wider nn.Linear weight); acc: add to the destination instead of overwriting
 __global__ __launch_bounds__(256) void k_wgrad_small_reduce(const float* __restrict__ partial, int n_chunks, int MO, int MI,
-                                                            float* __restrict__ dW, float* __restrict__ db) {
+                                                            float* __restrict__ dW, int ldW, float* __restrict__ db, int acc) {
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), nout = MO * (MI + 1);
     if (idx >= nout) return;
     const float s = chunk_sum_wave(partial + idx, (size_t)nout, n_chunks, threadIdx.x & 63);
     if ((threadIdx.x & 63) != 0) return;
     const int o = idx / (MI + 1), i = idx % (MI + 1);
-    if (i < MI) dW[o * MI + i] = s;
-    else if (db != nullptr) db[o] = s;
+    if (i < MI) { if (dW != nullptr) dW[(size_t)o * ldW + i] = acc ? dW[(size_t)o * ldW + i] + s : s; }
+    else if (db != nullptr) db[o] = acc ? db[o] + s : s;
 }
 
 // second pass: dW[o][i] (dense, logical nn.Linear shape) = sum over chunks in ascending order.  Logical index -> padded index by
 // sections (o = s * len + w -> s * pad + w), which undoes the 196 -> 208 padding of split projections.  `transposed`: the
 // partials are [x feature][dY feature] (the kernel ran with P = X, Q = dY).
 __global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int PP, int QP, int transposed, int o_len, int o_pad,
-                               int MO, int i_len, int i_pad, int MI, float* __restrict__ out) {
+                               int MO, int i_len, int i_pad, int MI, float* __restrict__ out, int ldW, int acc) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)MO * MI) return;
     const int o = (int)(idx / MI), i = (int)(idx % MI);
@@ -531,13 +532,14 @@ __global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, 
     const float* p = partial + (transposed ? (size_t)ip * QP + op : (size_t)op * QP + ip);
     float s = 0.f;
     for (int ch = 0; ch < n_chunks; ++ch) s += p[(size_t)ch * PP * QP];
-    out[idx] = s;
+    float* dst = out + (size_t)o * ldW + i;
+    *dst = acc ? *dst + s : s;
 }
 __global__ __launch_bounds__(256) void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int stride, int o_len, int o_pad,
-                                                      int MO, float* __restrict__ out) {          // one wave per output
+                                                      int MO, float* __restrict__ out, int acc) {  // one wave per output
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= MO) return;
     const int op = (o / o_len) * o_pad + o % o_len;
     const float s = chunk_sum_wave(bpartial + op, (size_t)stride, n_chunks, threadIdx.x & 63);
-    if ((threadIdx.x & 63) == 0) out[o] = s;
+    if ((threadIdx.x & 63) == 0) out[o] = acc ? out[o] + s : s;
 }

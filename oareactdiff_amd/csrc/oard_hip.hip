@@ -628,7 +628,7 @@ static int equi_msg_backward_impl(const TopoDev& tp, const char* tape, const Tap
     const Strided3 xq3{xq, 3 * D::H, D::H}, vec3{(const float*)(tape + to.vec_in[layer]), 3 * D::HP, D::HP}, cr3{cr, 3 * D::H, D::H},
         gv3{gv, 3 * D::H, D::H};
     LAUNCH(F_NODE, (k_equi_msg_bwd<D>), tp.N, 256, st, tp, (const float*)(tape + to.geo), xq3, vec3, (const float*)(tape + to.cd[layer]), cr3,
-           gs, D::H, gv3, dcd, dcr, dxq, dvec);
+           gs, D::H, gv3, dcd, dcr, dxq, dvec, D::H);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
@@ -914,6 +914,7 @@ int oard_topology_create_parts(const oard_config* c, const int64_t* cm, const in
     n_parts = std::max(1, std::min(std::min(n_parts, OARD_MAX_PARTS), B));
     oard_topology* tp = new oard_topology();
     tp->n_obj = n_obj; tp->B = B; tp->n_parts = n_parts;
+    for (int k = 0; k <= n_obj && k <= OARD_MAX_OBJECTS; ++k) tp->obj_start[k] = obj_start[k];
     for (int p = 0; p < n_parts; ++p) {
         const int lo = (int)((long long)B * p / n_parts), hi = (int)((long long)B * (p + 1) / n_parts);
         int rc = build_part(c, cm, nfs, N, obj_start, dense, ref_ptr_ref, lo, hi, tp->parts[p], tp->max_group, tp->max_ns);
@@ -1145,7 +1146,13 @@ int oard_forward_train(const oard_config* c, const oard_topology* topo, const vo
     return rc;
 }
 
-size_t oard_packed_bwd_bytes(const oard_config* c) { return config_ok(c) ? make_bwd_layout(c).total * sizeof(float) : 0; }
+}  // extern "C"
+#include "oard_train_layout.h"
+extern "C" {
+
+size_t oard_packed_bwd_bytes(const oard_config* c) {
+    return config_ok(c) ? make_node_bwd_layout(c, make_bwd_layout(c).total).total * sizeof(float) : 0;
+}
 
 int oard_pack_weights_bwd(const oard_config* c, const float* const* params, size_t n_params, void* packed,
                           size_t packed_bytes, oard_stream_t stream) {
@@ -1153,12 +1160,14 @@ int oard_pack_weights_bwd(const oard_config* c, const float* const* params, size
     const ParamIdx pi(c);
     if (n_params != (size_t)pi.count) return OARD_EINVAL;
     const BwdOff bo = make_bwd_layout(c);
-    if (packed_bytes < bo.total * sizeof(float)) return OARD_ENOMEM;
+    const NodeBwdOff nbo = make_node_bwd_layout(c, bo.total);       // the node-side transposes follow the edge-kernel streams
+    if (packed_bytes < nbo.total * sizeof(float)) return OARD_ENOMEM;
     const RDims d(c->hidden, c->num_radial);
     const int H = d.H, W = d.W;
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(packed, 0, bo.total * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(packed, 0, nbo.total * sizeof(float), st));
     Packer pk{params, (float*)packed, st};
+    pack_node_bwd(c, pk, nbo);
     for (int l = 0; l < c->num_layers; ++l) {
         const int g = pi.gcl0 + 14 * l, m = pi.msg0 + 9 * l;
         const size_t t3 = bo.layer[l].gcl, t2 = t3 + (size_t)d.WB * d.HT * 256, t1 = t2 + (size_t)d.HT * d.HT * 256;
@@ -1274,18 +1283,19 @@ size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows) {
     return std::max(big, (size_t)1024 * 1024 * sizeof(float));        // the small-output path: <= 1024 chunks x <= 1024 outputs
 }
 
-int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, const float* X, int ldX, int ncX,
-               int x_silu, int i_len, int i_pad, int MI, int64_t rows, float* dW, float* db, void* scratch,
-               size_t scratch_bytes, oard_stream_t stream) {
-    if (!dY || !X || !dW || !scratch || rows < 0 || (ncY & 3) || (ncX & 3) || (ldY & 3) || (ldX & 3) || ncY > ldY ||
-        ncX > ldX || o_len < 1 || i_len < 1 || o_pad < o_len || i_pad < i_len || MO < 1 || MI < 1)
+// dW (row stride ldW: the destination may be a column slice of a wider nn.Linear weight; nullptr: bias only) and db; acc != 0:
+// the result is ADDED to the destination (parameters shared between layers, gradient accumulation into .grad)
+static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, const float* X, int ldX, int ncX,
+                      int x_silu, int i_len, int i_pad, int MI, int64_t rows, float* dW, int ldW, float* db, int acc, void* scratch,
+                      size_t scratch_bytes, hipStream_t st) {
+    if (!dY || !X || (!dW && !db) || !scratch || rows < 0 || (ncY & 3) || (ncX & 3) || (ldY & 3) || (ldX & 3) || ncY > ldY ||
+        ncX > ldX || o_len < 1 || i_len < 1 || o_pad < o_len || i_pad < i_len || MO < 1 || MI < 1 || ldW < MI)
         return OARD_EINVAL;
     if (((MO - 1) / o_len) * o_pad + (MO - 1) % o_len >= ncY || ((MI - 1) / i_len) * i_pad + (MI - 1) % i_len >= ncX)
         return OARD_EINVAL;
     const WgradPlan p = wgrad_plan(ncY, ncX, rows);
     if (x_silu && p.transposed) return OARD_EINVAL;          // SiLU-on-load exists for the narrow operand only (never needed otherwise)
     if (scratch_bytes < oard_wgrad_scratch_bytes(ncY, ncX, rows)) return OARD_ENOMEM;
-    hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)scratch;
     if (o_len >= MO && i_len >= MI && MO <= 64 && MI < 64 && MO * (MI + 1) <= 1024) {      // small, unsectioned outputs
         const int n_chunks = (int)std::max<long long>(1, std::min<long long>(1024, cdiv(rows, 256)));
@@ -1293,7 +1303,7 @@ int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, 
         const int nch = (int)cdiv(std::max<long long>(rows, 1), rpc);
         ScopedLaunch sl_(F_WGRAD, st);
         hipLaunchKernelGGL(k_wgrad_small, dim3(nch), dim3(256), 0, st, dY, ldY, MO, X, ldX, MI, x_silu, (long long)rows, rpc, partial);
-        hipLaunchKernelGGL(k_wgrad_small_reduce, dim3((unsigned)cdiv(MO * (MI + 1), 4)), dim3(256), 0, st, partial, nch, MO, MI, dW, db);
+        hipLaunchKernelGGL(k_wgrad_small_reduce, dim3((unsigned)cdiv(MO * (MI + 1), 4)), dim3(256), 0, st, partial, nch, MO, MI, dW, ldW, db, acc);
         HIP_TRY(hipGetLastError());
         return OARD_OK;
     }
@@ -1311,13 +1321,119 @@ int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, 
         if (p.NT == 7) { if (x_silu) WG_LAUNCH(true, 7); else WG_LAUNCH(false, 7); }
         else { if (x_silu) WG_LAUNCH(true, 8); else WG_LAUNCH(false, 8); }
 #undef WG_LAUNCH
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 256)), dim3(256), 0, st, partial, p.n_chunks, p.PP,
-                           p.QP, p.transposed, o_len, o_pad, MO, i_len, i_pad, MI, dW);
+        if (dW)
+            hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 256)), dim3(256), 0, st, partial, p.n_chunks, p.PP,
+                               p.QP, p.transposed, o_len, o_pad, MO, i_len, i_pad, MI, dW, ldW, acc);
         if (db)
             hipLaunchKernelGGL(k_bgrad_reduce, dim3((unsigned)cdiv(MO, 4)), dim3(256), 0, st, bpartial, p.n_chunks,
-                               p.transposed ? p.QP : p.PP, o_len, o_pad, MO, db);
+                               p.transposed ? p.QP : p.PP, o_len, o_pad, MO, db, acc);
     }
     HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
+int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, const float* X, int ldX, int ncX,
+               int x_silu, int i_len, int i_pad, int MI, int64_t rows, float* dW, float* db, void* scratch,
+               size_t scratch_bytes, oard_stream_t stream) {
+    if (!dW) return OARD_EINVAL;
+    return wgrad_impl(dY, ldY, ncY, o_len, o_pad, MO, X, ldX, ncX, x_silu, i_len, i_pad, MI, rows, dW, MI, db, 0, scratch, scratch_bytes,
+                      (hipStream_t)stream);
+}
+
+}  // extern "C"
+#include "oard_train_stages.h"
+extern "C" {
+
+// ---- the backward sweep through the C ABI (include/oard.h) ------------------------------------------------------------------------
+size_t oard_train_scratch_bytes(const oard_config* c, const oard_topology* topo) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1) return 0;
+    return make_train_tail(c, topo->parts[0].d, make_train_ws(c, topo->parts[0].d).total).total;
+}
+
+#define TRAIN_ENTER()                                                                                                          \
+    if (!config_ok(c) || !topo || topo->n_parts != 1 || !packed || !packed_bwd || !tape || !scratch) return OARD_EINVAL;       \
+    if (scratch_bytes < oard_train_scratch_bytes(c, topo)) return OARD_ENOMEM;                                                  \
+    const TopoDev& tp = topo->parts[0].d;                                                                                      \
+    const TrainCtx x(c, &tp, packed, packed_bwd, tape, scratch, params, grads, (hipStream_t)stream);                           \
+    const TrainTail tw = make_train_tail(c, tp, x.w.total);                                                                    \
+    (void)tw;                                                                                                                  \
+    int rc = OARD_EINVAL
+
+int oard_train_scratch_poison(const oard_config* c, const oard_topology* topo, void* scratch, size_t scratch_bytes, oard_stream_t stream) {
+    if (!scratch || scratch_bytes < oard_train_scratch_bytes(c, topo)) return OARD_EINVAL;
+    HIP_TRY(hipMemsetAsync(scratch, 0xFF, oard_train_scratch_bytes(c, topo), (hipStream_t)stream));
+    return OARD_OK;
+}
+
+int oard_train_layer_backward(const oard_config* c, const oard_topology* topo, const void* packed, const void* packed_bwd,
+                              const void* tape, int layer, float* ds, float* dvec, float* dew, const float* const* params,
+                              float* const* grads, void* scratch, size_t scratch_bytes, oard_stream_t stream) {
+    TRAIN_ENTER();
+    if (!ds || !dvec || !dew || layer < 0 || layer >= c->num_layers) return OARD_EINVAL;
+    DISPATCH_DIMS(c, rc = tr_layer_bwd<D>(x, layer, ds, dvec, dew));
+    return rc;
+}
+
+int oard_train_tail_backward(const oard_config* c, const oard_topology* topo, const void* packed, const void* packed_bwd,
+                             const void* tape, const float* const* grad_out, float* ds, float* dvec, const float* const* params,
+                             float* const* grads, void* scratch, size_t scratch_bytes, oard_stream_t stream) {
+    TRAIN_ENTER();
+    if (!ds || !dvec) return OARD_EINVAL;
+    if (g_poison) HIP_TRY(hipMemsetAsync(scratch, 0xFF, oard_train_scratch_bytes(c, topo), (hipStream_t)stream));   // first call of a sweep
+    DISPATCH_DIMS(c, rc = tr_tail_bwd<D>(x, tw, topo, grad_out, ds, dvec));
+    return rc;
+}
+
+int oard_train_init_backward(const oard_config* c, const oard_topology* topo, const void* packed, const void* packed_bwd,
+                             const void* tape, const float* const* xh, const float* ds0, const float* dew, const float* const* params,
+                             float* const* grads, void* scratch, size_t scratch_bytes, oard_stream_t stream) {
+    TRAIN_ENTER();
+    if (!xh || !ds0 || !dew || !params) return OARD_EINVAL;
+    DISPATCH_DIMS(c, rc = tr_init_bwd<D>(x, tw, topo, xh, ds0, dew));
+    return rc;
+}
+
+// one stage of a layer in isolation (teacher-forced tests; tests/test_grad_stages.py).  OARD_STAGE_RECOMPUTE must have run for the layer.
+int oard_train_stage_backward(const oard_config* c, const oard_topology* topo, const void* packed, const void* packed_bwd,
+                              const void* tape, int layer, int stage, const float* in0, const float* in1, const float* in2,
+                              float* out0, float* out1, float* out2, const float* const* params, float* const* grads, void* scratch,
+                              size_t scratch_bytes, oard_stream_t stream) {
+    TRAIN_ENTER();
+    if (layer < 0 || layer >= c->num_layers) return OARD_EINVAL;
+    switch (stage) {
+        case OARD_STAGE_RECOMPUTE: DISPATCH_DIMS(c, rc = tr_recompute<D>(x, layer)); break;
+        case OARD_STAGE_UPDATE:    // in: ds, dvec  out: gs_a, gvec_a
+            if (!in0 || !in1 || !out0 || !out1) return OARD_EINVAL;
+            DISPATCH_DIMS(c, rc = tr_update_bwd<D>(x, layer, in0, in1, out0, out1)); break;
+        case OARD_STAGE_MESSAGE:   // in: gs_a, gvec_a  out: gx, dxq, dvec_in   (d cd / d cr per inner edge stay in the scratch)
+            if (!in0 || !in1 || !out0 || !out1 || !out2) return OARD_EINVAL;
+            DISPATCH_DIMS(c, rc = tr_msg_bwd<D>(x, layer, in0, in1, out0, out1, out2)); break;
+        case OARD_STAGE_GCL_NODE:  // in: gx, dxq  out: dxh, dagg
+            if (!in0 || !in1 || !out0 || !out1) return OARD_EINVAL;
+            DISPATCH_DIMS(c, rc = tr_gcl_node_bwd<D>(x, layer, in0, in1, out0, out1)); break;
+        case OARD_STAGE_NODE_PRE:  // in: dxh, dP, dQ  out: ds_in
+            if (!in0 || !in1 || !in2 || !out0) return OARD_EINVAL;
+            DISPATCH_DIMS(c, rc = tr_pre_bwd<D>(x, layer, in0, in1, in2, out0)); break;
+        default: return OARD_EINVAL;
+    }
+    return rc;
+}
+
+// scratch buffers a test may want to look at (xq, cr, d cd, d cr of the last recompute / message stage)
+int oard_train_scratch_entry(const oard_config* c, const oard_topology* topo, int which, size_t* offset_bytes, int64_t* rows,
+                             int64_t* row_floats) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1 || !offset_bytes || !rows || !row_floats) return OARD_EINVAL;
+    const TopoDev& d = topo->parts[0].d;
+    const TrainWs w = make_train_ws(c, d);
+    const RDims r(c->hidden, c->num_radial);
+    switch (which) {
+        case OARD_SCRATCH_XH: *offset_bytes = w.xh; *rows = d.N; *row_floats = r.HP; break;
+        case OARD_SCRATCH_XQ: *offset_bytes = w.xq; *rows = d.N; *row_floats = 3 * r.HP; break;
+        case OARD_SCRATCH_CR: *offset_bytes = w.cr; *rows = d.A + 1; *row_floats = 3 * r.HP; break;
+        case OARD_SCRATCH_DCD: *offset_bytes = w.dcd; *rows = d.A + 1; *row_floats = 3 * r.HP; break;
+        case OARD_SCRATCH_DCR: *offset_bytes = w.dcr; *rows = d.A + 1; *row_floats = 3 * r.HP; break;
+        default: return OARD_EINVAL;
+    }
     return OARD_OK;
 }
 

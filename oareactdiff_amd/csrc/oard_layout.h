@@ -91,6 +91,7 @@ struct oard_topology {
     int n_obj = 0, B = 0;
     long long N = 0, E = 0, A = 0;
     int max_group = 0, max_ns = 0;
+    int obj_start[OARD_MAX_OBJECTS + 1] = {};   // reference (object-major) row ranges of the objects
     hipStream_t side[OARD_MAX_PARTS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[OARD_MAX_PARTS] = {};
 };

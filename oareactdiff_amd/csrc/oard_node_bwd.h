@@ -166,9 +166,28 @@ template <class D>
 __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* __restrict__ geo, Strided3 xq, Strided3 vec,
                                                       const float* __restrict__ cd, Strided3 cr, const float* __restrict__ gX,
                                                       int gx_row, Strided3 gV, float* __restrict__ dcd, float* __restrict__ dcr,
-                                                      float* __restrict__ dxq, float* __restrict__ dvec) {
+                                                      float* __restrict__ dxq, float* __restrict__ dvec, int o_comp) {
+    // outputs d xq / d vec: [N][3][o_comp] (o_comp = H: dense; o_comp = HP: padded, the pads are written as zeros)
     const int n = blockIdx.x, ch = threadIdx.x;
-    if (ch >= D::H) return;
+    if (ch >= D::H) {
+        if (ch < o_comp) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { dxq[((size_t)n * 3 + k) * o_comp + ch] = 0.f; dvec[((size_t)n * 3 + k) * o_comp + ch] = 0.f; }
+            // padded mode: the per-edge gradients feed an MFMA kernel next (W^T rows of the pads are zero, but 0 x NaN is NaN)
+            const int qg = tp.node_sample[n] * tp.n_obj + tp.node_obj[n];
+            const int p0 = tp.grp_ptr[qg], pn = tp.grp_ptr[qg + 1] - p0, me = n - p0;
+            for (int kk = 0; kk < pn; ++kk) {
+                if (kk == me) continue;
+                const size_t a = (size_t)tp.act_ptr[n] + kk - (kk > me ? 1 : 0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    dcd[a * (size_t)(3 * D::HP) + (size_t)k * D::HP + ch] = 0.f;
+                    dcr[a * (size_t)(3 * D::HP) + (size_t)k * D::HP + ch] = 0.f;
+                }
+            }
+        }
+        return;
+    }
     const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt_h = 1.0f / sqrtf((float)D::H);
     const int q_grp = tp.node_sample[n] * tp.n_obj + tp.node_obj[n];
     const int g0 = tp.grp_ptr[q_grp], ng = tp.grp_ptr[q_grp + 1] - g0, self = n - g0;
@@ -225,8 +244,8 @@ __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* _
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        dxq[((size_t)n * 3 + k) * D::H + ch] = ax[k];
-        dvec[((size_t)n * 3 + k) * D::H + ch] = av[k];
+        dxq[((size_t)n * 3 + k) * o_comp + ch] = ax[k];
+        dvec[((size_t)n * 3 + k) * o_comp + ch] = av[k];
     }
 }
 

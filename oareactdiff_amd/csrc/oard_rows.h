@@ -1,0 +1,203 @@
+// oard_rows.h — row-generic building blocks of the node-side backward pass (training path, row N2).
+//
+// The node-side stages of LEFTNet (EquiUpdate, the GCL node MLP, x_proj, pos_expansion + the node halves of edge_mlp.0, the
+// output block, the init head: < 2 % of the FLOPs) act on O(N) rows of H-wide features.  Their adjoints are compositions of
+//   * a dense layer on rows:   Y = epi(W X + b)                      k_rows_dense      (fp32 MFMA column engine, 16 rows / workgroup)
+//   * its transpose:           dX = W^T dY (x SiLU'(z) | + residual)  the same kernel on a transposed weight pack
+//   * LayerNorm forward / backward on rows                            k_rows_ln_fwd / k_rows_ln_bwd
+//   * fixed-order column sums over rows (bias / LayerNorm / gate gradients)   k_colsum_part + k_colsum_fin
+// plus a few bespoke element-wise kernels per stage (oard_train_stages.h).  Everything is row-major [rows][ld] fp32 with the
+// feature pads (196 -> 208) kept at exactly 0: a dense layer's padded output rows have zero weights and zero bias, SiLU(0) = 0,
+// and SiLU'(0) x 0 = 0, so pads never need masking after the first producer (the tape's buffers come with zero pads).
+// Weight gradients are NOT formed here: every stage writes its (dY, X) operand pairs row-major and the weight-gradient GEMM
+// k_wgrad (oard_edge_bwd.h) contracts them over the rows, as for the edge stages.
+#pragma once
+#include "oard_node_v1.h"
+#include "oard_edge_bwd.h"
+#include "oard_node_bwd.h"
+
+enum { EPI_NONE = 0, EPI_SILU = 1, EPI_MUL_DSILU = 2, EPI_ADD = 3 };
+
+struct RowsDense {
+    const float* X; int ldx;        // input rows: K blocks 0 .. KB1-1 are X[r][16 b ..]
+    const float* X2; int ldx2;      // K blocks KB1 .. KB-1 are X2[r][16 (b - KB1) ..]   (concatenated inputs); unused if KB1 == KB
+    int KB1;
+    const float* W;                 // packed chunks [MT][KB] (oard_pack_weights / oard_pack_weights_bwd)
+    const float* bias;              // [16 MT] or nullptr
+    float* Y; int ldy;              // Y[r][16 t ..]
+    const float* Z; int ldz;        // EPI_MUL_DSILU: pre-activation z (Y = acc * SiLU'(z));  EPI_ADD: addend (Y = Z + scale * acc)
+    float* Zo; int ldzo;            // EPI_SILU: optional copy of the pre-activation (Zo = acc + bias), Y = SiLU(Zo)
+    long long rows;
+    int MT;
+    float scale;
+};
+
+template <int KB, int EPI, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_rows_dense(RowsDense a) {
+    __shared__ __attribute__((aligned(16))) float xin[KB * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r = (long long)blockIdx.x * 16 + (lane & 15);
+    const bool valid = r < a.rows;
+    const size_t row = (size_t)(valid ? r : a.rows - 1);
+    for (int b = wave; b < KB; b += WAVES) {
+        const f4 v = b < a.KB1 ? ld_blk(a.X, row, a.ldx, b, lane) : ld_blk(a.X2, row, a.ldx2, b - a.KB1, lane);
+        lds_st(xin, b, lane, v);
+    }
+    __syncthreads();
+    for (int t = wave; t < a.MT; t += WAVES) {
+        f4 acc = a.bias != nullptr ? ld_vec(a.bias, t, lane) : f4zero();
+        acc = dense_tile_lds<KB>(a.W, t, xin, lane, acc);
+        if (!valid) continue;
+        if (EPI == EPI_SILU) {
+            if (a.Zo != nullptr) st_blk(a.Zo, row, a.ldzo, t, lane, acc);
+            acc = silu4(acc);
+        } else if (EPI == EPI_MUL_DSILU) {
+            acc = acc * dsilu4(ld_blk(a.Z, row, a.ldz, t, lane));
+        } else if (EPI == EPI_ADD) {
+            acc = ld_blk(a.Z, row, a.ldz, t, lane) + acc * a.scale;
+        }
+        st_blk(a.Y, row, a.ldy, t, lane, acc);
+    }
+}
+
+// ---- LayerNorm on rows (torch.nn.LayerNorm: biased variance, eps = 1e-5 inside the sqrt) ---------------------------------------
+// one wave per row; HP <= 256 (4 features per lane).  gamma / beta may be nullptr (no affine part).
+// Y = LN(X + (Xadd ? Xadd : 0)); Sum (optional) receives X + Xadd (the tensor the statistics are taken of)
+__global__ __launch_bounds__(256) void k_rows_ln_fwd(const float* __restrict__ X, const float* __restrict__ Xadd, int ld, int H, int HP,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ Y, float* __restrict__ Sum, long long rows) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63, c0 = 4 * lane;
+    f4 x = f4zero();
+    if (c0 < HP) {
+        x = ld_f4(X + (size_t)r * ld + c0);
+        if (Xadd != nullptr) x += ld_f4(Xadd + (size_t)r * ld + c0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += c0 + i < H ? x[i] : 0.f;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float mean = s * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float dx = x[i] - mean; q += c0 + i < H ? dx * dx : 0.f; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / H) + 1e-5f);
+    if (c0 < HP) {
+        f4 y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = (x[i] - mean) * rstd;
+            if (gamma != nullptr) v = v * gamma[c0 + i] + beta[c0 + i];
+            y[i] = c0 + i < H ? v : 0.f;
+        }
+        *reinterpret_cast<f4*>(Y + (size_t)r * ld + c0) = y;
+        if (Sum != nullptr) *reinterpret_cast<f4*>(Sum + (size_t)r * ld + c0) = x;
+    }
+}
+// adjoint: given X (the normalised tensor's input) and dY:   dxhat = dY * gamma;
+//   dX = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));   G = dY * xhat (its column sums are d gamma; those of dY are d beta)
+// dX = (Dadd ? Dadd : 0) + that.
+__global__ __launch_bounds__(256) void k_rows_ln_bwd(const float* __restrict__ X, int ld, int H, int HP, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dY, const float* __restrict__ Dadd,
+                                                     float* __restrict__ dX, float* __restrict__ G, long long rows) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63, c0 = 4 * lane;
+    f4 x = f4zero(), dy = f4zero();
+    if (c0 < HP) { x = ld_f4(X + (size_t)r * ld + c0); dy = ld_f4(dY + (size_t)r * ld + c0); }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += c0 + i < H ? x[i] : 0.f;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float mean = s * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float dx = x[i] - mean; q += c0 + i < H ? dx * dx : 0.f; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / H) + 1e-5f);
+    f4 xhat, dxh;
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool ok = c0 + i < H;
+        xhat[i] = ok ? (x[i] - mean) * rstd : 0.f;
+        dxh[i] = ok ? dy[i] * (gamma != nullptr ? gamma[c0 + i] : 1.0f) : 0.f;
+        m1 += dxh[i];
+        m2 += dxh[i] * xhat[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { m1 += __shfl_xor(m1, d, 64); m2 += __shfl_xor(m2, d, 64); }
+    m1 *= 1.0f / H; m2 *= 1.0f / H;
+    if (c0 < HP) {
+        f4 o, g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = c0 + i < H;
+            o[i] = ok ? rstd * (dxh[i] - m1 - xhat[i] * m2) : 0.f;
+            g[i] = ok ? dy[i] * xhat[i] : 0.f;
+        }
+        if (Dadd != nullptr) o += ld_f4(Dadd + (size_t)r * ld + c0);
+        *reinterpret_cast<f4*>(dX + (size_t)r * ld + c0) = o;
+        if (G != nullptr) *reinterpret_cast<f4*>(G + (size_t)r * ld + c0) = g;
+    }
+}
+
+// ---- fixed-order column sums over rows [r0, r1) of a row-major buffer: out[c] (+)= sum_r w(r) X[r][c] ------------------------------
+// pass 1: row chunk q (CS_ROWS rows) -> part[q][c] (ascending rows, one thread per column);  pass 2: one wave per column adds the
+// chunks in a fixed order (chunk_sum_wave).  Deterministic, no atomics.  Optional per-row weight (a [rows] vector, e.g. the gate
+// adjoint) and SiLU applied to X on load (the att_mlp gradient: sum_e da_e SiLU(z2_e)).
+#define CS_ROWS 64
+__global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
+                                                     const float* __restrict__ wrow, int x_silu, float* __restrict__ part) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    const long long rb = r0 + (long long)blockIdx.x * CS_ROWS, re = rb + CS_ROWS < r1 ? rb + CS_ROWS : r1;
+    float s = 0.f;
+    for (long long r = rb; r < re; ++r) {
+        float v = X[(size_t)r * ld + c];
+        if (x_silu) v = silu1(v);
+        s += wrow != nullptr ? v * wrow[r] : v;
+    }
+    part[(size_t)blockIdx.x * ncols + c] = s;
+}
+__global__ __launch_bounds__(256) void k_colsum_fin(const float* __restrict__ part, int n_chunks, int ncols, float* __restrict__ out,
+                                                    int accumulate, float scale) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= ncols) return;
+    const float s = chunk_sum_wave(part + c, (size_t)ncols, n_chunks, threadIdx.x & 63) * scale;
+    if ((threadIdx.x & 63) == 0) out[c] = accumulate ? out[c] + s : s;
+}
+
+// out[i][j] (+)= a[i] * b[j]   (the constant-row term of layer 0's edge_mlp.0 gradient: outer(sum_e dz1_e, c0row))
+__global__ void k_outer_acc(float* __restrict__ out, int ld, const float* __restrict__ a, int na, const float* __restrict__ b, int nb_,
+                            int accumulate) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)na * nb_) return;
+    const int i = (int)(idx / nb_), j = (int)(idx % nb_);
+    const float v = a[i] * b[j];
+    float* o = out + (size_t)i * ld + j;
+    *o = accumulate ? *o + v : v;
+}
+
+// out[i * stride] += a[i]   (a gradient that lands in one column of a wider parameter)
+__global__ void k_strided_acc(const float* __restrict__ a, int n, float* __restrict__ out, int stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[(size_t)i * stride] += a[i];
+}
+__global__ void k_silu_rows(const float* __restrict__ z, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = silu1(z[i]);
+}
+// out = a * SiLU'(z)
+__global__ void k_mul_dsilu_rows(const float* __restrict__ a, const float* __restrict__ z, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float zz = z[i], s = __builtin_amdgcn_rcpf(1.0f + __expf(-zz));
+    out[i] = a[i] * (s * (1.0f + zz * (1.0f - s)));
+}

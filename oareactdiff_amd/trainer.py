@@ -88,6 +88,8 @@ class DDPMTrainer:
         for p in self.params:                          # p.grad = view into the bucket: backward accumulates in place
             p.grad = self.flat_grad[off: off + p.numel()].view_as(p)
             off += p.numel()
+        if hasattr(dynamics, "_get_packed_bwd"):        # the HIP module: its backward accumulates straight into these .grad views
+            dynamics.grad_inplace = True
         self.optimizer = torch.optim.AdamW(self.params, **dict(DEFAULT_OPTIMIZER, **(optimizer_config or {})))
         self.clip_grad = clip_grad
         if clip_grad:                                  # pl_trainer.py:143-146

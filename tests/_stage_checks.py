@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from _grad_cases import CNF, NODE_NFS, GradCase
+import _stage_refs as refs
 from oareactdiff_amd import _capi, training
 from oareactdiff_amd.dynamics import EGNNDynamics
 
@@ -50,34 +51,74 @@ def run(name, log=print):
     P = dyn._param_dict()
     log(f"{name}: N {N} E {E} A {A} loss {float(loss.detach()):.8f} ref64 {float(c.z['f64_loss']):.8f}")
     geo = tape.get(_capi.TAPE_GEO)[:A]
-    g = training.Geometry(topo.inner_src, topo.inner_tgt, topo.node_sample, topo.node_group, topo.B, topo.B * 3, geo,
+    g = refs.Geometry(topo.inner_src, topo.inner_tgt, topo.node_sample, topo.node_group, topo.B, topo.B * 3, geo,
                           tape.get(_capi.TAPE_RBF)[:A, :R], tape.get(_capi.TAPE_PP0)[:, 0], tape.get(_capi.TAPE_X1))
     stream = torch.cuda.current_stream(dev).cuda_stream
     L = _capi.lib()
+    packed_f, packed_b = dyn._get_packed(cfg, stream), dyn._get_packed_bwd(cfg, stream)
+    sc_buf = torch.empty(L.oard_train_scratch_bytes(C.byref(cfg), topo.handle), dtype=torch.uint8, device=dev)
+    _capi.check(L.oard_train_scratch_poison(C.byref(cfg), topo.handle, sc_buf.data_ptr(), sc_buf.numel(), stream), "poison")
+    tensors_all = dyn._ordered_tensors()
+    params_tab = (C.c_void_p * len(tensors_all))(*[t.data_ptr() for t in tensors_all])
+
+    def pad(x):                        # [N, H] -> [N, HP] with zero pads
+        o = torch.zeros(x.shape[0], HP, device=dev)
+        o[:, :H] = x
+        return o
+
+    def pad3(x):                       # [N, 3, H] -> [3N, HP]
+        o = torch.zeros(x.shape[0], 3, HP, device=dev)
+        o[:, :, :H] = x
+        return o.view(3 * x.shape[0], HP)
+
+    def unpad(x):
+        return x.view(-1, HP)[:, :H]
+
+    def unpad3(x):
+        return x.view(-1, 3, HP)[:, :, :H]
+
+    def scratch(which):
+        off, rows, ld = C.c_size_t(0), C.c_int64(0), C.c_int64(0)
+        _capi.check(L.oard_train_scratch_entry(C.byref(cfg), topo.handle, which, C.byref(off), C.byref(rows), C.byref(ld)), "scratch entry")
+        return sc_buf[off.value: off.value + 4 * rows.value * ld.value].view(torch.float32).view(rows.value, ld.value)
+
+    def grad_dests(names):
+        """fresh zero destinations for the named parameters -> (table, {name: tensor})"""
+        d = {n_: torch.zeros_like(P[n_]) for n_ in names}
+        return training.gradient_table(dyn, {id(P[n_]): t for n_, t in d.items()}), d
+
+    def stage(which, layer, ins=(), outs=(), names=()):
+        tab, d = grad_dests(names)
+        ip = [t.data_ptr() for t in ins] + [None] * (3 - len(ins))
+        op = [t.data_ptr() for t in outs] + [None] * (3 - len(outs))
+        _capi.check(L.oard_train_stage_backward(C.byref(cfg), topo.handle, packed_f.data_ptr(), packed_b.data_ptr(), tape.buf.data_ptr(),
+                                                layer, which, *ip, *op, params_tab, tab, sc_buf.data_ptr(), sc_buf.numel(), stream),
+                    f"oard_train_stage_backward({which})")
+        return d
     with torch.no_grad():
         # ---- 1. forward consistency of the stage functions -------------------------------------------------------
         hin = tape.get(_capi.TAPE_HIN)[:, :Cc]
-        s0, ew0, c0 = training.stage_init(P, hin, g, H)
+        s0, ew0, c0 = refs.stage_init(P, hin, g, H)
         note("fwd init: s0, ew0", rel(s0, tape.get(_capi.TAPE_S_IN, 0)[:, :H]), rel(ew0, tape.get(_capi.TAPE_EW, 0)[:A, :W]))
         for l in range(NL):
             s_in = tape.get(_capi.TAPE_S_IN, l)[:, :H]
             vec_in = tape.get(_capi.TAPE_VEC_IN, l).view(N, 3, HP)[:, :, :H]
-            xh, Pn, Qn = training.stage_node_pre(P, l, s_in, g, H)
+            xh, Pn, Qn = refs.stage_node_pre(P, l, s_in, g, H)
             agg = tape.get(_capi.TAPE_AGG, l)[:, :H]
             cd = tape.get(_capi.TAPE_CD, l)[:A].view(A, 3, HP)[:, :, :H]
-            s_out, vec_out = training.stage_node_mid(P, l, xh, agg, cd, vec_in, g, H)
+            s_out, vec_out = refs.stage_node_mid(P, l, xh, agg, cd, vec_in, g, H)
             note(f"fwd layer {l}: s_out, vec_out", rel(s_out, tape.get(_capi.TAPE_S_IN, l + 1)[:, :H]),
                  rel(vec_out, tape.get(_capi.TAPE_VEC_IN, l + 1).view(N, 3, HP)[:, :, :H]))
     # ---- 2a. edge scalarisation + lin3 (k_scalarize): HIP adjoint vs torch autograd, random cotangent ------------------
     if A > 0:
         with torch.no_grad():
-            _, NE1, _, _ = training.stage_init_head(P, hin, g, H)
+            _, NE1, _, _ = refs.stage_init_head(P, hin, g, H)
         gen0 = torch.Generator(device="cpu").manual_seed(11)
         Gs = torch.randn(A, 2 * H, generator=gen0).to(dev)
         l3n = ["model.lin3.0.weight", "model.lin3.0.bias", "model.lin3.2.weight", "model.lin3.2.bias"]
         NE1t = NE1.detach().clone().requires_grad_(True)
         with torch.enable_grad():
-            sc = training.stage_scalarize(P, NE1t, g, H)
+            sc = refs.stage_scalarize(P, NE1t, g, H)
         gs = torch.autograd.grad([sc], [NE1t] + [P[n] for n in l3n], [Gs])
         dews = torch.zeros(E + 1, WP, device=dev)
         dews[:A, :2 * H] = Gs
@@ -104,7 +145,7 @@ def run(name, log=print):
         last = l == NL - 1
         with torch.no_grad():
             s_in = tape.get(_capi.TAPE_S_IN, l)[:, :H]
-            xh, Pn, Qn = training.stage_node_pre(P, l, s_in, g, H)
+            xh, Pn, Qn = refs.stage_node_pre(P, l, s_in, g, H)
         c0row = dyn._c0row(P, H, R).detach()
         ew_l = tape.get(_capi.TAPE_EW, l)[:E, :W].clone()
         if l == 0:
@@ -154,45 +195,72 @@ def run(name, log=print):
         note(f"bwd layer {l} gcl: dW1c", rel(gw, gr[3][:, 2 * H:]))
         m0t = F.silu(tape.get(_capi.TAPE_Z2, l)[:E, :H])
         note(f"bwd layer {l} gcl: dwatt, dbatt", rel((da[:E, None] * m0t).sum(0, keepdim=True), gr[8]), rel(da[:E].sum().reshape(1), gr[9]))
-        # ---- EquiMessage gather half (k_equi_node_v1 part 1): HIP adjoint vs torch autograd ----
-        if A > 0:
-            with torch.no_grad():
-                agg0 = tape.get(_capi.TAPE_AGG, l)[:, :H]
-                s_mid, xq0 = training.stage_gcl_node(P, l, xh, agg0, H)
-            xq_t = xq0.detach().clone().requires_grad_(True)
-            cd_t = tape.get(_capi.TAPE_CD, l)[:A].view(A, 3, HP)[:, :, :H].detach().clone().requires_grad_(True)
-            vec_t = tape.get(_capi.TAPE_VEC_IN, l).view(N, 3, HP)[:, :, :H].detach().clone().requires_grad_(True)
-            rbfw = P[e + "rbf_proj.weight"]
-            with torch.enable_grad():
-                s_a, vec_a = training.stage_equi_message(P, l, s_mid, xq_t, cd_t, vec_t, g, H)
-            note(f"fwd layer {l} equi message: s_a, vec_a", rel(s_a, tape.get(_capi.TAPE_S_A, l)[:, :H]),
-                 rel(vec_a, tape.get(_capi.TAPE_VEC_A, l).view(N, 3, HP)[:, :, :H]))
-            gS, gVc = torch.randn(N, H, generator=gen).to(dev), torch.randn(N, 3, H, generator=gen).to(dev)
-            gm = torch.autograd.grad([s_a, vec_a], [xq_t, cd_t, vec_t, rbfw], [gS, gVc])
-            gxh = (gS * training.INV_SQRT2).contiguous()
-            crh = F.linear(g.rbf, rbfw).detach()
-            dcdh, dcrh = torch.zeros(A + 1, 3, HP, device=dev), torch.zeros(A + 1, 3, HP, device=dev)
-            dxqh, dvech = torch.empty(N, 3 * H, device=dev), torch.empty(N, 3, H, device=dev)
-            _capi.check(L.oard_equi_msg_backward(C.byref(cfg), topo.handle, tape.buf.data_ptr(), l, xq0.contiguous().data_ptr(), crh.data_ptr(),
-                                                 gxh.data_ptr(), gVc.contiguous().data_ptr(), dcdh.data_ptr(), dcrh.data_ptr(), dxqh.data_ptr(),
-                                                 dvech.data_ptr(), stream), "equi msg bwd")
-            grbf = training._wgrad(dcrh.view(A + 1, 3 * HP), 3 * HP, H, HP, 3 * H, tape.get(_capi.TAPE_RBF), training._pad16(R), False, R, R, R,
-                                   A, False, dyn, stream)[0]
-            note(f"bwd layer {l} equi message: dxq, dcd, dvec, drbf_proj", rel(dxqh, gm[0]), rel(dcdh[:A, :, :H], gm[1]), rel(dvech, gm[2]),
-                 rel(grbf, gm[3]))
-        # ---- EquiUpdate with the HIP frame-scalar op (Lin3uFunction) vs the plain torch formulation ----
+        # ---- node-side stages of the layer through oard_train_stage_backward, each against torch autograd of its restatement ----
+        agg0 = tape.get(_capi.TAPE_AGG, l)[:, :H]
+        with torch.no_grad():
+            s_mid_r, xq_r = refs.stage_gcl_node(P, l, xh, agg0, H)
+        stage(_capi.STAGE_RECOMPUTE, l)
+        note(f"recompute layer {l}: xh, xq", rel(unpad(scratch(_capi.SCRATCH_XH)), xh), rel(unpad3(scratch(_capi.SCRATCH_XQ)), xq_r.view(N, 3, H)))
+        # EquiUpdate
         un = [n_ for n_ in P if n_.startswith(f"model.update_layers.{l}.")]
         sa0 = tape.get(_capi.TAPE_S_A, l)[:, :H]
         va0 = tape.get(_capi.TAPE_VEC_A, l).view(N, 3, HP)[:, :, :H]
         cs, cv = torch.randn(N, H, generator=gen).to(dev), torch.randn(N, 3, H, generator=gen).to(dev)
-        res = []
-        for hip in (None, (dyn, cfg, l, stream)):
-            a_, b_ = sa0.detach().clone().requires_grad_(True), va0.detach().clone().requires_grad_(True)
+        a_, b_ = sa0.detach().clone().requires_grad_(True), va0.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            o1, o2 = refs.stage_equi_update(P, l, a_, b_, g, H)
+        note(f"fwd layer {l} equi update: s, vec", rel(o1, tape.get(_capi.TAPE_S_IN, l + 1)[:, :H]),
+             rel(o2, tape.get(_capi.TAPE_VEC_IN, l + 1).view(N, 3, HP)[:, :, :H]))
+        gu = torch.autograd.grad([o1, o2], [a_, b_] + [P[n_] for n_ in un], [cs, cv])
+        gs_a, gvec_a = torch.empty(N, HP, device=dev), torch.empty(3 * N, HP, device=dev)
+        gt = stage(_capi.STAGE_UPDATE, l, (pad(cs), pad3(cv)), (gs_a, gvec_a), un)
+        note(f"bwd layer {l} equi update: ds_a, dvec_a, " + " ".join(n_.split(".", 3)[3] for n_ in un), rel(unpad(gs_a), gu[0]),
+             rel(unpad3(gvec_a), gu[1]), *[rel(gt[n_], gu[2 + i]) for i, n_ in enumerate(un)])
+        # EquiMessage gather half
+        if A > 0:
+            xq_t = xq_r.detach().clone().requires_grad_(True)
+            cd_t = tape.get(_capi.TAPE_CD, l)[:A].view(A, 3, HP)[:, :, :H].detach().clone().requires_grad_(True)
+            vec_t = tape.get(_capi.TAPE_VEC_IN, l).view(N, 3, HP)[:, :, :H].detach().clone().requires_grad_(True)
+            rbfn = e + "rbf_proj.weight"
             with torch.enable_grad():
-                o1, o2 = training.stage_equi_update(P, l, a_, b_, g, H, hip=hip)
-            res.append((o1.detach(), o2.detach(), torch.autograd.grad([o1, o2], [a_, b_] + [P[n_] for n_ in un], [cs, cv])))
-        note(f"fwd layer {l} equi update (HIP lin3u vs torch): s, vec", rel(res[1][0], res[0][0]), rel(res[1][1], res[0][1]))
-        note(f"bwd layer {l} equi update (HIP lin3u vs torch)", *[rel(x_, y_) for x_, y_ in zip(res[1][2], res[0][2])])
+                s_a, vec_a = refs.stage_equi_message(P, l, s_mid_r, xq_t, cd_t, vec_t, g, H)
+            note(f"fwd layer {l} equi message: s_a, vec_a", rel(s_a, tape.get(_capi.TAPE_S_A, l)[:, :H]),
+                 rel(vec_a, tape.get(_capi.TAPE_VEC_A, l).view(N, 3, HP)[:, :, :H]))
+            gS, gVc = torch.randn(N, H, generator=gen).to(dev), torch.randn(N, 3, H, generator=gen).to(dev)
+            gm = torch.autograd.grad([s_a, vec_a], [xq_t, cd_t, vec_t, P[rbfn]], [gS, gVc])
+            gx_o, dxq_o, dvec_o = torch.empty(N, HP, device=dev), torch.empty(N, 3 * HP, device=dev), torch.empty(3 * N, HP, device=dev)
+            gt = stage(_capi.STAGE_MESSAGE, l, (pad(gS), pad3(gVc)), (gx_o, dxq_o, dvec_o), [rbfn])
+            note(f"bwd layer {l} equi message: gx, dxq, dcd, dvec, drbf_proj", rel(unpad(gx_o), gS * refs.INV_SQRT2),
+                 rel(unpad3(dxq_o).reshape(N, 3 * H), gm[0]), rel(scratch(_capi.SCRATCH_DCD)[:A].view(A, 3, HP)[:, :, :H], gm[1]),
+                 rel(unpad3(dvec_o), gm[2]), rel(gt[rbfn], gm[3]))
+            pads = scratch(_capi.SCRATCH_DCD).view(A + 1, 3, HP)
+            assert float(pads[:A, :, H:].abs().max() if HP > H else 0.0) == 0.0          # the MFMA edge kernel reads the pads
+        # GCL node update + x_proj
+        gn = [n_ for n_ in P if n_.startswith((q + "node_mlp.", e + "x_layernorm.", e + "x_proj."))]
+        xh_t, agg_t = xh.detach().clone().requires_grad_(True), agg0.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            sm_t, xq_t2 = refs.stage_gcl_node(P, l, xh_t, agg_t, H)
+        note(f"fwd layer {l} gcl node: s_mid", rel(sm_t, tape.get(_capi.TAPE_S_MID, l)[:, :H]))
+        c1, c2 = torch.randn(N, H, generator=gen).to(dev), torch.randn(N, 3, H, generator=gen).to(dev)
+        gg = torch.autograd.grad([sm_t, xq_t2], [xh_t, agg_t] + [P[n_] for n_ in gn], [c1, c2.reshape(N, 3 * H)])
+        dxh_o, dagg_o = torch.empty(N, HP, device=dev), torch.empty(N, HP, device=dev)
+        gt = stage(_capi.STAGE_GCL_NODE, l, (pad(c1), pad3(c2).view(N, 3 * HP)), (dxh_o, dagg_o), gn)
+        note(f"bwd layer {l} gcl node: dxh, dagg, " + " ".join(n_.split(".", 3)[3] for n_ in gn), rel(unpad(dxh_o), gg[0]), rel(unpad(dagg_o), gg[1]),
+             *[rel(gt[n_], gg[2 + i]) for i, n_ in enumerate(gn)])
+        # pos_expansion + LayerNorm + node halves of edge_mlp.0
+        pn = [n_ for n_ in P if n_.startswith(("model.pos_expansion.", q + "x_layernorm."))] + [q + "edge_mlp.mlp.0.linear.weight", q + "edge_mlp.mlp.0.linear.bias"]
+        s_t = tape.get(_capi.TAPE_S_IN, l)[:, :H].detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            xh2, P2, Q2 = refs.stage_node_pre(P, l, s_t, g, H)
+        c1, c2, c3 = (torch.randn(N, H, generator=gen).to(dev) for _ in range(3))
+        gp = torch.autograd.grad([xh2, P2, Q2], [s_t] + [P[n_] for n_ in pn], [c1, c2, c3])
+        ds_o = torch.empty(N, HP, device=dev)
+        gt = stage(_capi.STAGE_NODE_PRE, l, (pad(c1), pad(c2), pad(c3)), (ds_o,), pn)
+        w1g = gt[q + "edge_mlp.mlp.0.linear.weight"]
+        assert float(w1g[:, 2 * H:].abs().max()) == 0.0                               # the edge columns belong to the edge kernel's GEMM
+        note(f"bwd layer {l} node pre: ds_in, " + " ".join(n_.split(".", 2)[2] for n_ in pn), rel(unpad(ds_o), gp[0]),
+             *[rel(gt[n_][:, :2 * H] if n_.endswith("edge_mlp.mlp.0.linear.weight") else gt[n_],
+                   gp[1 + i][:, :2 * H] if n_.endswith("edge_mlp.mlp.0.linear.weight") else gp[1 + i]) for i, n_ in enumerate(pn)])
         # ---- Equi edge ----
         if A > 0:
             ew1 = tape.get(_capi.TAPE_EW, l + 1)[:A, :W].detach().clone().requires_grad_(True)
@@ -214,6 +282,45 @@ def run(name, log=print):
                                        dyn, stream)
             note(f"bwd layer {l} equi: dew, dp0 w b, dp2 w b", rel(dew2[:A, :W], ge[0]), rel(gw0, ge[1]), rel(gb0, ge[2]),
                  rel(gw2, ge[3]), rel(gb2, ge[4]))
+    # ---- tail (output block + velocity / CoM + decoders) and init head + encoders through the C ABI, vs torch autograd --------------
+    n_obj, emb = len(NODE_NFS), dyn.embed_dim
+    dec = [dyn._module_prefix("decoders", k) for k in range(n_obj)]
+    enc = [dyn._module_prefix("encoders", k) for k in range(n_obj)]
+    tn = [n_ for n_ in P if n_.startswith(("model.out_pos.", "model.embedding_out.", *dec))]
+    s_t = tape.get(_capi.TAPE_S_IN, NL)[:, :H].detach().clone().requires_grad_(True)
+    v_t = tape.get(_capi.TAPE_VEC_IN, NL).view(N, 3, HP)[:, :, :H].detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        outs_t = refs.stage_tail(P, dec, s_t, v_t, topo.node_group, topo.B * n_obj, topo.group_count, topo.obj_rows, topo.node_row, emb)
+    cots = [torch.randn(o_.shape, generator=gen).to(dev) for o_ in outs_t]
+    gtl = torch.autograd.grad(list(outs_t), [s_t, v_t] + [P[n_] for n_ in tn], cots, allow_unused=True)
+    ds_o, dvec_o = torch.empty(N, HP, device=dev), torch.empty(3 * N, HP, device=dev)
+    tab, dd = grad_dests(tn)
+    go = (C.c_void_p * n_obj)(*[c_.contiguous().data_ptr() for c_ in cots])
+    _capi.check(L.oard_train_tail_backward(C.byref(cfg), topo.handle, packed_f.data_ptr(), packed_b.data_ptr(), tape.buf.data_ptr(), go,
+                                           ds_o.data_ptr(), dvec_o.data_ptr(), params_tab, tab, sc_buf.data_ptr(), sc_buf.numel(), stream), "tail")
+    zero = lambda t_, like: torch.zeros_like(like) if t_ is None else t_      # noqa: E731
+    note("bwd tail: ds, dvec, " + " ".join(n_.split(".", 1)[1] for n_ in tn), rel(unpad(ds_o), gtl[0]), rel(unpad3(dvec_o), gtl[1]),
+         *[rel(dd[n_], zero(gtl[2 + i], P[n_])) for i, n_ in enumerate(tn)])
+    inn = [n_ for n_ in P if n_.startswith(("model.embedding.", "model.neighbor_emb.", "model.s2v.", "model.radial_lin.", "model.lin3.", *enc))]
+    feats = [x_[:, 3:] for x_ in st.xh]
+    hin_tail = tape.get(_capi.TAPE_HIN)[:, emb:Cc]
+    with torch.enable_grad():
+        hd = refs.stage_head(P, enc, feats, topo.node_ref, hin_tail)
+        s0_t, ewi_t, c0_t = refs.stage_init(P, hd, g, H)
+    note("fwd head: hin", rel(hd, tape.get(_capi.TAPE_HIN)[:, :Cc]))
+    c_s = torch.randn(N, H, generator=gen).to(dev)
+    c_e = torch.randn(A, W, generator=gen).to(dev)
+    c_e[:, :2 * H] = 0          # the scalarisation link has its own check above (2a): its sign-noisy items would mask everything else here
+    c_c = torch.randn(max(E - A, 0), W, generator=gen).to(dev)
+    gin = torch.autograd.grad([s0_t, ewi_t, c0_t], [P[n_] for n_ in inn], [c_s, c_e, c_c.sum(0)], allow_unused=True)
+    dew_i = torch.zeros(E + 1, WP, device=dev)
+    dew_i[:A, :W] = c_e
+    dew_i[A:E, :W] = c_c
+    tab, dd = grad_dests(inn)
+    xhp = (C.c_void_p * n_obj)(*[x_.data_ptr() for x_ in st.xh])
+    _capi.check(L.oard_train_init_backward(C.byref(cfg), topo.handle, packed_f.data_ptr(), packed_b.data_ptr(), tape.buf.data_ptr(), xhp,
+                                           pad(c_s).data_ptr(), dew_i.data_ptr(), params_tab, tab, sc_buf.data_ptr(), sc_buf.numel(), stream), "init")
+    note("bwd init: " + " ".join(n_.split(".", 1)[1] for n_ in inn), *[rel(dd[n_], zero(gin[i], P[n_])) for i, n_ in enumerate(inn)])
     # ---- 3. whole step ---------------------------------------------------------------------------------------------------
     training.DynamicsFunction.forward = orig
     loss.backward()

@@ -1,5 +1,5 @@
-"""The torch stage functions of oareactdiff_amd/training.py (what the training path differentiates by local autograd for the
-node-side stages) composed into a whole forward on the CPU, in float64, against the oracle: every restatement and the internal
+"""The torch stage functions of tests/_stage_refs.py (the references the hand-written HIP adjoints of the node-side stages are
+checked against on the GPU) composed into a whole forward on the CPU, in float64, against the oracle: every restatement and the internal
 (sample-major node, target-sorted inner edge) layout conventions are checked without a GPU.  The two edge stages, which are
 HIP kernels in the product, are stood in for by a few lines of torch here (on the GPU they are tested in
 tests/test_grad_stages.py against the same stage functions)."""
@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 import leftnet_oracle as oracle
 from _cases import Case, rel
-from oareactdiff_amd import training
+import _stage_refs as training
 
 
 def _internal_layout(c, st):
