@@ -324,6 +324,8 @@ int oard_wgrad(const float* dY_dev, int ldY, int ncY, int o_len, int o_pad, int 
 #define OARD_STAGE_MESSAGE 2     /* in: gs_a, gvec_a      out: gx, dxq, dvec_in   */
 #define OARD_STAGE_GCL_NODE 3    /* in: gx, dxq           out: dxh, dagg          */
 #define OARD_STAGE_NODE_PRE 4    /* in: dxh, dP, dQ       out: ds_in              */
+#define OARD_STAGE_GCL_EDGE 5    /* in: dagg              in/out: dew (out0)      out: dP, dQ   (+ every GCLMessage edge-MLP gradient) */
+#define OARD_STAGE_EQUI_EDGE 6   /* in: dcd [A+1][3HP]    in/out: dew (out0)      (+ dir_proj gradients)  */
 #define OARD_SCRATCH_XH 1
 #define OARD_SCRATCH_XQ 2
 #define OARD_SCRATCH_CR 3

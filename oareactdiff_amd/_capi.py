@@ -24,7 +24,7 @@ EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_by
            "oard_equi_backward_dx", "oard_scalarize_backward", "oard_equi_msg_backward", "oard_lin3u_forward", "oard_lin3u_backward", "oard_wgrad_scratch_bytes", "oard_wgrad",
            "oard_train_scratch_bytes", "oard_train_scratch_poison", "oard_train_scratch_entry", "oard_train_tail_backward",
            "oard_train_layer_backward", "oard_train_init_backward", "oard_train_stage_backward"]
-STAGE_RECOMPUTE, STAGE_UPDATE, STAGE_MESSAGE, STAGE_GCL_NODE, STAGE_NODE_PRE = range(5)
+STAGE_RECOMPUTE, STAGE_UPDATE, STAGE_MESSAGE, STAGE_GCL_NODE, STAGE_NODE_PRE, STAGE_GCL_EDGE, STAGE_EQUI_EDGE = range(7)
 SCRATCH_XH, SCRATCH_XQ, SCRATCH_CR, SCRATCH_DCD, SCRATCH_DCR = range(1, 6)
 
 # oard_topology_export tables / oard_tape_entry tensors (include/oard.h)

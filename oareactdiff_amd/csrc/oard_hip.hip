@@ -1414,6 +1414,14 @@ int oard_train_stage_backward(const oard_config* c, const oard_topology* topo, c
         case OARD_STAGE_NODE_PRE:  // in: dxh, dP, dQ  out: ds_in
             if (!in0 || !in1 || !in2 || !out0) return OARD_EINVAL;
             DISPATCH_DIMS(c, rc = tr_pre_bwd<D>(x, layer, in0, in1, in2, out0)); break;
+        case OARD_STAGE_GCL_EDGE: {  // in: dagg  in/out: out0 = dew  out: dP, dQ
+            if (!in0 || !out0 || !out1 || !out2) return OARD_EINVAL;
+            DISPATCH_DIMS(c, rc = tr_gcl_edge_bwd<D>(x, layer, in0, out0, out1, out2)); break; }
+        case OARD_STAGE_EQUI_EDGE: { // in: dcd [A+1][3HP] (pads and spare row zero)  in/out: out0 = dew
+            if (!in0 || !out0) return OARD_EINVAL;
+            const RDims r(c->hidden, c->num_radial);
+            HIP_TRY(hipMemcpyAsync(x.f(x.w.dcd), in0, (size_t)(tp.A + 1) * 3 * r.HP * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            DISPATCH_DIMS(c, rc = tr_equi_edge_bwd<D>(x, layer, out0)); break; }
         default: return OARD_EINVAL;
     }
     return rc;

@@ -57,9 +57,19 @@ static TrainWs make_train_ws(const oard_config* c, const TopoDev& td) {
     w.csum = take(4096 * F);
     w.cpart = take(std::max((size_t)cdiv(std::max<size_t>(E, 3 * N), CS_ROWS) * std::max<size_t>(d.WP, 1024),
                             (size_t)cdiv(N * HP, CS_ROWS) * 16) * F);
-    // the largest weight-gradient GEMM of the sweep (oard_wgrad_scratch_bytes is monotone in every argument)
-    w.wg_bytes = std::max(oard_wgrad_scratch_bytes(d.WP, d.WP, (int64_t)E), oard_wgrad_scratch_bytes(3 * d.HP, d.D1P, (int64_t)A));
-    w.wg_bytes = std::max(w.wg_bytes, oard_wgrad_scratch_bytes(48, 48, (int64_t)items));
+    // partials of the weight-gradient GEMMs: the largest requirement over every (dY width, X width, rows) shape of the sweep (the
+    // chunk count of oard_wgrad's plan is not monotone in the widths: narrow operands are cut into more row chunks)
+    {
+        const int HPi = d.HP, WPi = d.WP, D1 = d.D1P, RPi = d.RP, PPi = d.PP;
+        const int64_t Er = (int64_t)E, Ar = (int64_t)A, Nr = (int64_t)N, Ir = (int64_t)items;
+        const struct { int y, x; int64_t r; } shapes[] = {
+            {WPi, HPi, Er}, {HPi, HPi, Er}, {HPi, WPi, Er},                                             // GCLMessage edge MLP
+            {3 * HPi, D1, Ar}, {D1, WPi, Ar}, {3 * HPi, RPi, Ar}, {HPi, HPi, Ar}, {HPi, RPi, Ar},       // dir_proj, rbf_proj, radial_lin
+            {3 * HPi, HPi, Nr}, {HPi, HPi, Nr}, {2 * HPi, HPi, 3 * Nr}, {HPi, HPi, 3 * Nr}, {HPi, 16, Nr}, {16, HPi, Nr}, {HPi, PPi, Nr},
+            {48, 4, Ir}, {8, 48, Ir}, {32, 16, Nr}, {16, 32, Nr}};
+        w.wg_bytes = 0;
+        for (const auto& sh : shapes) w.wg_bytes = std::max(w.wg_bytes, oard_wgrad_scratch_bytes(sh.y, sh.x, sh.r));
+    }
     w.wg = take(w.wg_bytes);
     w.total = cur;
     return w;
