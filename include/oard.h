@@ -353,6 +353,28 @@ int oard_train_stage_backward(const oard_config* cfg, const oard_topology* topo,
                               float* out0, float* out1, float* out2, const float* const* params_dev, float* const* grads_dev,
                               void* scratch_dev, size_t scratch_bytes, oard_stream_t stream);
 
+/* ---- The training caller around the network call, fused (round 3) --------------------------------------------------------------
+ * oard_loss_prepare  EnVariationalDiffusion.forward up to the network call (en_diffusion.py:56-123, noised_representation :250-281,
+ *                    sample_combined_position_feature_noise :283-306): normalises the dataset-layout batch (pos float32 [n_k][3],
+ *                    one_hot int64 [n_k][nf_k-4], charge int64 [n_k][1]; reference rows), removes the per-(sample, object) CoM of the
+ *                    raw N(0,1) position noise, z_t = alpha_t x + sigma_t eps with gamma = gamma_table[t_int[b]].
+ * oard_loss_terms    the rest of it + DDPMModule.compute_loss (pl_trainer.py:208-282, l2 training form): per-sample nll [B], logged
+ *                    terms [2 n_obj][B] (normalised and un-normalised error per object) and d(mean_b nll)/d(network output).
+ * oard_adamw_step    torch.optim.AdamW(amsgrad) (pl_trainer.py:150) over one flat bucket, gradient-clipping factor folded in.
+ * norm_values / norm_biases [3], scales [n_obj]: host arrays.  t_int [B] float32 (device), gamma table [T+1] (device). */
+int oard_loss_prepare(const oard_config* cfg, const oard_topology* topo, const float* const* pos_dev, const int64_t* const* one_hot_dev,
+                      const int64_t* const* charge_dev, const float* const* noise_dev, const float* t_int_dev, const float* gamma_dev,
+                      int T, const float* norm_values, const float* norm_biases, int pos_only, int fixed_mask, float* const* z_dev,
+                      float* const* eps_dev, oard_stream_t stream);
+int oard_loss_terms(const oard_config* cfg, const oard_topology* topo, const float* const* eps_dev, const float* const* net_dev,
+                    const float* const* z_dev, const int64_t* const* one_hot_dev, const int64_t* const* charge_dev,
+                    const float* t_int_dev, const float* gamma_dev, int T, const float* norm_values, const float* norm_biases,
+                    const float* scales, int pos_only, int B, float* nll_dev, float* terms_dev, float* const* dnet_dev,
+                    oard_stream_t stream);
+int oard_adamw_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* max_exp_avg_sq_dev,
+                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, int amsgrad,
+                    float grad_scale, oard_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

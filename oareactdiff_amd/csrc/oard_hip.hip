@@ -1342,6 +1342,7 @@ int oard_wgrad(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, 
 
 }  // extern "C"
 #include "oard_train_stages.h"
+#include "oard_loss.h"
 extern "C" {
 
 // ---- the backward sweep through the C ABI (include/oard.h) ------------------------------------------------------------------------
@@ -1425,6 +1426,67 @@ int oard_train_stage_backward(const oard_config* c, const oard_topology* topo, c
         default: return OARD_EINVAL;
     }
     return rc;
+}
+
+// ---- the training caller, fused (oard_loss.h) ------------------------------------------------------------------------------------
+static LossCfg make_loss_cfg(const oard_config* c, const float* norm_values, const float* norm_biases, const float* scales, int pos_only,
+                             int fixed_mask, int T) {
+    LossCfg lc;
+    memset(&lc, 0, sizeof(lc));
+    for (int i = 0; i < 3; ++i) { lc.norm_value[i] = norm_values ? norm_values[i] : 1.0f; lc.norm_bias[i] = norm_biases ? norm_biases[i] : 0.0f; }
+    for (int k = 0; k < c->n_obj; ++k) lc.scale[k] = scales ? scales[k] : 1.0f;
+    lc.pos_only = pos_only; lc.fixed_mask = fixed_mask; lc.T = T;
+    return lc;
+}
+int oard_loss_prepare(const oard_config* c, const oard_topology* topo, const float* const* pos, const int64_t* const* one_hot,
+                      const int64_t* const* charge, const float* const* noise, const float* t_int, const float* gamma, int T,
+                      const float* norm_values, const float* norm_biases, int pos_only, int fixed_mask, float* const* z,
+                      float* const* eps, oard_stream_t stream) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1 || !pos || !one_hot || !charge || !noise || !t_int || !gamma || !z || !eps)
+        return OARD_EINVAL;
+    LossPtrs lp;
+    memset(&lp, 0, sizeof(lp));
+    for (int k = 0; k < c->n_obj; ++k) {
+        if (c->node_nf[k] < 5 || c->node_nf[k] - 4 > 16) return OARD_EINVAL;      // [pos 3 | one_hot >= 1 | charge 1]
+        lp.pos[k] = pos[k]; lp.one_hot[k] = (const long long*)one_hot[k]; lp.charge[k] = (const long long*)charge[k];
+        lp.noise[k] = noise[k]; lp.z[k] = z[k]; lp.eps[k] = eps[k]; lp.node_nf[k] = c->node_nf[k];
+    }
+    const TopoDev& tp = topo->parts[0].d;
+    LAUNCH(F_OTHER, k_loss_prep, cdiv(tp.N, 128), 128, (hipStream_t)stream, tp, lp,
+           make_loss_cfg(c, norm_values, norm_biases, nullptr, pos_only, fixed_mask, T), t_int, gamma);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+int oard_loss_terms(const oard_config* c, const oard_topology* topo, const float* const* eps, const float* const* net,
+                    const float* const* z, const int64_t* const* one_hot, const int64_t* const* charge, const float* t_int,
+                    const float* gamma, int T, const float* norm_values, const float* norm_biases, const float* scales, int pos_only,
+                    int B, float* nll, float* terms, float* const* dnet, oard_stream_t stream) {
+    if (!config_ok(c) || !topo || topo->n_parts != 1 || !eps || !net || !z || !one_hot || !charge || !t_int || !gamma || !nll || !terms ||
+        !dnet || B < 1)
+        return OARD_EINVAL;
+    LossPtrs lp;
+    memset(&lp, 0, sizeof(lp));
+    for (int k = 0; k < c->n_obj; ++k) {
+        if (c->node_nf[k] < 5 || c->node_nf[k] - 4 > 16) return OARD_EINVAL;
+        lp.eps[k] = (float*)eps[k]; lp.net[k] = net[k]; lp.z[k] = (float*)z[k]; lp.one_hot[k] = (const long long*)one_hot[k];
+        lp.charge[k] = (const long long*)charge[k]; lp.dnet[k] = dnet[k]; lp.node_nf[k] = c->node_nf[k];
+    }
+    const TopoDev& tp = topo->parts[0].d;
+    LAUNCH(F_OTHER, k_loss_terms, tp.B, 64, (hipStream_t)stream, tp, lp, make_loss_cfg(c, norm_values, norm_biases, scales, pos_only, 0, T),
+           t_int, gamma, B, nll, terms);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+int oard_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int64_t step, int amsgrad, float grad_scale,
+                    oard_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || (amsgrad && !max_exp_avg_sq) || n < 0 || step < 1) return OARD_EINVAL;
+    if (n == 0) return OARD_OK;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    LAUNCH(F_OTHER, k_adamw, cdiv(n, 256), 256, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, (long long)n, lr, beta1,
+           beta2, eps, weight_decay, bc1, bc2s, amsgrad, grad_scale);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
 }
 
 // scratch buffers a test may want to look at (xq, cr, d cd, d cr of the last recompute / message stage)

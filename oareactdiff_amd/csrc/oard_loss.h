@@ -1,0 +1,163 @@
+// oard_loss.h — the training caller around the denoising call, fused.
+//
+// What the reference does per training step in ~150 eager torch ops (+ their autograd backward):
+//   EnVariationalDiffusion.forward          oa_reactdiff/diffusion/en_diffusion.py:56-248 (helpers :250-449)
+//   DDPMModule.compute_loss / training_step oa_reactdiff/trainer/pl_trainer.py:208-282, 327-347
+//   AdamW(amsgrad=True) + clip_grad_norm_   pl_trainer.py:150, 391-418
+// Here: k_loss_prep (normalise the batch, CoM-free noise, z_t = alpha x + sigma eps), ONE network call, k_loss_terms (per-sample
+// L2 error, the t = 0 likelihood terms, nll, the logged means AND d(mean nll)/d(net output) - the loss is quadratic in the network
+// output, so its gradient is closed-form and no autograd graph is needed), k_adamw (one pass over the flat parameter bucket,
+// gradient clipping factor folded in).  oareactdiff_amd.loss.DiffusionLoss stays the general differentiable formulation (the
+// tests compare the two term by term).
+#pragma once
+#include "oard_kernels.h"
+
+struct LossPtrs {
+    const float* pos[OARD_MAX_OBJECTS];          // [n_k][3]            dataset layout (dataset/base_dataset.py:55-88), reference rows
+    const long long* one_hot[OARD_MAX_OBJECTS];  // [n_k][nf_k - 4]
+    const long long* charge[OARD_MAX_OBJECTS];   // [n_k][1]
+    const float* noise[OARD_MAX_OBJECTS];        // [n_k][nf_k]         raw N(0,1) draws
+    float* z[OARD_MAX_OBJECTS];                  // [n_k][nf_k]         noised, normalised representation (network input)
+    float* eps[OARD_MAX_OBJECTS];                // [n_k][nf_k]         the noise that was added (CoM-free positions)
+    const float* net[OARD_MAX_OBJECTS];          // [n_k][nf_k]         network output
+    float* dnet[OARD_MAX_OBJECTS];               // [n_k][nf_k]         d(mean_b nll)/d net
+    int node_nf[OARD_MAX_OBJECTS];
+};
+struct LossCfg {
+    float norm_value[3], norm_bias[3];           // _normalizer.py: (x - bias) / value for pos | one_hot | charge
+    float scale[OARD_MAX_OBJECTS];               // pl_trainer.py scales
+    int pos_only, fixed_mask;                    // fixed_mask bit k: object k gets zero noise (fixed_idx)
+    int T;
+};
+
+OARD_DEV float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+OARD_DEV float gauss_cdf(float x) { return 0.5f * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// one thread per node: z_t, eps                                    en_diffusion.py:250-306 (noised_representation, sample_*_noise)
+__global__ void k_loss_prep(TopoDev tp, LossPtrs lp, LossCfg lc, const float* __restrict__ t_int, const float* __restrict__ gamma) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= tp.N) return;
+    const int obj = tp.node_obj[n], row = tp.node_row[n], nf = lp.node_nf[obj];
+    const int q = tp.node_sample[n] * tp.n_obj + obj;
+    const int g0 = tp.grp_ptr[q], g1 = tp.grp_ptr[q + 1];
+    const float ti = t_int[tp.node_tidx[n]];
+    const float gm = gamma[(int)(ti + 0.5f)];                            // gamma_module(t) = gamma[round(t T)], t = t_int / T
+    const float alpha = sqrtf(sigmoid_f(-gm)), sigma = sqrtf(sigmoid_f(gm));
+    const float* R = lp.noise[obj];
+    const bool fixed = (lc.fixed_mask >> obj) & 1;
+    float m[3] = {0.f, 0.f, 0.f};
+    for (int k = g0; k < g1; ++k) {                                      // scatter_mean order = ascending row (_utils.py:22-31)
+        const float* r = R + (size_t)tp.node_row[k] * nf;
+        m[0] += r[0]; m[1] += r[1]; m[2] += r[2];
+    }
+    const float inv = 1.0f / (float)(g1 - g0);
+    float* Z = lp.z[obj] + (size_t)row * nf;
+    float* Eo = lp.eps[obj] + (size_t)row * nf;
+    const float* r = R + (size_t)row * nf;
+    for (int c = 0; c < nf; ++c) {
+        float x, e;
+        if (c < 3) {
+            x = (lp.pos[obj][(size_t)row * 3 + c] - lc.norm_bias[0]) / lc.norm_value[0];
+            e = r[c] - m[c] * inv;
+        } else if (c < nf - 1) {
+            x = ((float)lp.one_hot[obj][(size_t)row * (nf - 4) + (c - 3)] - lc.norm_bias[1]) / lc.norm_value[1];
+            e = lc.pos_only ? 0.f : r[c];
+        } else {
+            x = ((float)lp.charge[obj][row] - lc.norm_bias[2]) / lc.norm_value[2];
+            e = lc.pos_only ? 0.f : r[c];
+        }
+        if (fixed) e = 0.f;
+        Eo[c] = e;
+        Z[c] = alpha * x + sigma * e;
+    }
+}
+
+// one 64-thread block per sample: error terms, t = 0 likelihood terms, nll, logged terms, d(mean nll)/d(net)
+//   terms [2 n_obj][B]: rows 0..n_obj-1 = normalised, scaled error per object (before the division by scales + 1e-4 of the log),
+//                       rows n_obj.. = un-normalised error per object                                      pl_trainer.py:268-277
+__global__ __launch_bounds__(64) void k_loss_terms(TopoDev tp, LossPtrs lp, LossCfg lc, const float* __restrict__ t_int,
+                                                   const float* __restrict__ gamma, int B, float* __restrict__ nll,
+                                                   float* __restrict__ terms) {
+    const int sb = blockIdx.x, lane = threadIdx.x;
+    const int n_first = tp.sample_ptr[sb];
+    const int b = tp.node_tidx[n_first];                                  // row of t_int / nll this sample belongs to
+    const float ti = t_int[b];
+    const bool tz = ti == 0.f;
+    const float gm = gamma[(int)(ti + 0.5f)];
+    const float sigma0 = sqrtf(sigmoid_f(gm));
+    float total = 0.f;
+    for (int k = 0; k < tp.n_obj; ++k) {
+        const int q = sb * tp.n_obj + k, g0 = tp.grp_ptr[q], g1 = tp.grp_ptr[q + 1], nf = lp.node_nf[k], ncat = nf - 4;
+        const int ncol = lc.pos_only ? 3 : nf;                            // pos_only: the feature outputs are zeroed before the loss (:212-215)
+        float e_all = 0.f, e_pos = 0.f, l_cat = 0.f, l_chg = 0.f;
+        for (int i = g0 + lane; i < g1; i += 64) {
+            const size_t o = (size_t)tp.node_row[i] * nf;
+            const float* E = lp.eps[k] + o;
+            const float* Nn = lp.net[k] + o;
+            for (int c = 0; c < nf; ++c) {
+                const float d = E[c] - (c < ncol ? Nn[c] : 0.f);
+                e_all += d * d;
+                if (c < 3) e_pos += d * d;
+            }
+            if (tz) {                                                     // log p(h | z0), en_diffusion.py:389-449 (discretised Gaussians)
+                const float* Z = lp.z[k] + o;
+                const float s_cat = sigma0 * lc.norm_value[1], s_chg = sigma0 * lc.norm_value[2];
+                float lpv[16], mx = -3.0e38f;
+                for (int j = 0; j < ncat && j < 16; ++j) {
+                    const float cen = (Z[3 + j] * lc.norm_value[1] + lc.norm_bias[1]) - 1.0f;
+                    lpv[j] = logf(gauss_cdf((cen + 0.5f) / s_cat) - gauss_cdf((cen - 0.5f) / s_cat) + 1e-10f);
+                    mx = fmaxf(mx, lpv[j]);
+                }
+                float se = 0.f;
+                for (int j = 0; j < ncat && j < 16; ++j) se += expf(lpv[j] - mx);
+                const float lse = mx + logf(se);
+                for (int j = 0; j < ncat && j < 16; ++j)
+                    l_cat += (lpv[j] - lse) * (float)lp.one_hot[k][(size_t)tp.node_row[i] * ncat + j];
+                const float chg = (float)lp.charge[k][tp.node_row[i]];
+                const float est = truncf(Z[nf - 1] * lc.norm_value[2] + lc.norm_bias[2]);      // .long(): truncation, as the reference does
+                const float cc = chg - est;
+                l_chg += logf(gauss_cdf((cc + 0.5f) / s_chg) - gauss_cdf((cc - 0.5f) / s_chg) + 1e-10f);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            e_all += __shfl_xor(e_all, d, 64); e_pos += __shfl_xor(e_pos, d, 64);
+            l_cat += __shfl_xor(l_cat, d, 64); l_chg += __shfl_xor(l_chg, d, 64);
+        }
+        const float size = (float)(g1 - g0), width = lc.pos_only ? 3.0f : 3.0f + (float)nf;   // pl_trainer.py:236-244: (pos_dim + node_nf) * size
+        const float err_t = tz ? 0.f : e_all;
+        const float err_n = size > 0.f ? err_t / (width * size) * lc.scale[k] : 0.f;
+        const float l0x = (tz && size > 0.f) ? 0.5f * e_pos * lc.scale[k] / (3.0f * size) : 0.f;
+        total += err_n + l0x + (tz ? -(l_cat + l_chg) : 0.f);
+        if (lane == 0) { terms[(size_t)k * B + b] = err_n; terms[(size_t)(tp.n_obj + k) * B + b] = err_t; }
+        // d(mean_b nll)/d net: error_t path 2 (net - eps) scale / (width size), t = 0 path (net - eps) scale / (3 size) on the positions
+        const float cA = (!tz && size > 0.f) ? 2.0f * lc.scale[k] / (width * size) / (float)B : 0.f;
+        const float cP = (tz && size > 0.f) ? lc.scale[k] / (3.0f * size) / (float)B : 0.f;
+        for (int i = g0 + lane; i < g1; i += 64) {
+            const size_t o = (size_t)tp.node_row[i] * nf;
+            for (int c = 0; c < nf; ++c) {
+                const float d = c < ncol ? lp.net[k][o + c] - lp.eps[k][o + c] : 0.f;
+                lp.dnet[k][o + c] = c < ncol ? d * (cA + (c < 3 ? cP : 0.f)) : 0.f;
+            }
+        }
+    }
+    if (lane == 0) nll[b] = total;
+}
+
+// AdamW (torch.optim.AdamW single-tensor semantics, amsgrad optional) over a flat bucket; `gscale` multiplies the gradient first
+// (clip_grad_norm_'s factor; 1 = no clipping).  bc1 = 1 - beta1^step, bc2s = sqrt(1 - beta2^step) from the host.
+__global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                        float* __restrict__ vmax, long long n, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                        float bc2s, int amsgrad, float gscale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gr = g[i] * gscale;
+    float x = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] + (gr - m[i]) * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * beta2 + gr * gr * (1.0f - beta2);
+    m[i] = mi; v[i] = vi;
+    float den;
+    if (amsgrad) { const float vm = fmaxf(vmax[i], vi); vmax[i] = vm; den = sqrtf(vm) / bc2s + eps; }
+    else den = sqrtf(vi) / bc2s + eps;
+    p[i] = x - (lr / bc1) * (mi / den);
+}

@@ -353,17 +353,12 @@ class EGNNDynamics(nn.Module):
             raise _capi.OardError("t has fewer rows than samples")
         return tt.reshape(-1).contiguous(), 0
 
-    def _forward_train(self, cfg, packed: Tensor, xh: List[Tensor], edge_index: Tensor, t: Tensor, conditions: Tensor,
-                       n_frag_switch: Tensor, combined_mask: Tensor, stream: int):
-        """Forward under autograd: training-mode HIP forward (tape) wrapped in `training.DynamicsFunction`."""
+    def _get_train_topology(self, cfg, edge_index: Tensor, n_frag_switch: Tensor, combined_mask: Tensor, stream: int):
+        """One (single sub-batch) topology per layout, edge_index verified on it when it is built.  Cached like the inference
+        topologies, by the identity of the three tensors: a loader that reuses its batch tensors (bench.py, fixed-size batches
+        through DiffusionLoss's layout cache) pays the host copy of the masks, the table uploads and the one `ok.item()` of the
+        edge_index check once, not every step."""
         from . import training
-        L = _capi.lib()
-        dev = xh[0].device
-        n_obj = len(self.node_nfs)
-        # one (single sub-batch) topology per layout, edge_index verified on it when it is built.  Cached like the inference
-        # topologies, by the identity of the three tensors: a loader that reuses its batch tensors (bench.py, fixed-size
-        # batches through DiffusionLoss's layout cache) pays the host copy of the masks, the table uploads and the one
-        # `ok.item()` of the edge_index check once, not every step
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
                n_frag_switch.data_ptr(), n_frag_switch._version, combined_mask.data_ptr(), combined_mask._version,
                combined_mask.numel())
@@ -376,43 +371,66 @@ class EGNNDynamics(nn.Module):
                 self._train_topo_cache.popitem(last=False)
         else:
             self._train_topo_cache.move_to_end(key)
-        check = topo
+        return topo
+
+    def _train_inputs(self, topo, xh: List[Tensor], t: Tensor, conditions: Tensor, dev):
+        n_obj = len(self.node_nfs)
         xs = []
         for k in range(n_obj):
             x = xh[k].detach()
             if x.dtype != torch.float32 or not x.is_contiguous():
                 x = x.contiguous().float()
-            if x.shape != (check.obj_counts[k], self.node_nfs[k]):
+            if x.shape != (topo.obj_counts[k], self.node_nfs[k]):
                 raise _capi.OardError(f"xh[{k}] has shape {tuple(x.shape)}")
             xs.append(x)
-        tt, t_scalar = self._time_argument(t, dev, check.max_sample_id)
+        tt, t_scalar = self._time_argument(t, dev, topo.max_sample_id)
         cond = None
         if self.condition_nf > 0:
             cond = conditions.detach().to(device=dev, dtype=torch.float32).contiguous()
-            if cond.shape[0] <= check.max_sample_id or cond.shape[1] != self.condition_nf:
+            if cond.shape[0] <= topo.max_sample_id or cond.shape[1] != self.condition_nf:
                 raise _capi.OardError("conditions has the wrong shape")
+        return xs, tt, t_scalar, cond
+
+    def _run_forward_train(self, cfg, topo, packed: Tensor, xs: List[Tensor], tt: Tensor, t_scalar: int, cond: Optional[Tensor],
+                           stream: int):
+        """oard_forward_train on prepared inputs -> (outs, TrainState); no autograd involved (DDPMTrainer's fused step calls this
+        directly and feeds the closed-form loss gradient to training.backward_sweep)."""
+        from . import training
+        L = _capi.lib()
+        dev = xs[0].device
+        n_obj = len(self.node_nfs)
+        outs = [torch.empty_like(x) for x in xs]
+        need = L.oard_workspace_bytes(C.byref(cfg), topo.handle)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        # one tape per call (it lives until that call's backward has run; the caching allocator recycles it)
+        tape = torch.empty(L.oard_tape_bytes(C.byref(cfg), topo.handle), dtype=torch.uint8, device=dev)
+        status = torch.zeros(2, dtype=torch.int32, device=dev)
+        xp = (C.c_void_p * n_obj)(*[x.data_ptr() for x in xs])
+        op = (C.c_void_p * n_obj)(*[o.data_ptr() for o in outs])
+        rc = L.oard_forward_train(C.byref(cfg), topo.handle, packed.data_ptr(), xp, tt.data_ptr(), t_scalar,
+                                  cond.data_ptr() if cond is not None else None, op, self._ws.data_ptr(), self._ws.numel(),
+                                  tape.data_ptr(), tape.numel(), status.data_ptr(), stream)
+        _capi.check(rc, "oard_forward_train")
+        self.last_status = status
+        if self.nan_check != "sync":
+            if self.nan_seen is None or self.nan_seen.device != dev:
+                self.nan_seen = torch.zeros(2, dtype=torch.int32, device=dev)
+            self.nan_seen.bitwise_or_(status)         # device-side, no sync (DDPMTrainer reads it with the gradient norm)
+        state = training.TrainState(cfg, topo, training.Tape(cfg, topo, tape), xs, tt, bool(t_scalar), cond)
+        return outs, state
+
+    def _forward_train(self, cfg, packed: Tensor, xh: List[Tensor], edge_index: Tensor, t: Tensor, conditions: Tensor,
+                       n_frag_switch: Tensor, combined_mask: Tensor, stream: int):
+        """Forward under autograd: training-mode HIP forward (tape) wrapped in `training.DynamicsFunction`."""
+        from . import training
+        dev = xh[0].device
+        n_obj = len(self.node_nfs)
+        topo = self._get_train_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+        xs, tt, t_scalar, cond = self._train_inputs(topo, xh, t, conditions, dev)
 
         def run_forward():
-            outs = [torch.empty_like(x) for x in xs]
-            need = L.oard_workspace_bytes(C.byref(cfg), topo.handle)
-            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            # one tape per call (it lives until that call's backward has run; the caching allocator recycles it)
-            tape = torch.empty(L.oard_tape_bytes(C.byref(cfg), topo.handle), dtype=torch.uint8, device=dev)
-            status = torch.zeros(2, dtype=torch.int32, device=dev)
-            xp = (C.c_void_p * n_obj)(*[x.data_ptr() for x in xs])
-            op = (C.c_void_p * n_obj)(*[o.data_ptr() for o in outs])
-            rc = L.oard_forward_train(C.byref(cfg), topo.handle, packed.data_ptr(), xp, tt.data_ptr(), t_scalar,
-                                      cond.data_ptr() if cond is not None else None, op, self._ws.data_ptr(), self._ws.numel(),
-                                      tape.data_ptr(), tape.numel(), status.data_ptr(), stream)
-            _capi.check(rc, "oard_forward_train")
-            self.last_status = status
-            if self.nan_check != "sync":
-                if self.nan_seen is None or self.nan_seen.device != dev:
-                    self.nan_seen = torch.zeros(2, dtype=torch.int32, device=dev)
-                self.nan_seen.bitwise_or_(status)         # device-side, no sync (DDPMTrainer reads it with the gradient norm)
-            state = training.TrainState(cfg, topo, training.Tape(cfg, topo, tape), xs, tt, bool(t_scalar), cond)
-            return outs, state
+            return self._run_forward_train(cfg, topo, packed, xs, tt, t_scalar, cond, stream)
 
         names = self._param_names()
         P = self._param_dict()

@@ -62,7 +62,7 @@ class DDPMTrainer:
                  norm_biases: Sequence[float] = (0.0, 0.0, 0.0), loss_type: str = "l2", pos_only: bool = False,
                  scales: Sequence[float] = (1.0, 1.0, 1.0), fixed_idx: Optional[List[int]] = None,
                  optimizer_config: Optional[Dict] = None, clip_grad: bool = True,
-                 process_group: Optional["dist.ProcessGroup"] = None):
+                 process_group: Optional["dist.ProcessGroup"] = None, fused: Optional[bool] = None):
         self.dynamics = dynamics
         self.loss = DiffusionLoss(dynamics, noise_schedule, timesteps, precision, norm_values=norm_values,
                                   norm_biases=norm_biases, pos_only=pos_only, fixed_idx=fixed_idx, loss_type=loss_type,
@@ -88,9 +88,27 @@ class DDPMTrainer:
         for p in self.params:                          # p.grad = view into the bucket: backward accumulates in place
             p.grad = self.flat_grad[off: off + p.numel()].view_as(p)
             off += p.numel()
-        if hasattr(dynamics, "_get_packed_bwd"):        # the HIP module: its backward accumulates straight into these .grad views
+        self.opt_config = dict(DEFAULT_OPTIMIZER, **(optimizer_config or {}))
+        self.fused = (hasattr(dynamics, "_get_packed_bwd") and self.params[0].device.type == "cuda" and loss_type == "l2"
+                      and self.params[0].dtype == torch.float32) if fused is None else bool(fused)
+        if self.fused:
+            # the HIP module: (1) its backward accumulates straight into the .grad views of the bucket; (2) the parameters
+            # themselves become views of ONE flat buffer, so that AdamW is a single kernel over it (oard_adamw_step) and
+            # state_dict() / load_state_dict() keep working on the same storage
             dynamics.grad_inplace = True
-        self.optimizer = torch.optim.AdamW(self.params, **dict(DEFAULT_OPTIMIZER, **(optimizer_config or {})))
+            self.flat_param = torch.empty(n, dtype=torch.float32, device=self.flat_grad.device)
+            off = 0
+            with torch.no_grad():
+                for p in self.params:
+                    self.flat_param[off: off + p.numel()].copy_(p.reshape(-1))
+                    p.data = self.flat_param[off: off + p.numel()].view_as(p)
+                    off += p.numel()
+            self.exp_avg = torch.zeros_like(self.flat_param)
+            self.exp_avg_sq = torch.zeros_like(self.flat_param)
+            self.max_exp_avg_sq = torch.zeros_like(self.flat_param)
+            self.opt_step = 0
+        self.optimizer = torch.optim.AdamW(self.params, **self.opt_config)      # the generic path's optimiser (CPU / non-HIP module)
+        self._gamma_dev = None
         self.clip_grad = clip_grad
         if clip_grad:                                  # pl_trainer.py:143-146
             self.gradnorm_queue = Queue()
@@ -153,8 +171,125 @@ class DDPMTrainer:
             self.gradnorm_queue.add(grad_norm)
         return grad_norm, max_grad_norm
 
+    # ---- fused step (HIP module): no autograd graph, ~20 launches around the network call ----------------------------------------
+    def _fused_forward_backward(self, batch, t_int: Optional[Tensor] = None, draw=None):
+        """loss terms + gradients into the bucket: oard_loss_prepare -> oard_forward_train -> oard_loss_terms -> the backward sweep
+        (training.backward_sweep) fed with the closed-form d(mean nll)/d(net).  Returns (nll [B], terms [2K, B]) on the device.
+        Same noise stream as DiffusionLoss (per object: randn(n, 3) then randn(n, nf - 3))."""
+        import ctypes as C
+        from . import _capi, training
+        reps, cond = batch
+        dyn, ls = self.dynamics, self.loss
+        dev = self.flat_grad.device
+        K = len(reps)
+        L = _capi.lib()
+        masks, sizes = [r["mask"] for r in reps], [r["size"] for r in reps]
+        combined_mask, edge_index, n_frag_switch = ls._layout(masks, sizes)
+        B = int(sizes[0].numel())
+        with torch.cuda.device(dev), torch.no_grad():
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            cfg = dyn._config()
+            _capi.check(L.oard_supported(C.byref(cfg)), "oard_supported (hidden_channels/num_radial not built)")
+            packed = dyn._get_packed(cfg, stream)
+            topo = dyn._get_train_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+            if draw is None:
+                def draw(shape):
+                    return torch.randn(shape, device=dev)
+            if t_int is None:
+                t_int = torch.randint(0, ls.T + 1, size=(B, 1), device=dev).float()
+            t_int = t_int.detach().to(device=dev, dtype=torch.float32).reshape(B).contiguous()
+            nfs = list(dyn.node_nfs)
+            noise = [torch.cat([draw((int(m.numel()), 3)).float(), draw((int(m.numel()), nfs[k] - 3)).float()], dim=1) for k, m in enumerate(masks)]
+            gamma = self._gamma_dev
+            if gamma is None or gamma.device != dev:
+                gamma = self._gamma_dev = ls.schedule.gamma.to(device=dev, dtype=torch.float32).contiguous()
+            pos = [r["pos"].detach().to(torch.float32).contiguous() for r in reps]
+            one_hot = [r["one_hot"].detach().to(torch.int64).contiguous() for r in reps]
+            charge = [r["charge"].detach().to(torch.int64).contiguous() for r in reps]
+            z = [torch.empty(int(m.numel()), nfs[k], device=dev) for k, m in enumerate(masks)]
+            eps = [torch.empty_like(x) for x in z]
+            arr = lambda ts: (C.c_void_p * K)(*[t.data_ptr() for t in ts])      # noqa: E731
+            f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])              # noqa: E731
+            nv, nb = f3(ls.norm_values), f3(ls.norm_biases)
+            sc = (C.c_float * K)(*[float(x) for x in ls.scales[:K]])
+            fixed_mask = sum(1 << int(k) for k in ls.fixed_idx)
+            _capi.check(L.oard_loss_prepare(C.byref(cfg), topo.handle, arr(pos), arr(one_hot), arr(charge), arr(noise), t_int.data_ptr(),
+                                            gamma.data_ptr(), ls.T, nv, nb, 1 if ls.pos_only else 0, fixed_mask, arr(z), arr(eps), stream),
+                        "oard_loss_prepare")
+            t = (t_int / ls.T).view(B, 1)
+            xs, tt, t_scalar, cnd = dyn._train_inputs(topo, z, t, cond, dev)
+            net, state = dyn._run_forward_train(cfg, topo, packed, xs, tt, t_scalar, cnd, stream)
+            nll = torch.empty(B, device=dev)
+            terms = torch.empty(2 * K, B, device=dev)
+            dnet = [torch.empty_like(o) for o in net]
+            _capi.check(L.oard_loss_terms(C.byref(cfg), topo.handle, arr(eps), arr(net), arr(z), arr(one_hot), arr(charge), t_int.data_ptr(),
+                                          gamma.data_ptr(), ls.T, nv, nb, sc, 1 if ls.pos_only else 0, B, nll.data_ptr(), terms.data_ptr(),
+                                          arr(dnet), stream), "oard_loss_terms")
+            dests = {id(p): p.grad for p in self.params}
+            training.backward_sweep(dyn, state, dnet, stream, dests)
+        return nll, terms
+
+    def _fused_step(self, batch, **kw) -> Dict[str, float]:
+        import ctypes as C  # noqa: F401
+        from . import _capi
+        dyn = self.dynamics
+        prev = dyn.nan_check
+        dyn.nan_check = "async"
+        dyn.reset_nan_seen()
+        self._bucket.zero_()
+        try:
+            nll, terms = self._fused_forward_backward(batch, **kw)
+        finally:
+            dyn.nan_check = prev
+        K = terms.shape[0] // 2
+        means = torch.cat([nll.mean(0, keepdim=True), terms.mean(dim=1)])          # loss, err_n[k], err_t[k]
+        bad = (~torch.isfinite(means[0])).to(torch.float32)
+        if dyn.nan_seen is not None:
+            bad = bad + (dyn.nan_seen[0] != 0).to(torch.float32)
+        self._bucket[-1] = bad + (~torch.isfinite(self.flat_grad.sum())).to(torch.float32)
+        self.all_reduce_gradients()
+        stats = torch.cat([torch.linalg.vector_norm(self.flat_grad, 2.0).reshape(1), self._bucket[-1:], means]).tolist()   # the one host sync
+        grad_norm, flag = stats[0], stats[1]
+        info: Dict[str, float] = {}
+        for k in range(K):
+            info[f"error_t_{k}"] = stats[3 + k] / (self.loss.scales[k] + 1e-4)
+            info[f"unorm_error_t_{k}"] = stats[3 + K + k]
+        skipped = flag != 0 or not math.isfinite(grad_norm)
+        gscale = 1.0
+        if skipped:
+            self.skipped_steps += 1
+            print(f"Warning: non-finite loss / gradient / network output on some rank: step skipped on all ranks "
+                  f"({self.skipped_steps} so far)")
+            if self.clip_grad:
+                info["grad_norm"], info["max_grad_norm"] = grad_norm, float("nan")
+        else:
+            if self.clip_grad:                        # pl_trainer.py:391-418, with the factor folded into the optimiser kernel
+                max_norm = 1.5 * self.gradnorm_queue.mean() + 3 * self.gradnorm_queue.std()
+                if grad_norm > max_norm:
+                    gscale = max_norm / (grad_norm + 1e-6)
+                    self.gradnorm_queue.add(float(max_norm))
+                    print(f"Clipped gradient with value {grad_norm:.1f} while allowed {max_norm:.1f}")
+                else:
+                    self.gradnorm_queue.add(grad_norm)
+                info["grad_norm"], info["max_grad_norm"] = grad_norm, max_norm
+            o = self.opt_config
+            self.opt_step += 1
+            stream = torch.cuda.current_stream(self.flat_grad.device).cuda_stream
+            with torch.cuda.device(self.flat_grad.device):
+                _capi.check(_capi.lib().oard_adamw_step(self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                        self.exp_avg_sq.data_ptr(), self.max_exp_avg_sq.data_ptr(), self.flat_param.numel(),
+                                                        float(o["lr"]), float(o["betas"][0]), float(o["betas"][1]), float(o.get("eps", 1e-8)),
+                                                        float(o.get("weight_decay", 0.0)), self.opt_step, 1 if o.get("amsgrad", False) else 0,
+                                                        float(gscale), stream), "oard_adamw_step")
+            dyn._packed_key = dyn._packed_bwd_key = None      # the weights changed behind torch's version counters
+        info["loss"] = stats[2]
+        info["skipped"] = int(skipped)
+        return info
+
     def training_step(self, batch, **kw) -> Dict[str, float]:
         """`kw` (t_int=, draw=) injects the step's randomness for tests; by default it is drawn like the reference does.
+        With the HIP module on a ROCm device and the l2 loss this is the fused step (`_fused_step`: no autograd graph, the loss
+        terms, their gradient and AdamW as HIP kernels); otherwise the generic autograd formulation below.
 
         Non-finite values (the reference replaces a NaN network output by randn and trains on, egnn_dynamics.py:138-143 - every
         DDP rank in lock-step): here the network's device-side NaN flag and the finiteness of the local loss / gradient travel
@@ -162,6 +297,9 @@ class DDPMTrainer:
         optimiser step (weights, AdamW state and the clipping history untouched), counts it in `skipped_steps` and reports
         `info["skipped"] = 1`.  No rank leaves the step before the collective, and the only host sync is the one read of
         [gradient norm, flag, loss] after it."""
+        if self.fused and not kw.get("generic", False):
+            return self._fused_step(batch, **{k: v for k, v in kw.items() if k != "generic"})
+        kw.pop("generic", None)
         dyn = self.dynamics
         prev = getattr(dyn, "nan_check", None)
         if prev is not None:

@@ -1,0 +1,93 @@
+"""The fused training step of DDPMTrainer (oard_loss_prepare / oard_loss_terms / backward sweep / oard_adamw_step: no autograd
+graph) against the generic formulation (DiffusionLoss under torch autograd + torch.optim.AdamW) on recorded training steps of the
+reference (tests/golden/g9_grad_*.npz): same per-sample nll, same logged terms, same gradient bucket; the AdamW kernel against
+torch.optim.AdamW(amsgrad) on random gradients, with and without the clipping factor."""
+import ctypes as C
+
+import pytest
+import torch
+
+from _grad_cases import CNF, NODE_NFS, GradCase
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(c, dev, fused, pos_only):
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.trainer import DDPMTrainer
+    dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=NODE_NFS, edge_nf=0, condition_nf=CNF, device=dev)
+    dyn.load_state_dict(c.state_dict(), strict=True)
+    return DDPMTrainer(dyn, timesteps=c.meta["T"], norm_values=c.meta["norm_values"], scales=(1.0, 2.0, 1.0), pos_only=pos_only,
+                       fused=fused)
+
+
+@pytest.mark.parametrize("name,pos_only", [("g9_grad_prod_l2", False), ("g9_grad_h32", True), ("g9_grad_prod_n23", True)])
+def test_fused_loss_and_gradients_equal_the_autograd_formulation(name, pos_only):
+    c = GradCase(name)                      # g9_grad_prod_l2 holds a t_int = 0 sample: the discretised-likelihood terms are live
+    dev = torch.device("cuda:0")
+    B = len(c.meta["sizes"])
+    t_int = torch.tensor(c.meta["t_int"], dtype=torch.float32, device=dev).view(-1, 1)
+    cond = torch.zeros(B, 1, device=dev)
+
+    def draws():
+        it = iter(range(c.meta["n_randn"]))
+        return lambda shape: torch.from_numpy(c.z[f"randn{next(it)}"]).to(dev)
+    # generic: DiffusionLoss + autograd into the bucket
+    tg = _trainer(c, dev, False, pos_only)
+    tg._bucket.zero_()
+    nll_g, info_g = tg.compute_loss((c.reps(torch.float32, dev), cond), training=True, t_int=t_int, draw=draws())
+    nll_g.mean(0).backward()
+    # fused
+    tf = _trainer(c, dev, True, pos_only)
+    tf._bucket.zero_()
+    nll_f, terms = tf._fused_forward_backward((c.reps(torch.float32, dev), cond), t_int=t_int, draw=draws())
+    e_nll = float(((nll_f - nll_g.detach()).abs() / nll_g.detach().abs().clamp(min=1e-6)).max())
+    gd = float((tf.flat_grad - tg.flat_grad).norm() / tg.flat_grad.norm())
+    gmax = float((tf.flat_grad - tg.flat_grad).abs().max() / tg.flat_grad.abs().max())
+    print(f"{name} pos_only={pos_only}: nll rel {e_nll:.2e}; gradient bucket |d|_2/|g|_2 {gd:.2e}, max|d|/max|g| {gmax:.2e}")
+    assert e_nll <= 2e-6 and gd <= 2e-6 and gmax <= 2e-6
+    K = 3
+    for k in range(K):
+        assert abs(float(terms[k].mean()) / (tf.loss.scales[k] + 1e-4) - info_g[f"error_t_{k}"]) <= 2e-6 * max(1.0, abs(info_g[f"error_t_{k}"]))
+        assert abs(float(terms[K + k].mean()) - info_g[f"unorm_error_t_{k}"]) <= 2e-6 * max(1.0, abs(info_g[f"unorm_error_t_{k}"]))
+
+
+def test_fused_step_runs_and_moves_the_weights():
+    c = GradCase("g9_grad_h32")
+    dev = torch.device("cuda:0")
+    tr = _trainer(c, dev, True, True)
+    w0 = tr.flat_param.clone()
+    B = len(c.meta["sizes"])
+    batch = (c.reps(torch.float32, dev), torch.zeros(B, 1, device=dev))
+    torch.manual_seed(3)
+    i1 = tr.training_step(batch)
+    i2 = tr.training_step(batch)
+    assert i1["skipped"] == 0 and i2["skipped"] == 0 and i1["grad_norm"] > 0
+    assert all(k in i1 for k in ("loss", "error_t_0", "unorm_error_t_2", "max_grad_norm"))
+    d = (tr.flat_param - w0).abs()
+    assert float(d.max()) > 0 and float(d.max()) <= 2.1 * 2.5e-4        # two AdamW steps of lr each, at most
+    # the module's parameters ARE the bucket (state_dict sees the update), and the next forward repacks them
+    sd = tr.dynamics.state_dict()
+    assert any(not torch.equal(sd[k].cpu(), v) for k, v in c.state_dict().items() if v.is_floating_point() and "radial_emb" not in k)
+    assert len(tr.gradnorm_queue) == 3
+
+
+@pytest.mark.parametrize("amsgrad,wd,gscale", [(True, 0.0, 1.0), (True, 0.01, 0.37), (False, 0.0, 1.0)])
+def test_adamw_kernel_matches_torch(amsgrad, wd, gscale):
+    from oareactdiff_amd import _capi
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    n = 100003
+    p0 = torch.randn(n, generator=g).to(dev)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=2.5e-4, betas=(0.9, 0.999), weight_decay=wd, amsgrad=amsgrad, foreach=False)
+    p, m, v, vm = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for step in range(1, 6):
+        gr = (torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-3, 2, (1,), generator=g)))).to(dev)
+        ref.grad = gr * gscale
+        opt.step()
+        _capi.check(_capi.lib().oard_adamw_step(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), vm.data_ptr(), n, 2.5e-4, 0.9, 0.999,
+                                                1e-8, wd, step, 1 if amsgrad else 0, gscale, stream), "adamw")
+        e = float((p - ref.detach()).abs().max())
+        assert e <= 2e-7, (step, e)           # a few ulp of lr-sized updates on O(1) weights
