@@ -90,4 +90,4 @@ def test_adamw_kernel_matches_torch(amsgrad, wd, gscale):
         _capi.check(_capi.lib().oard_adamw_step(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), vm.data_ptr(), n, 2.5e-4, 0.9, 0.999,
                                                 1e-8, wd, step, 1 if amsgrad else 0, gscale, stream), "adamw")
         e = float((p - ref.detach()).abs().max())
-        assert e <= 2e-7, (step, e)           # a few ulp of lr-sized updates on O(1) weights
+        assert e <= 1e-6, (step, e)           # an ulp or two of O(1..5) weights
