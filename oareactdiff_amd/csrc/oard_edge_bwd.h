@@ -463,6 +463,145 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ P, i
     }
 }
 
+// =====================================================================================================
+// k_wgrad_lds (round 3): the same contraction with a row panel SHARED through LDS.  k_wgrad's per-wave tile (64 x 16 NT outputs)
+// has an arithmetic intensity of ~20 FLOP per operand byte, i.e. it sits on the HBM ridge and depends on L2 hits for the operand
+// re-reads of the other tasks (measured round 2: FETCH x 2 = 68.6 GB per training step for 23 GB of unique operands, 55 % MFMA-busy).
+// Here a workgroup of 8 waves owns PBW P blocks x QGW Q groups (PBW QGW = 8 tasks, 256 x 16 NT QGW outputs) of one row chunk and
+// stages GROUPS of 32 rows of exactly those columns in LDS, double-buffered: every operand element is fetched once per workgroup
+// (~60 FLOP per byte), as coalesced 1-KiB row segments, SiLU-on-load is applied once per element instead of once per task, and the
+// next group's loads are in flight during the 8 steps (8 x 4 NT MFMAs per wave) of the current one.  One barrier per group.
+//   P panel [32][256] floats (a wave's A operand = one conflict-free ds_read_b128);  Q panel [32][QLD = 16 NT QGW + 16] floats: the
+//   +16 shifts consecutive rows by 16 banks, so the four rows a ds_read_b32 of the B operand touches hit 64 distinct banks.
+// Same partial / psum / qsum layout as k_wgrad (the reduce passes are shared); rows beyond the chunk count as zero.
+// =====================================================================================================
+#define WGL_ROWS 32
+template <bool QSILU, int NT, int PBW, int QGW>
+__global__ __launch_bounds__(512, 1) void k_wgrad_lds(const float* __restrict__ P, int ldP, int ncP, const float* __restrict__ Q, int ldQ,
+                                                       int ncQ, long long r0, long long r1, long long rows_per_chunk, int nPB, int nQG,
+                                                       float* __restrict__ partial, float* __restrict__ psum, float* __restrict__ qsum) {
+    static_assert(PBW * QGW == 8, "one task per wave");
+    constexpr int PW = 64 * PBW, QW = 16 * NT * QGW, QLD = QW + 16;
+    constexpr int PF4 = WGL_ROWS * PW / 4 / 512, QF4 = (WGL_ROWS * QW / 4 + 511) / 512;      // float4 loads per thread and group
+    extern __shared__ __attribute__((aligned(16))) float wgl_sm[];
+    float* sP = wgl_sm;                                  // [2][WGL_ROWS][PW]
+    float* sQ = wgl_sm + 2 * WGL_ROWS * PW;              // [2][WGL_ROWS][QLD]
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, i = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nPT = (nPB + PBW - 1) / PBW, nQT_ = (nQG + QGW - 1) / QGW;
+    const int chunk = blockIdx.x / (nPT * nQT_), tile = blockIdx.x % (nPT * nQT_);
+    const int pt = tile / nQT_, qt = tile % nQT_;
+    const int pb = pt * PBW + wave / QGW, qg = qt * QGW + wave % QGW;
+    const bool active = pb < nPB && qg < nQG;
+    const long long rb = r0 + (long long)chunk * rows_per_chunk;
+    const long long re = rb + rows_per_chunk < r1 ? rb + rows_per_chunk : r1;
+    if (rb >= r1) return;                                 // whole workgroup (uniform)
+    const long long nrows = re - rb;
+    const int ngroups = (int)((nrows + WGL_ROWS - 1) / WGL_ROWS);
+    const int p_col0 = 64 * PBW * pt, q_col0 = 16 * NT * QGW * qt;
+
+    f4 stP[PF4], stQ[QF4];
+    auto fetch = [&](int grp) {                           // global -> registers (clamped addresses, invalid rows / columns become 0)
+        const long long gr0 = rb + (long long)grp * WGL_ROWS;
+#pragma unroll
+        for (int k = 0; k < PF4; ++k) {
+            const int idx = tid + 512 * k, row = idx / (PW / 4), c = p_col0 + 4 * (idx % (PW / 4));
+            const long long r = gr0 + row;
+            const bool ok = r < re && c < ncP;
+            const f4 v = *reinterpret_cast<const f4*>(P + (size_t)(r < re ? r : re - 1) * ldP + (c < ncP ? c : ncP - 4));
+            stP[k] = ok ? v : f4zero();
+        }
+#pragma unroll
+        for (int k = 0; k < QF4; ++k) {
+            const int idx = tid + 512 * k, row = idx / (QW / 4), c = q_col0 + 4 * (idx % (QW / 4));
+            const long long r = gr0 + row;
+            const bool ok = row < WGL_ROWS && r < re && c < ncQ;
+            f4 v = *reinterpret_cast<const f4*>(Q + (size_t)((row < WGL_ROWS && r < re) ? r : re - 1) * ldQ + (c < ncQ ? c : ncQ - 4));
+            if (QSILU) v = silu4(v);
+            stQ[k] = ok ? v : f4zero();
+        }
+    };
+    auto stash = [&](int buf) {                           // registers -> LDS
+#pragma unroll
+        for (int k = 0; k < PF4; ++k) {
+            const int idx = tid + 512 * k;
+            *reinterpret_cast<f4*>(sP + (size_t)buf * WGL_ROWS * PW + 4 * idx) = stP[k];
+        }
+#pragma unroll
+        for (int k = 0; k < QF4; ++k) {
+            const int idx = tid + 512 * k, row = idx / (QW / 4), c4 = idx % (QW / 4);
+            if (row < WGL_ROWS) *reinterpret_cast<f4*>(sQ + ((size_t)buf * WGL_ROWS + row) * QLD + 4 * c4) = stQ[k];
+        }
+    };
+
+    f4 acc[4][NT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[c][u] = f4zero();
+    f4 ps = f4zero();
+    float qs[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) qs[u] = 0.f;
+    const bool sums = active && ((psum != nullptr && qg == 0) || (qsum != nullptr && pb == 0));
+    const int pl = wave / QGW, ql = wave % QGW;           // this wave's block / group inside the panel
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int grp = 0; grp < ngroups; ++grp) {
+        const int buf = grp & 1;
+        if (grp + 1 < ngroups) fetch(grp + 1);
+        if (active) {
+            const float* bp = sP + (size_t)buf * WGL_ROWS * PW + 64 * pl + 4 * i;
+            const float* bq = sQ + (size_t)buf * WGL_ROWS * QLD + 16 * NT * ql + i;
+            bp += (size_t)g * PW; bq += (size_t)g * QLD;
+#pragma unroll 2
+            for (int stp = 0; stp < WGL_ROWS / 4; ++stp, bp += 4 * PW, bq += 4 * QLD) {
+                const f4 a = *reinterpret_cast<const f4*>(bp);
+                float b[NT];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) b[u] = bq[16 * u];
+                if (sums) {
+                    ps += a;
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) qs[u] += b[u];
+                }
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[u], acc[0][u], 0, 0, 0);
+                    acc[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[u], acc[1][u], 0, 0, 0);
+                    acc[2][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[u], acc[2][u], 0, 0, 0);
+                    acc[3][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u], acc[3][u], 0, 0, 0);
+                }
+            }
+        }
+        if (grp + 1 < ngroups) stash(buf ^ 1);
+        __syncthreads();
+    }
+    if (!active) return;
+    const int PP = nPB * 64, QP = nQG * NT * 16;
+    float* out = partial + (size_t)chunk * PP * QP;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                out[(size_t)(64 * pb + 4 * (4 * g + q) + c) * QP + 16 * (qg * NT + u) + i] = acc[c][u][q];
+    if (psum != nullptr && qg == 0) {
+        ps.x = col_reduce(ps.x); ps.y = col_reduce(ps.y); ps.z = col_reduce(ps.z); ps.w = col_reduce(ps.w);
+        if (g == 0) st_f4(psum + (size_t)chunk * PP + 64 * pb + 4 * i, ps);
+    }
+    if (qsum != nullptr && pb == 0) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const float v = col_reduce(qs[u]);
+            if (g == 0) qsum[(size_t)chunk * QP + 16 * (qg * NT + u) + i] = v;
+        }
+    }
+}
+
 // Small outputs (MO * (MI + 1) <= 1024, e.g. the 8 x 48 / 48 x 2 / 1 x 9 layers of the frame-scalar MLPs over ~1e6 rows): the MFMA
 // kernel above would run 128 x 256 tiles that are almost all padding and is latency-bound there.  Here a workgroup stages 64
 // rows of both operands in LDS and every thread owns up to four outputs (o, i); column i == MI is the bias (X = 1).
@@ -523,17 +662,31 @@ __global__ __launch_bounds__(256) void k_wgrad_small_reduce(const float* __restr
 // second pass: dW[o][i] (dense, logical nn.Linear shape) = sum over chunks in ascending order.  Logical index -> padded index by
 // sections (o = s * len + w -> s * pad + w), which undoes the 196 -> 208 padding of split projections.  `transposed`: the
 // partials are [x feature][dY feature] (the kernel ran with P = X, Q = dY).
-__global__ void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int PP, int QP, int transposed, int o_len, int o_pad,
+// 256 threads = 32 consecutive outputs x 8 chunk slices: slice s adds chunks s, s + 8, ... in ascending order (eight loads in flight
+// per output instead of one thread walking all chunks), the eight slice sums are then added in slice order - a fixed order again.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int PP, int QP, int transposed, int o_len, int o_pad,
                                int MO, int i_len, int i_pad, int MI, float* __restrict__ out, int ldW, int acc) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)MO * MI) return;
-    const int o = (int)(idx / MI), i = (int)(idx % MI);
-    const int op = (o / o_len) * o_pad + o % o_len, ip = (i / i_len) * i_pad + i % i_len;
-    const float* p = partial + (transposed ? (size_t)ip * QP + op : (size_t)op * QP + ip);
+    __shared__ float red[8][33];
+    const int oi = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long long idx = (long long)blockIdx.x * 32 + oi;
+    const bool ok = idx < (long long)MO * MI;
     float s = 0.f;
-    for (int ch = 0; ch < n_chunks; ++ch) s += p[(size_t)ch * PP * QP];
-    float* dst = out + (size_t)o * ldW + i;
-    *dst = acc ? *dst + s : s;
+    int o = 0, i = 0;
+    if (ok) {
+        o = (int)(idx / MI); i = (int)(idx % MI);
+        const int op = (o / o_len) * o_pad + o % o_len, ip = (i / i_len) * i_pad + i % i_len;
+        const float* p = partial + (transposed ? (size_t)ip * QP + op : (size_t)op * QP + ip);
+        for (int ch = sl; ch < n_chunks; ch += 8) s += p[(size_t)ch * PP * QP];
+    }
+    red[sl][oi] = s;
+    __syncthreads();
+    if (sl == 0 && ok) {
+        float t = red[0][oi];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][oi];
+        float* dst = out + (size_t)o * ldW + i;
+        *dst = acc ? *dst + t : t;
+    }
 }
 __global__ __launch_bounds__(256) void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int stride, int o_len, int o_pad,
                                                       int MO, float* __restrict__ out, int acc) {  // one wave per output

@@ -65,6 +65,7 @@ int g_poison = 0;           // 1: fill the workspace with NaN bit patterns befor
 int g_parts = 0;            // sub-batches per topology (0 = auto: 4 for B >= 32, 2 for B >= 16, else 1)
 int g_small_split = 128;     // EquiMessage latency kernel: launches of <= this many 16-edge tiles run one launch per dense stage
                             // (a workgroup = 16 edges x 8 output tiles); 0 = never
+int g_wgrad_lds = 256;       // workgroups per weight-gradient GEMM of the LDS-panel kernel (0: always the per-wave-tile kernel k_wgrad)
 int g_wgrad_wgs = 512;       // workgroups per weight-gradient GEMM (row chunks x task groups): one round of 2 x 4 waves per CU
                             // (measured per training step: 384 -> 38.1 ms, 512 -> 30.7, 768 -> 36.0, 1024 -> 33.2, 2048 -> 38.1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
@@ -636,7 +637,7 @@ static int equi_msg_backward_impl(const TopoDev& tp, const char* tape, const Tap
 // plan of the weight-gradient GEMM: a pure function of the shape, so that the summation order (and with it the result,
 // bit for bit) does not depend on anything else.  Q (16-wide tiles, no padding waste) is the narrower operand; when that is
 // dY the kernel produces the transposed product.
-struct WgradPlan { int transposed, NT, nPB, nQG, PP, QP, gy; long long rpc; int n_chunks; };
+struct WgradPlan { int transposed, NT, nPB, nQG, PP, QP, gy; long long rpc; int n_chunks; int lds; };
 static WgradPlan wgrad_plan(int ncY, int ncX, long long rows) {
     WgradPlan p;
     p.transposed = ncX > ncY ? 1 : 0;
@@ -647,9 +648,21 @@ static WgradPlan wgrad_plan(int ncY, int ncX, long long rows) {
     p.PP = p.nPB * 64; p.QP = p.nQG * p.NT * 16;
     p.gy = (int)cdiv((long long)p.nPB * p.nQG, 4);            // workgroups (4 waves = 4 (P block, Q group) tasks) per row chunk
     long long want = std::max<long long>(1, g_wgrad_wgs / p.gy);
-    want = std::min(want, std::max<long long>(1, cdiv(rows, 64)));
+    want = std::min(want, std::max<long long>(1, cdiv(rows, rows < 16384 ? 128 : 64)));      // short contractions: fewer, longer chunks (the partials dominate)
     p.rpc = align_up((size_t)cdiv(std::max<long long>(rows, 1), want), 4 * OARD_WG_PD);
     p.n_chunks = (int)cdiv(std::max<long long>(rows, 1), p.rpc);
+    // long contractions with at least two Q groups: the LDS-panel kernel (k_wgrad_lds), one 8-wave workgroup per CU and round;
+    // a workgroup owns 4 P blocks x 2 Q groups of a row chunk
+    p.lds = (g_wgrad_lds > 0 && rows >= 16384 && p.nQG >= 2) ? 1 : 0;
+    if (p.lds && (long long)p.nPB * p.nQG * 4 < cdiv(p.nPB, 4) * cdiv(p.nQG, 2) * 8 * 3) p.lds = 0;     // < 75 % of the wave slots would hold a task
+    if (p.lds) {
+        const long long tiles = cdiv(p.nPB, 4) * cdiv(p.nQG, 2);
+        long long w2 = std::max<long long>(1, g_wgrad_lds / tiles);
+        w2 = std::min(w2, std::max<long long>(1, cdiv(rows, 4 * WGL_ROWS)));
+        p.rpc = align_up((size_t)cdiv(rows, w2), WGL_ROWS);
+        p.n_chunks = (int)cdiv(rows, p.rpc);
+        p.gy = (int)tiles;
+    }
     return p;
 }
 }  // namespace
@@ -1313,7 +1326,14 @@ static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, i
     const int ldP = p.transposed ? ldX : ldY, ncP = p.transposed ? ncX : ncY, ldQ = p.transposed ? ldY : ldX, ncQ = p.transposed ? ncY : ncX;
     float* psum = (db && !p.transposed) ? bpartial : nullptr;
     float* qsum = (db && p.transposed) ? bpartial : nullptr;
-    {
+    if (p.lds) {
+#define WGL_LAUNCH(SILU_, NT_) do { constexpr size_t lds_ = (size_t)(2 * WGL_ROWS * 256 + 2 * WGL_ROWS * (16 * NT_ * 2 + 16)) * sizeof(float); \
+        LAUNCH_LDS(F_WGRAD, (k_wgrad_lds<SILU_, NT_, 4, 2>), p.n_chunks * p.gy, 512, lds_, st, Pm, ldP, ncP, Qm, ldQ, ncQ, 0LL, (long long)rows, \
+                   p.rpc, p.nPB, p.nQG, partial, psum, qsum); } while (0)
+        if (p.NT == 7) { if (x_silu) WGL_LAUNCH(true, 7); else WGL_LAUNCH(false, 7); }
+        else { if (x_silu) WGL_LAUNCH(true, 8); else WGL_LAUNCH(false, 8); }
+#undef WGL_LAUNCH
+    } else {
         ScopedLaunch sl_(F_WGRAD, st);
         const dim3 grid((unsigned)(p.n_chunks * p.gy)), block(256);
 #define WG_LAUNCH(SILU_, NT_) hipLaunchKernelGGL((k_wgrad<SILU_, NT_>), grid, block, 0, st, Pm, ldP, ncP, Qm, ldQ, ncQ, 0LL, (long long)rows, \
@@ -1321,8 +1341,11 @@ static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, i
         if (p.NT == 7) { if (x_silu) WG_LAUNCH(true, 7); else WG_LAUNCH(false, 7); }
         else { if (x_silu) WG_LAUNCH(true, 8); else WG_LAUNCH(false, 8); }
 #undef WG_LAUNCH
+    }
+    {
+        ScopedLaunch sl_(F_WGRAD, st);
         if (dW)
-            hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 256)), dim3(256), 0, st, partial, p.n_chunks, p.PP,
+            hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 32)), dim3(256), 0, st, partial, p.n_chunks, p.PP,
                                p.QP, p.transposed, o_len, o_pad, MO, i_len, i_pad, MI, dW, ldW, acc);
         if (db)
             hipLaunchKernelGGL(k_bgrad_reduce, dim3((unsigned)cdiv(MO, 4)), dim3(256), 0, st, bpartial, p.n_chunks,
@@ -1557,6 +1580,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "auto_tiny") == 0) { g_auto_tiny = value; return OARD_OK; }
     if (strcmp(name, "npb") == 0) { g_npb = value; return OARD_OK; }
     if (strcmp(name, "wgrad_wgs") == 0) { g_wgrad_wgs = value; return OARD_OK; }
+    if (strcmp(name, "wgrad_lds") == 0) { g_wgrad_lds = value; return OARD_OK; }
     if (strcmp(name, "small_split") == 0) { g_small_split = value; return OARD_OK; }
 #ifdef OARD_PRIO_BALANCE
     if (strcmp(name, "prio_k") == 0) { HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prio_k), &value, sizeof(int))); return OARD_OK; }

@@ -166,6 +166,34 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X
     }
     part[(size_t)blockIdx.x * ncols + c] = s;
 }
+// narrow matrices (ncols <= 16, e.g. the [items][12] operand of the frame-scalar MLP's last layer): one thread per ROW slice instead
+// of one per column - thread t of chunk q adds rows q CSN_ROWS + t, + 256, ... for all columns in registers, then the 256 thread
+// sums are combined by a fixed tree in LDS.  part[q][c] as above.
+#define CSN_ROWS 8192
+__global__ __launch_bounds__(256) void k_colsum_narrow(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
+                                                       const float* __restrict__ wrow, float* __restrict__ part) {
+    __shared__ float red[256][17];
+    const long long rb = r0 + (long long)blockIdx.x * CSN_ROWS, re = rb + CSN_ROWS < r1 ? rb + CSN_ROWS : r1;
+    float s[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s[c] = 0.f;
+    for (long long r = rb + threadIdx.x; r < re; r += 256) {
+        const float w = wrow != nullptr ? wrow[r] : 1.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < ncols) s[c] += X[(size_t)r * ld + c] * w;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) red[threadIdx.x][c] = s[c];
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) red[threadIdx.x][c] += red[threadIdx.x + d][c];
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < ncols) part[(size_t)blockIdx.x * ncols + threadIdx.x] = red[0][threadIdx.x];
+}
 __global__ __launch_bounds__(256) void k_colsum_fin(const float* __restrict__ part, int n_chunks, int ncols, float* __restrict__ out,
                                                     int accumulate, float scale) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);

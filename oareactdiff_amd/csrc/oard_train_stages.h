@@ -123,8 +123,14 @@ static void colsum(const TrainCtx& x, const float* X, int ld, long long r0, long
                    const float* wrow = nullptr, int x_silu = 0, float scale = 1.0f) {
     if (out == nullptr || ncols <= 0) return;
     ScopedLaunch sl_(F_WGRAD, x.st);
-    const int nch = (int)std::max<long long>(1, cdiv(std::max<long long>(r1 - r0, 0), CS_ROWS));
     float* part = x.f(x.w.cpart);
+    if (ncols <= 16 && !x_silu && r1 - r0 > 4 * CS_ROWS) {            // narrow and long: one thread per row slice
+        const int nchn = (int)cdiv(r1 - r0, CSN_ROWS);
+        hipLaunchKernelGGL(k_colsum_narrow, dim3((unsigned)nchn), dim3(256), 0, x.st, X, ld, r0, r1, ncols, wrow, part);
+        hipLaunchKernelGGL(k_colsum_fin, dim3((unsigned)cdiv(ncols, 4)), dim3(256), 0, x.st, (const float*)part, nchn, ncols, out, accumulate, scale);
+        return;
+    }
+    const int nch = (int)std::max<long long>(1, cdiv(std::max<long long>(r1 - r0, 0), CS_ROWS));
     if (r1 > r0)
         hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)nch, (unsigned)cdiv(ncols, 256)), dim3(256), 0, x.st, X, ld, r0, r1, ncols, wrow,
                            x_silu, part);

@@ -53,3 +53,33 @@ def test_wgrad_small_outputs(rows):
     # the frame-scalar MLP layers: 48 x 4 (weight | bias column), 8 x 48, 1 x 12
     _case(rows, 48, 48, 48, 48, 4, 4, 4, 1, False, True, seed=rows)
     _case(rows, 8, 8, 8, 8, 48, 48, 48, 48, False, True, seed=rows + 1)
+
+
+@pytest.mark.parametrize("rows", [16384, 16385, 20011, 40000])
+def test_wgrad_lds_panel_kernel(rows):
+    """rows >= 16 384 with at least two 16-tile groups on the narrow side run k_wgrad_lds (row panels of 32 rows shared through
+    LDS by the eight (P block, Q group) tasks of a workgroup): ragged last groups / chunks, partial 64-column blocks, partial
+    tile groups (37 tiles = 4 full groups of 8 + 5), section padding, SiLU applied when the panel is staged, column sums."""
+    _case(rows, 688, 684, 684, 684, 208, 196, 196, 196, False, True, seed=rows)                    # edge_out_trans: dz3 x m
+    _case(rows, 208, 196, 196, 196, 688, 684, 684, 684, False, False, seed=rows + 1)               # edge_mlp.0 (transposed product)
+    _case(rows, 624, 196, 208, 588, 592, 588, 588, 588, True, True, seed=rows + 2, ld_extra=8)     # dir_proj.2: SiLU on load, thirds
+    _case(rows, 592, 588, 588, 588, 688, 684, 684, 684, False, True, seed=rows + 3)                # dir_proj.0 (transposed, bias on the Q side)
+    _case(rows, 208, 196, 196, 196, 208, 196, 196, 196, True, True, seed=rows + 4)                 # edge_mlp.1
+
+
+def test_wgrad_lds_and_per_wave_kernels_agree():
+    """A/B of the two kernels on one shape through the debug option (deterministic each, equal up to summation order)."""
+    from oareactdiff_amd import _capi
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    rows = 30000
+    dY, X = torch.randn(rows, 688, generator=g).to(dev), torch.randn(rows, 208, generator=g).to(dev)
+    out = {}
+    for mode in (256, 0):
+        assert _capi.lib().oard_debug_option(b"wgrad_lds", mode) == 0
+        out[mode] = training._wgrad(dY, 688, 684, 684, 684, X, 208, False, 196, 196, 196, rows, True, _Owner(), torch.cuda.current_stream().cuda_stream)
+        again = training._wgrad(dY, 688, 684, 684, 684, X, 208, False, 196, 196, 196, rows, True, _Owner(), torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(out[mode][0], again[0]) and torch.equal(out[mode][1], again[1])       # run-to-run deterministic
+    _capi.lib().oard_debug_option(b"wgrad_lds", 256)
+    assert float((out[256][0] - out[0][0]).abs().max()) <= 2e-6 * float(out[0][0].abs().max())
+    assert float((out[256][1] - out[0][1]).abs().max()) <= 2e-6 * float(out[0][1].abs().max())
