@@ -372,8 +372,8 @@ int oard_loss_terms(const oard_config* cfg, const oard_topology* topo, const flo
                     const float* scales, int pos_only, int B, float* nll_dev, float* terms_dev, float* const* dnet_dev,
                     oard_stream_t stream);
 int oard_adamw_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* max_exp_avg_sq_dev,
-                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, int amsgrad,
-                    float grad_scale, oard_stream_t stream);
+                    int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, int amsgrad,
+                    double grad_scale, oard_stream_t stream);
 
 #ifdef __cplusplus
 }

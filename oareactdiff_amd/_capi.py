@@ -120,7 +120,8 @@ def lib() -> C.CDLL:
     pf, cf = C.POINTER(C.c_float), C.c_float
     L.oard_loss_prepare.argtypes = [cfgp, vp, pvp, pvp, pvp, pvp, vp, vp, ci, pf, pf, ci, ci, pvp, pvp, vp]; L.oard_loss_prepare.restype = ci
     L.oard_loss_terms.argtypes = [cfgp, vp, pvp, pvp, pvp, pvp, pvp, vp, vp, ci, pf, pf, pf, ci, ci, vp, vp, pvp, vp]; L.oard_loss_terms.restype = ci
-    L.oard_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, cf, cf, cf, cf, cf, i64, ci, cf, vp]; L.oard_adamw_step.restype = ci
+    cd = C.c_double
+    L.oard_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, cd, cd, cd, cd, cd, i64, ci, cd, vp]; L.oard_adamw_step.restype = ci
     L.oard_debug_stop_after.argtypes = [C.c_int]; L.oard_debug_stop_after.restype = C.c_int
     L.oard_debug_option.argtypes = [C.c_char_p, C.c_int]; L.oard_debug_option.restype = C.c_int
     L.oard_timing_enable.argtypes = [C.c_int]; L.oard_timing_enable.restype = C.c_int

@@ -1500,14 +1500,15 @@ int oard_loss_terms(const oard_config* c, const oard_topology* topo, const float
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
-int oard_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, int64_t step, int amsgrad, float grad_scale,
+int oard_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, int64_t step, int amsgrad, double grad_scale,
                     oard_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || (amsgrad && !max_exp_avg_sq) || n < 0 || step < 1) return OARD_EINVAL;
     if (n == 0) return OARD_OK;
-    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    LAUNCH(F_OTHER, k_adamw, cdiv(n, 256), 256, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, (long long)n, lr, beta1,
-           beta2, eps, weight_decay, bc1, bc2s, amsgrad, grad_scale);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    LAUNCH(F_OTHER, k_adamw, cdiv(n, 256), 256, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, (long long)n,
+           (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1),
+           (float)(1.0 / sqrt(bc2)), amsgrad, (float)grad_scale);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }

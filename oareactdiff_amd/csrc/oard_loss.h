@@ -145,19 +145,21 @@ __global__ __launch_bounds__(64) void k_loss_terms(TopoDev tp, LossPtrs lp, Loss
 }
 
 // AdamW (torch.optim.AdamW single-tensor semantics, amsgrad optional) over a flat bucket; `gscale` multiplies the gradient first
-// (clip_grad_norm_'s factor; 1 = no clipping).  bc1 = 1 - beta1^step, bc2s = sqrt(1 - beta2^step) from the host.
+// (clip_grad_norm_'s factor; 1 = no clipping).  Every derived scalar comes from the host in double precision, rounded once, exactly
+// as torch passes its Python-float scalars to the element-wise kernels: decay = 1 - lr wd, w1 = 1 - beta1, w2 = 1 - beta2,
+// step_size = lr / (1 - beta1^t), inv_bc2s = 1 / sqrt(1 - beta2^t) (torch divides a tensor by a scalar as a product with its inverse).
 __global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                        float* __restrict__ vmax, long long n, float lr, float beta1, float beta2, float eps, float wd, float bc1,
-                        float bc2s, int amsgrad, float gscale) {
+                        float* __restrict__ vmax, long long n, float decay, float w1, float beta2, float w2, float eps, float step_size,
+                        float inv_bc2s, int amsgrad, float gscale) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float gr = g[i] * gscale;
-    float x = p[i] * (1.0f - lr * wd);
-    const float mi = m[i] + (gr - m[i]) * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = v[i] * beta2 + gr * gr * (1.0f - beta2);
+    const float x = p[i] * decay;
+    const float mi = m[i] + w1 * (gr - m[i]);                             // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * beta2 + w2 * (gr * gr);                       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     m[i] = mi; v[i] = vi;
     float den;
-    if (amsgrad) { const float vm = fmaxf(vmax[i], vi); vmax[i] = vm; den = sqrtf(vm) / bc2s + eps; }
-    else den = sqrtf(vi) / bc2s + eps;
-    p[i] = x - (lr / bc1) * (mi / den);
+    if (amsgrad) { const float vm = fmaxf(vmax[i], vi); vmax[i] = vm; den = sqrtf(vm) * inv_bc2s + eps; }
+    else den = sqrtf(vi) * inv_bc2s + eps;
+    p[i] = x - step_size * (mi / den);                                    // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
