@@ -353,6 +353,12 @@ int oard_train_stage_backward(const oard_config* cfg, const oard_topology* topo,
                               float* out0, float* out1, float* out2, const float* const* params_dev, float* const* grads_dev,
                               void* scratch_dev, size_t scratch_bytes, oard_stream_t stream);
 
+/* The reference's NaN guard (egnn_dynamics.py:138-143) without its host sync: if `status_dev[0]` (written by oard_forward) is set,
+ * the velocity columns of every out[k] are replaced by noise[k] ([n_k][3] N(0,1) draws of the caller) minus its per-(sample, object)
+ * mean; otherwise nothing is written.  Asynchronous on `stream`. */
+int oard_nan_replace(const oard_config* cfg, const oard_topology* topo, const int32_t* status_dev, const float* const* noise_dev,
+                     float* const* out_dev, oard_stream_t stream);
+
 /* ---- The training caller around the network call, fused (round 3) --------------------------------------------------------------
  * oard_loss_prepare  EnVariationalDiffusion.forward up to the network call (en_diffusion.py:56-123, noised_representation :250-281,
  *                    sample_combined_position_feature_noise :283-306): normalises the dataset-layout batch (pos float32 [n_k][3],

@@ -24,7 +24,7 @@ EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_by
            "oard_equi_backward_dx", "oard_scalarize_backward", "oard_equi_msg_backward", "oard_lin3u_forward", "oard_lin3u_backward", "oard_wgrad_scratch_bytes", "oard_wgrad",
            "oard_train_scratch_bytes", "oard_train_scratch_poison", "oard_train_scratch_entry", "oard_train_tail_backward",
            "oard_train_layer_backward", "oard_train_init_backward", "oard_train_stage_backward",
-           "oard_loss_prepare", "oard_loss_terms", "oard_adamw_step"]
+           "oard_loss_prepare", "oard_loss_terms", "oard_adamw_step", "oard_nan_replace"]
 STAGE_RECOMPUTE, STAGE_UPDATE, STAGE_MESSAGE, STAGE_GCL_NODE, STAGE_NODE_PRE, STAGE_GCL_EDGE, STAGE_EQUI_EDGE = range(7)
 SCRATCH_XH, SCRATCH_XQ, SCRATCH_CR, SCRATCH_DCD, SCRATCH_DCR = range(1, 6)
 
@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
     L.oard_train_init_backward.argtypes = [cfgp, vp, vp, vp, vp, pvp, vp, vp, pvp, pvp, vp, sz, vp]; L.oard_train_init_backward.restype = ci
     L.oard_train_stage_backward.argtypes = [cfgp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, pvp, pvp, vp, sz, vp]
     L.oard_train_stage_backward.restype = ci
+    L.oard_nan_replace.argtypes = [cfgp, vp, vp, pvp, pvp, vp]; L.oard_nan_replace.restype = ci
     pf, cf = C.POINTER(C.c_float), C.c_float
     L.oard_loss_prepare.argtypes = [cfgp, vp, pvp, pvp, pvp, pvp, vp, vp, ci, pf, pf, ci, ci, pvp, pvp, vp]; L.oard_loss_prepare.restype = ci
     L.oard_loss_terms.argtypes = [cfgp, vp, pvp, pvp, pvp, pvp, pvp, vp, vp, ci, pf, pf, pf, ci, ci, vp, vp, pvp, vp]; L.oard_loss_terms.restype = ci

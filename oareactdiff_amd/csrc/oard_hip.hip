@@ -1451,6 +1451,18 @@ int oard_train_stage_backward(const oard_config* c, const oard_topology* topo, c
     return rc;
 }
 
+int oard_nan_replace(const oard_config* c, const oard_topology* topo, const int32_t* status, const float* const* noise,
+                     float* const* out, oard_stream_t stream) {
+    if (!config_ok(c) || !topo || !status || !noise || !out || c->n_obj != topo->n_obj) return OARD_EINVAL;
+    NanPtrs np;
+    memset(&np, 0, sizeof(np));
+    for (int k = 0; k < c->n_obj; ++k) { np.noise[k] = noise[k]; np.out[k] = out[k]; np.node_nf[k] = c->node_nf[k]; }
+    for (int p = 0; p < topo->n_parts; ++p)
+        LAUNCH(F_OTHER, k_nan_replace, cdiv(topo->parts[p].d.N, 128), 128, (hipStream_t)stream, topo->parts[p].d, np, (const int*)status);
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
 // ---- the training caller, fused (oard_loss.h) ------------------------------------------------------------------------------------
 static LossCfg make_loss_cfg(const oard_config* c, const float* norm_values, const float* norm_biases, const float* scales, int pos_only,
                              int fixed_mask, int T) {

@@ -221,6 +221,26 @@ __global__ void k_post(TopoDev tp, ObjPtrs op, const float* __restrict__ wb, con
     }
 }
 
+// NaN guard of the reference without its host sync (egnn_dynamics.py:138-143: `if torch.any(torch.isnan(vel)): vel = randn_like(vel)`
+// before the per-object CoM removal): when the call's status flag is set, EVERY object's velocity block is replaced by CoM-free
+// N(0,1) noise the caller drew beforehand; otherwise nothing is touched.  One thread per node.
+struct NanPtrs { const float* noise[OARD_MAX_OBJECTS]; float* out[OARD_MAX_OBJECTS]; int node_nf[OARD_MAX_OBJECTS]; };
+__global__ void k_nan_replace(TopoDev tp, NanPtrs np, const int* __restrict__ status) {
+    if (status[0] == 0) return;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= tp.N) return;
+    const int obj = tp.node_obj[n], row = tp.node_row[n], nf = np.node_nf[obj];
+    const int q = tp.node_sample[n] * tp.n_obj + obj;
+    const int g0 = tp.grp_ptr[q], g1 = tp.grp_ptr[q + 1];
+    const float* R = np.noise[obj];
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (int k = g0; k < g1; ++k) { const float* r = R + (size_t)tp.node_row[k] * 3; m0 += r[0]; m1 += r[1]; m2 += r[2]; }
+    const float inv = 1.0f / (float)(g1 - g0);
+    float* o = np.out[obj] + (size_t)row * nf;
+    const float* r = R + (size_t)row * 3;
+    o[0] = r[0] - m0 * inv; o[1] = r[1] - m1 * inv; o[2] = r[2] - m2 * inv;
+}
+
 // =====================================================================================================
 // sampler step (en_diffusion.py:562-702, 278-305; _utils.py:9-31): one thread per node
 // =====================================================================================================

@@ -136,6 +136,8 @@ class EGNNDynamics(nn.Module):
             self.decoders.load_state_dict(source["decoders"])
 
         #: "sync": reference behaviour (egnn_dynamics.py:138-143) — one host sync per call, NaN -> randn.
+        #: "replace": the same replacement WITHOUT a host sync (oard_nan_replace reads the flag on the device; one randn draw per
+        #: object and call whether or not it is used), flag kept like "async".
         #: "async": no host sync; the device-side flag of the last call is kept in `self.last_status` and OR-ed into
         #: the sticky flag `self.nan_seen` (reset it with `reset_nan_seen()`; the sampling loops read it once at the end).
         self.nan_check = "sync"
@@ -322,6 +324,10 @@ class EGNNDynamics(nn.Module):
                 if self.nan_seen is None or self.nan_seen.device != dev:
                     self.nan_seen = torch.zeros(2, dtype=torch.int32, device=dev)
                 self.nan_seen.bitwise_or_(status)         # device-side, no sync
+            if self.nan_check == "replace":               # the reference's guard (:138-143) on the device: randn velocities iff the flag is set
+                noise = [torch.randn(o.shape[0], self.pos_dim, device=dev) for o in outs]
+                nz = (C.c_void_p * n_obj)(*[x.data_ptr() for x in noise])
+                _capi.check(L.oard_nan_replace(C.byref(cfg), topo.handle, status.data_ptr(), nz, op, stream), "oard_nan_replace")
             if self.nan_check == "sync" and int(status[0].item()) != 0:   # egnn_dynamics.py:138-143
                 print("Warning: detected nan in pos, resetting EGNN output to randn.")
                 for k in range(n_obj):

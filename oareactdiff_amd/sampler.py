@@ -28,8 +28,11 @@ class DiffusionSampler:
         """`on_nan`: what to do when any network call of a run predicted a NaN displacement.  The reference replaces that
         step's velocity by randn, prints a warning and keeps sampling (egnn_dynamics.py:138-143) - one host sync per
         step.  Here the loop never syncs: every call ORs its NaN flag into a device-side sticky flag which is read ONCE
-        after the loop; "raise" (default) raises FloatingPointError, "warn" warns and returns the (NaN) samples."""
-        assert on_nan in ("raise", "warn")
+        after the loop; "raise" (default) raises FloatingPointError, "warn" warns and returns the (NaN) samples,
+        "replace" reproduces the reference: the step's velocity becomes CoM-free randn ON THE DEVICE (oard_nan_replace, keyed on the
+        call's device-side flag; costs one extra randn draw per object and step, so the noise stream of a seeded run differs from the
+        other modes) and a warning is printed once after the loop."""
+        assert on_nan in ("raise", "warn", "replace")
         self.on_nan = on_nan
         self.dynamics = dynamics
         self.schedule = Schedule(noise_schedule, timesteps, precision)
@@ -62,6 +65,9 @@ class DiffusionSampler:
     def _check_nan(self, dyn) -> None:
         """The single host read of a sampling run: did any of its network calls produce a NaN displacement?"""
         if dyn.nan_seen is not None and int(dyn.nan_seen[0].item()) != 0:
+            if self.on_nan == "replace":
+                print("Warning: detected nan in pos, resetting EGNN output to randn.")       # the reference's message (:139)
+                return
             msg = ("a network call of this sampling run predicted NaN positions; the reference would have replaced that "
                    "step by randn (egnn_dynamics.py:138-143), this loop does not: the affected samples are NaN")
             if self.on_nan == "raise":
@@ -177,7 +183,7 @@ class DiffusionSampler:
         h0d = [h.to(device=dev, dtype=torch.float32).contiguous() for h in h0] if h0 is not None else None
         sizes = [int(m.numel()) for m in masks]
         old_nan = dyn.nan_check
-        dyn.nan_check = "async"
+        dyn.nan_check = "replace" if self.on_nan == "replace" else "async"
         dyn.reset_nan_seen()
         try:
             with torch.cuda.device(dev):
@@ -297,7 +303,7 @@ class DiffusionSampler:
             xf[k][:, :pd] = EGNNDynamics.remove_mean_batch(xf[k][:, :pd], masks[k])
         sizes = [int(m.numel()) for m in masks]
         old_nan = dyn.nan_check
-        dyn.nan_check = "async"
+        dyn.nan_check = "replace" if self.on_nan == "replace" else "async"
         dyn.reset_nan_seen()
         try:
             with torch.cuda.device(dev):

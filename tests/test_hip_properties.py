@@ -140,3 +140,39 @@ def test_switch_fragments_same_encoding():
         a, _ = dyn(xh, ei, t, cond, nfs, cm)
         b, _ = dyn([xh[1], xh[0]], ei, t, cond, nfs, cm)
     assert rel(b[1], a[0]) < EPS and rel(b[0], a[1]) < EPS
+
+
+@pytest.mark.gpu
+def test_nan_guard_replaces_velocities_on_the_device():
+    """egnn_dynamics.py:138-143: a NaN in the predicted velocity -> warning + randn for EVERY object's velocity (then the per-object
+    CoM removal).  nan_check="replace" does it without the reference's host sync: oard_nan_replace reads the call's flag on the device."""
+    import torch
+    from _cases import Case
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    dev = torch.device("cuda:0")
+    c = Case("g2_prod_b2_n23")
+    dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=[f"o{k}" for k in range(c.n_obj)], node_nfs=c.node_nfs, edge_nf=0,
+                       condition_nf=c.cnf, device=dev)
+    dyn.load_state_dict(c.state_dict(), strict=True)
+    args = ([x.to(dev) for x in c.xh], c.edge_index.to(dev), c.t.to(dev), c.conditions.to(dev), c.n_frag_switch.to(dev), c.combined_mask.to(dev))
+    dyn.nan_check = "replace"
+    with torch.no_grad():
+        clean, _ = dyn(*args)                                    # no NaN: the guard must not touch anything
+    assert int(dyn.last_status[0].item()) == 0
+    v, h = c.split([o.cpu() for o in clean])
+    rv, rh = c.split(c.ref64)
+    assert float((v - rv).abs().max() / rv.abs().max()) <= 1e-5
+    bad = [x.clone() for x in args[0]]
+    bad[1][3, 0] = float("nan")                                  # one poisoned coordinate in the second object
+    torch.manual_seed(11)
+    with torch.no_grad():
+        out, _ = dyn(bad, *args[1:])
+    assert int(dyn.last_status[0].item()) != 0 and int(dyn.nan_seen[0].item()) != 0
+    masks = [c.combined_mask[c.n_frag_switch == k] for k in range(c.n_obj)]
+    for k in range(c.n_obj):
+        vel = out[k][:, :3].cpu()
+        assert bool(torch.isfinite(vel).all())
+        B = int(masks[k].max()) + 1
+        mean = torch.zeros(B, 3).index_add_(0, masks[k], vel) / torch.bincount(masks[k], minlength=B).clamp(min=1).unsqueeze(1)
+        assert float(mean.abs().max()) <= 1e-6                    # CoM-free per (sample, object)
+        assert 0.5 < float(vel.std()) < 1.5                       # N(0, 1) draws, not the network's output
