@@ -49,6 +49,11 @@ struct GclBwdStream {
     static constexpr int NP3 = (WB + GP - 1) / GP, NP2 = (HT + GP - 1) / GP, NP1 = NP3, NPH = NP3 + NP2 + NP1;
     static constexpr int C3 = WB * G, C2 = HT * G, C1 = WB * G, CHUNKS = C3 + C2 + C1;
     static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
+    // round 3: the forward's padding trims (oard_edge_v1.h), same conditions, matching flags in oard_pack_weights_bwd:
+    //   compact K tail - the 13th block of dz2 / dz1 holds <= 4 real features: T2 / T1 tiles end with 1 MFMA instead of 4;
+    //   4-row tiles    - the 13th output tile of W3^T (T3, K-outer) and of W2^T (T2) has <= 4 real rows: v_mfma_f32_4x4x1.
+    static constexpr bool TAIL1 = (D::H % 16) >= 1 && (D::H % 16) <= 4 && HT >= 3 && (HT & 1);
+    static constexpr bool ROWS4 = TAIL1;
 };
 
 struct GclBwdArgs {
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = GclBwdStream<D, GP>;
     constexpr int HT = D::HT, WB = D::WB, G = S::G;
+    constexpr bool TAIL1 = S::TAIL1, ROWS4 = S::ROWS4;
     const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -108,6 +114,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
 
     // ---- T3: dm += W3^T . dz3   (K-outer); the dz3 blocks are stored one phase late ---------------------
     f4 xs[GP];
+    f4 dmx = f4zero();                                   // ROWS4: second accumulator of the 4-row tile (unreduced k-slice sums)
     for (int p3 = 0; HAS_S3 && p3 < S::NP3; ++p3, ++p) {
         phase_barrier();
         if (p3 > 0) {
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
         }
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg)
-            if (p3 * GP + gg < WB) chain_kouter<HT>(SL(p), gg * G, x[gg], dm, hook);
+            if (p3 * GP + gg < WB) chain_kouter<HT, ROWS4>(SL(p), gg * G, x[gg], dm, dmx, hook);
         pf.flush();
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) xs[gg] = x[gg];
@@ -137,6 +144,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
         for (int gg = 0; gg < GP; ++gg) {
             const int b = (S::NP3 - 1) * GP + gg;
             if (b < WB) st_f4(dz3row + 16 * b, xs[gg]);
+        }
+        if (ROWS4) {                                     // k-slice sums of the 4-row tile -> block layout (real rows in lanes g = 0)
+            const f4 v = reduce_g(dm[HT - 1] + dmx);
+            dm[HT - 1] = g == 0 ? v : f4zero();
         }
     }
 
@@ -171,6 +182,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
     // ---- T2: dz1 = (W2^T dz2) * SiLU'(z1), one output tile per group ---------------------------------------
     f4 dz1[HT];
     f4 z1n[GP], on[GP];
+    const float dz2_tail = TAIL1 ? tail_compact(dz2[HT - 1], lane) : 0.f;
 #pragma unroll
     for (int gg = 0; gg < GP; ++gg) z1n[gg] = gg < HT ? ld_blk(a.z1, e, D::HP, gg, lane) : f4zero();
 #pragma unroll
@@ -194,7 +206,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
         for (int gg = 0; gg < GP; ++gg) {
             const int t = p2 * GP + gg;                // compile-time after unrolling
             if (t < HT) {
-                dz1[t] = chain_tile<HT>(SL(p), gg * G, dz2, f4zero(), hook) * dsilu4(zc[gg]);
+                if (ROWS4 && t == HT - 1) {             // 13th tile: 4 real rows on 4x4x1 MFMAs (rows4 packing, K tail not compacted)
+                    const f4 v = reduce_g(chain_tile4<HT>(SL(p), gg * G, dz2, f4zero(), hook));
+                    dz1[t] = (g == 0 ? v : f4zero()) * dsilu4(zc[gg]);
+                } else {
+                    dz1[t] = chain_tile<HT, TAIL1>(SL(p), gg * G, dz2, f4zero(), dz2_tail, hook) * dsilu4(zc[gg]);
+                }
                 st_blk(a.dz1, e, D::HP, t, lane, dz1[t]);
             }
         }
@@ -203,6 +220,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
 
     // ---- T1: G_out = G + W1c^T dz1, one output tile per group; stores one phase late --------------------------
     f4 pend[GP];
+    const float dz1_tail = TAIL1 ? tail_compact(dz1[HT - 1], lane) : 0.f;
     for (int p1 = 0; p1 < S::NP1; ++p1, ++p) {
         phase_barrier();
         if (p1 > 0) {
@@ -223,7 +241,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
             const int t = p1 * GP + gg;
-            if (t < WB) pend[gg] = chain_tile<HT>(SL(p), gg * G, dz1, o[gg], hook);
+            if (t < WB) pend[gg] = chain_tile<HT, TAIL1>(SL(p), gg * G, dz1, o[gg], dz1_tail, hook);
         }
         pf.flush();
     }

@@ -1185,11 +1185,14 @@ int oard_pack_weights_bwd(const oard_config* c, const float* const* params, size
         const int g = pi.gcl0 + 14 * l, m = pi.msg0 + 9 * l;
         const size_t t3 = bo.layer[l].gcl, t2 = t3 + (size_t)d.WB * d.HT * 256, t1 = t2 + (size_t)d.HT * d.HT * 256;
         // W3^T, K-outer over the WB blocks of dz3: chunk (t, b) = W3[16b..][16t..]^T
-        pk.matrix(g + 8, H, 0, H, d.HP, 1, W, d.WP, 1, d.HT, d.WB, t3, 256, (size_t)d.HT * 256, 0, 1);
+        // GclBwdStream::TAIL1 / ROWS4 (the forward's condition): compact K tail of the H-wide inputs of T2 / T1, 13th output tile of
+        // W3^T / W2^T packed for the 4x4x1 MFMA
+        const int tc = (H % 16 >= 1 && H % 16 <= 4 && d.HT >= 3 && (d.HT & 1)) ? 1 : 0;
+        pk.matrix(g + 8, H, 0, H, d.HP, 1, W, d.WP, 1, d.HT, d.WB, t3, 256, (size_t)d.HT * 256, 0, 1, 0, tc * d.HT);
         // W2^T tiles
-        pk.matrix(g + 2, H, 0, H, d.HP, 1, H, d.HP, 1, d.HT, d.HT, t2, 0, 256, 0, 1);
+        pk.matrix(g + 2, H, 0, H, d.HP, 1, H, d.HP, 1, d.HT, d.HT, t2, 0, 256, 0, 1, tc, tc * d.HT);
         // W1c^T tiles (edge_mlp.0 columns 2H..2H+W)
-        pk.matrix(g + 0, 2 * H + W, 2 * H, W, d.WP, 1, H, d.HP, 1, d.WB, d.HT, t1, 0, 256, 0, 1);
+        pk.matrix(g + 0, 2 * H + W, 2 * H, W, d.WP, 1, H, d.HP, 1, d.WB, d.HT, t1, 0, 256, 0, 1, tc, 0);
         pk.vec(g + 10, H, d.HP, 1, d.HP, bo.layer[l].watt);
         const size_t u2 = bo.layer[l].equi, u1 = u2 + (size_t)3 * d.HT * d.D1T * 256;
         // dir_proj.2^T, K-outer over the 3*HT blocks of dcd (thirds padded 196 -> 208): rows = dir_proj hidden

@@ -90,4 +90,4 @@ def test_adamw_kernel_matches_torch(amsgrad, wd, gscale):
         _capi.check(_capi.lib().oard_adamw_step(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), vm.data_ptr(), n, 2.5e-4, 0.9, 0.999,
                                                 1e-8, wd, step, 1 if amsgrad else 0, gscale, stream), "adamw")
         e = float((p - ref.detach()).abs().max())
-        assert e <= 1e-6, (step, e)           # an ulp or two of O(1..5) weights
+        assert e <= 3e-6, (step, e)           # a few ulp of O(1..5) weights (the derived scalars are rounded once, like torch does)
