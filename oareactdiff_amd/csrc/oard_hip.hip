@@ -7,6 +7,8 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <utility>
 
 #include "oard_kernels.h"
 #include "oard_edge_v1.h"
@@ -200,29 +202,77 @@ struct ParamIdx {
 
 struct Packer {
     const float* const* p; float* blob; hipStream_t st;
+    std::vector<GenJob> jobs;
+    long long blocks = 0;
+    void push(GenJob j, size_t work) {
+        j.block0 = blocks;
+        blocks += cdiv((long long)std::max<size_t>(work, 1), 256);
+        jobs.push_back(j);
+    }
     void matrix(int src, int src_ld, int col_off, int msl, int msp, int ms, int ksl, int ksp, int ks, int MT, int KB,
                 size_t dst, size_t tstride = 0, size_t bstride = 256, int perm_ht = 0, int transpose = 0, int tail_compact = 0,
                 int rows4 = 0) {
         if (tstride == 0) tstride = (size_t)KB * 256;
-        PackJob j{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst, tstride, bstride, perm_ht, transpose, rows4, tail_compact};
-        const size_t total = (size_t)MT * KB * 256;
-        hipLaunchKernelGGL(k_pack_matrix, dim3((unsigned)std::min<size_t>(cdiv(total, 256), 4096)), dim3(256), 0, st, j, blob);
+        GenJob j;
+        memset(&j, 0, sizeof(j));
+        j.type = 0;
+        j.m = PackJob{p[src], src_ld, col_off, msl, msp, ms, ksl, ksp, ks, MT, KB, dst, tstride, bstride, perm_ht, transpose, rows4, tail_compact};
+        push(j, (size_t)MT * KB * 256);
     }
     // natural (unsectioned) matrix [M][K] taken from columns [col_off, col_off+K) of a [M][src_ld] tensor
     void nat(int src, int src_ld, int col_off, int M, int K, int MT, int KB, size_t dst) {
         matrix(src, src_ld, col_off, M, MT * 16, 1, K, KB * 16, 1, MT, KB, dst);
     }
     void vec(int src, int sect_len, int sect_pad, int sects, int n_dst, size_t dst) {
-        hipLaunchKernelGGL(k_pack_vector, dim3((unsigned)cdiv(n_dst, 256)), dim3(256), 0, st,
-                           src >= 0 ? p[src] : nullptr, blob + dst, sect_len, sect_pad, sects, n_dst);
+        GenJob j;
+        memset(&j, 0, sizeof(j));
+        j.type = 1; j.src = src >= 0 ? p[src] : nullptr; j.dst = dst; j.sect_len = sect_len; j.sect_pad = sect_pad; j.sects = sects; j.n = n_dst;
+        push(j, (size_t)n_dst);
     }
     void bias_chunks(int src, int sect_len, int sect_pad, int sects, int n_tiles, size_t dst, size_t tstride,
                      int perm_ht = 0) {
-        hipLaunchKernelGGL(k_pack_bias_chunks, dim3((unsigned)cdiv((long long)n_tiles * 256, 256)), dim3(256), 0, st,
-                           p[src], blob + dst, sect_len, sect_pad, sects, n_tiles, tstride, perm_ht);
+        GenJob j;
+        memset(&j, 0, sizeof(j));
+        j.type = 2; j.src = p[src]; j.dst = dst; j.sect_len = sect_len; j.sect_pad = sect_pad; j.sects = sects; j.n = n_tiles * 256;
+        j.tstride = tstride; j.perm_ht = perm_ht;
+        push(j, (size_t)n_tiles * 256);
     }
     void raw(int src, int n, size_t dst) {
-        hipLaunchKernelGGL(k_copy_raw, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, p[src], blob + dst, n);
+        GenJob j;
+        memset(&j, 0, sizeof(j));
+        j.type = 3; j.src = p[src]; j.dst = dst; j.n = n;
+        push(j, (size_t)n);
+    }
+    // one launch for everything recorded so far.  The job table lives on the device, cached per blob address: it only changes when the
+    // parameter tensors move (it is compared with the cached host copy on every call, a few hundred KiB of memcmp)
+    int flush() {
+        if (jobs.empty()) return OARD_OK;
+        struct Cached { std::vector<GenJob> host; GenJob* dev = nullptr; size_t cap = 0; };
+        static std::mutex mu;
+        static std::map<std::pair<const void*, int>, Cached> cache;
+        int devid = 0;
+        (void)hipGetDevice(&devid);
+        const GenJob* table = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            Cached& c = cache[{(const void*)blob, devid}];
+            const bool same = c.host.size() == jobs.size() && memcmp(c.host.data(), jobs.data(), jobs.size() * sizeof(GenJob)) == 0;
+            if (!same) {
+                HIP_TRY(hipStreamSynchronize(st));            // a launch that still reads the old table may be in flight
+                if (c.cap < jobs.size()) {
+                    if (c.dev) (void)hipFree(c.dev);
+                    HIP_TRY(hipMalloc((void**)&c.dev, jobs.size() * sizeof(GenJob)));
+                    c.cap = jobs.size();
+                }
+                HIP_TRY(hipMemcpy(c.dev, jobs.data(), jobs.size() * sizeof(GenJob), hipMemcpyHostToDevice));
+                c.host = jobs;
+            }
+            table = c.dev;
+        }
+        hipLaunchKernelGGL(k_pack_all, dim3((unsigned)blocks), dim3(256), 0, st, table, (int)jobs.size(), blob);
+        jobs.clear();
+        blocks = 0;
+        return OARD_OK;
     }
 };
 // scratch of the stage-split latency path (activations between the stage launches), set per forward call / sub-batch
@@ -685,7 +735,7 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
     const int H = d.H, R = d.R, W = d.W, C = c->in_hidden, emb = embed_dim(c);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(packed, 0, po.total * sizeof(float), st));
-    Packer pk{params, (float*)packed, st};
+    Packer pk{params, (float*)packed, st, {}, 0};
 
     pk.nat(pi.emb_w, C, 0, H, C, d.HT, 1, po.emb);          pk.vec(pi.emb_b, H, d.HP, 1, d.HP, po.emb_b);
     pk.nat(pi.nbemb_w, C, 0, H, C, d.HT, 1, po.nbemb);      pk.vec(pi.nbemb_b, H, d.HP, 1, d.HP, po.nbemb_b);
@@ -769,6 +819,7 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
             pk.bias_chunks(m + 3, H, d.HP, 3, 3 * d.HT, t2, GE, d.HT);
         }
     }
+    { int rcf = pk.flush(); if (rcf != OARD_OK) return rcf; }
     hipLaunchKernelGGL(k_c0row, dim3((unsigned)cdiv(d.WP, 256)), dim3(256), 0, st, params[pi.lin30_b], params[pi.lin32_w],
                        params[pi.lin32_b], params[pi.rl0_b], params[pi.rl2_w], params[pi.rl2_b],
                        (float*)packed + po.c0row, H, d.H4, d.WP);
@@ -1179,7 +1230,7 @@ int oard_pack_weights_bwd(const oard_config* c, const float* const* params, size
     const int H = d.H, W = d.W;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(packed, 0, nbo.total * sizeof(float), st));
-    Packer pk{params, (float*)packed, st};
+    Packer pk{params, (float*)packed, st, {}, 0};
     pack_node_bwd(c, pk, nbo);
     for (int l = 0; l < c->num_layers; ++l) {
         const int g = pi.gcl0 + 14 * l, m = pi.msg0 + 9 * l;
@@ -1200,6 +1251,7 @@ int oard_pack_weights_bwd(const oard_config* c, const float* const* params, size
         // dir_proj.0^T tiles
         pk.matrix(m + 0, W, 0, W, d.WP, 1, 3 * H, d.D1P, 1, d.WB, d.D1T, u1, 0, 256, 0, 1);
     }
+    { int rcf = pk.flush(); if (rcf != OARD_OK) return rcf; }
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }

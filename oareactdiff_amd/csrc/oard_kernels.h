@@ -101,6 +101,64 @@ __global__ void k_copy_raw(const float* __restrict__ src, float* __restrict__ ds
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
 }
+// ---- all packing jobs of one oard_pack_weights(_bwd) call in ONE launch --------------------------------------------------------------
+// The weights change every training step, so both blobs are re-packed every step: ~420 launches of a few microseconds each.  The jobs
+// (matrix -> MFMA chunks, padded vectors, bias chunks, raw copies) only depend on the parameter / blob addresses, so their table is
+// built once on the host, cached on the device, and one kernel walks it: block b belongs to the job whose [block0, block0 + nblocks)
+// range holds it (binary search), 256 elements per block.
+struct GenJob {
+    int type;                  // 0 matrix, 1 vector, 2 bias chunks, 3 raw copy
+    PackJob m;                 // type 0 (dst inside)
+    const float* src;          // types 1..3
+    size_t dst;
+    int sect_len, sect_pad, sects, n;      // n: destination elements (1: n_dst, 2: n_tiles * 256, 3: n)
+    size_t tstride;
+    int perm_ht;
+    long long block0;          // first block of this job
+};
+__global__ __launch_bounds__(256) void k_pack_all(const GenJob* __restrict__ jobs, int n_jobs, float* __restrict__ blob) {
+    int lo = 0, hi = n_jobs - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) {                                     // last job with block0 <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const GenJob& J = jobs[lo];
+    const size_t i = (size_t)(b - J.block0) * 256 + threadIdx.x;
+    if (J.type == 0) {
+        const PackJob& j = J.m;
+        const size_t total = (size_t)j.MT * j.KB * 256;
+        if (i >= total) return;
+        const int c = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        const size_t ch = i >> 8;
+        const int bb = (int)(ch % j.KB), t = (int)(ch / j.KB);
+        const bool r4 = j.rows4 > 0 && t % j.rows4 == j.rows4 - 1;
+        const bool tail = j.tail_compact && bb == j.KB - 1 && !r4;
+        const int r = 16 * t + (r4 ? (lane & 3) : (lane & 15)), k = tail ? 16 * bb + (lane >> 4) : 16 * bb + 4 * (lane >> 4) + c;
+        const int rs = r / j.msect_pad, rw = r % j.msect_pad;
+        const int ks = k / j.ksect_pad, kw = k % j.ksect_pad;
+        float v = 0.f;
+        if (rs < j.msects && rw < j.msect_len && ks < j.ksects && kw < j.ksect_len && !(tail && c != 0))
+            v = j.transpose ? j.src[(size_t)(ks * j.ksect_len + kw) * j.src_ld + j.col_off + rs * j.msect_len + rw]
+                            : j.src[(size_t)(rs * j.msect_len + rw) * j.src_ld + j.col_off + ks * j.ksect_len + kw];
+        const int slot = j.perm_ht > 0 ? (t % j.perm_ht) * 3 + t / j.perm_ht : t;
+        blob[j.dst + (size_t)slot * j.tstride + (size_t)bb * j.bstride + (i & 255)] = v;
+    } else if (J.type == 1) {
+        if (i >= (size_t)J.n) return;
+        const int s = (int)(i / J.sect_pad), w = (int)(i % J.sect_pad);
+        blob[J.dst + i] = (J.src != nullptr && s < J.sects && w < J.sect_len) ? J.src[s * J.sect_len + w] : 0.f;
+    } else if (J.type == 2) {
+        if (i >= (size_t)J.n) return;
+        const int t = (int)(i >> 8), lane = (int)((i >> 2) & 63), c = (int)(i & 3);
+        const int r = 16 * t + 4 * (lane >> 4) + c;
+        const int s = r / J.sect_pad, w = r % J.sect_pad;
+        const int slot = J.perm_ht > 0 ? (t % J.perm_ht) * 3 + t / J.perm_ht : t;
+        blob[J.dst + (size_t)slot * J.tstride + (i & 255)] = (J.src != nullptr && s < J.sects && w < J.sect_len) ? J.src[s * J.sect_len + w] : 0.f;
+    } else {
+        if (i < (size_t)J.n) blob[J.dst + i] = J.src[i];
+    }
+}
+
 // constant state of a masked edge (leftnet.py:768-809 with dist = 0, radial_emb = 0, frame = 0):
 //   [ lin3(0) x 2H | radial_lin(0) | 0 x R | pad ]
 __global__ void k_c0row(const float* __restrict__ lin3w0b /*b0*/, const float* __restrict__ lin3w2,
