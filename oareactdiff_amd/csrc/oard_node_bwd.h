@@ -323,3 +323,141 @@ __global__ __launch_bounds__(256) void k_lin3u_bwd(const float* __restrict__ p, 
     }
     dx[i] = dxv;
 }
+
+
+// =====================================================================================================
+// k_lin3u_bwd_fused (round 3): the same adjoint WITH its weight gradients.  k_lin3u_bwd leaves 120 floats per item in HBM
+// (h1, dz1, dz2, h2a, xa: 440 MB per layer at B = 64) for two k_wgrad_small passes and two column sums to read back - ~0.45 ms per
+// layer for a 593-parameter MLP.  Here a wave keeps the operands of its 64 items in LDS and contracts them over the items on the
+// matrix cores (the items are the MFMA K index, 16 steps of v_mfma_f32_16x16x4_f32 per 64 items):
+//     Y2^T [16 x items] x [h1 | 1] [items x (48 + 1)]     Y2 = (dz2 [8] | dout h2 [8])  ->  d lin3.2.weight, d lin3.2.bias, d lin3.4.weight
+//     dz1^T [48 x items] x (x, 1) [items x 2]                                             ->  d lin3.0.weight[:, 0], d lin3.0.bias
+// The accumulators live in registers over all the groups a wave walks; one partial block per wave at the end, reduced in a fixed
+// order by k_lin3u_reduce (deterministic; d lin3.4.bias = sum of dout by a wave butterfly).
+// LDS per wave: operand rows [64][52] (h1, then dz1 in the same place), Y2 [64][20], x [64]; the strides (52, 20) make the float4
+// row writes of the 64 lanes conflict-free (208- / 80-byte row pitch = odd multiples of 16 bytes).
+// =====================================================================================================
+#define L3F_S1 52
+#define L3F_S2 20
+#define L3F_WAVE_FLOATS (64 * L3F_S1 + 64 * L3F_S2 + 64)
+#define L3F_PART 1856            // per wave: acc W2 [4 tiles][64 lanes][4] | acc W0 [3][64][4] | sum dout (1, padded to 64)
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_lin3u_bwd_fused(const float* __restrict__ p, const float* __restrict__ x,
+                                                                 const float* __restrict__ dout, long long n, float* __restrict__ dx,
+                                                                 float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float l3f_sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    float* OP = l3f_sm + (size_t)wave * L3F_WAVE_FLOATS;          // [64][L3F_S1]
+    float* Y2 = OP + 64 * L3F_S1;                                  // [64][L3F_S2]
+    float* XS = Y2 + 64 * L3F_S2;                                  // [64]
+    const float* w0 = p;
+    const float* b0 = p + 144;
+    const float* w2 = p + 192;
+    const float* b2 = p + 576;
+    const float* w4 = p + 584;
+    f4 aw2[4], aw0[3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) aw2[t] = f4zero();
+#pragma unroll
+    for (int t = 0; t < 3; ++t) aw0[t] = f4zero();
+    float sg = 0.f;
+    const long long ngroups = (n + 63) / 64;
+    for (long long grp = (long long)blockIdx.x * WAVES + wave; grp < ngroups; grp += (long long)gridDim.x * WAVES) {
+        const long long it = grp * 64 + lane;
+        const bool ok = it < n;
+        const float xv = ok ? x[it] : 0.f, gv = ok ? dout[it] : 0.f;     // items beyond n: dout = 0 -> every gradient operand is 0
+        sg += gv;
+        float z2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z2[j] = b2[j];
+        for (int k0 = 0; k0 < 48; k0 += 4) {
+            f4 h;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = k0 + c;
+                const float hk = silu1(w0[3 * k] * xv + b0[k]);
+                h[c] = hk;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z2[j] += w2[j * 48 + k] * hk;
+            }
+            st_f4(OP + lane * L3F_S1 + k0, h);
+        }
+        float dz2[8];
+        f4 ya = f4zero(), yb = f4zero(), yc = f4zero(), yd = f4zero();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float h2 = silu1(z2[j]);
+            dz2[j] = gv * w4[j] * dsilu1(z2[j]);
+            if (j < 4) { ya[j] = dz2[j]; yc[j] = gv * h2; } else { yb[j - 4] = dz2[j]; yd[j - 4] = gv * h2; }
+        }
+        st_f4(Y2 + lane * L3F_S2, ya); st_f4(Y2 + lane * L3F_S2 + 4, yb); st_f4(Y2 + lane * L3F_S2 + 8, yc); st_f4(Y2 + lane * L3F_S2 + 12, yd);
+        XS[lane] = xv;
+        __builtin_amdgcn_wave_barrier();                                  // same-wave LDS traffic: the queue is in order, keep the compiler in order too
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {                                    // Y2^T x [h1 | 1]
+            const int r = 4 * s + g;
+            const float a2 = Y2[r * L3F_S2 + i];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) aw2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, OP[r * L3F_S1 + 16 * t + i], aw2[t], 0, 0, 0);
+            aw2[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, i == 0 ? 1.0f : 0.f, aw2[3], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float dxv = 0.f;
+        for (int k0 = 0; k0 < 48; k0 += 4) {                              // dz1 over the h1 rows
+            f4 d;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = k0 + c;
+                float dh = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dh += w2[j * 48 + k] * dz2[j];
+                const float dz = dh * dsilu1(w0[3 * k] * xv + b0[k]);
+                d[c] = dz;
+                dxv += w0[3 * k] * dz;
+            }
+            st_f4(OP + lane * L3F_S1 + k0, d);
+        }
+        if (ok) dx[it] = dxv;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {                                    // dz1^T x (x, 1)
+            const int r = 4 * s + g;
+            const float bx = i == 0 ? XS[r] : (i == 1 ? 1.0f : 0.f);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) aw0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(OP[r * L3F_S1 + 16 * t + i], bx, aw0[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sg += __shfl_xor(sg, d, 64);
+    float* out = partial + ((size_t)blockIdx.x * WAVES + wave) * L3F_PART;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) st_f4(out + (t * 64 + lane) * 4, aw2[t]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) st_f4(out + 1024 + (t * 64 + lane) * 4, aw0[t]);
+    if (lane == 0) out[1792] = sg;
+}
+// one wave per parameter-gradient entry: fixed-order sum over the per-wave partial blocks, ADDED to the destination
+//   entries: [0, 384) lin3.2.weight [8][48] | [384, 392) lin3.2.bias | [392, 400) lin3.4.weight | [400, 448) lin3.0.weight[:, 0]
+//            | [448, 496) lin3.0.bias | 496 lin3.4.bias
+__global__ __launch_bounds__(256) void k_lin3u_reduce(const float* __restrict__ partial, int n_waves, float* __restrict__ gw0,
+                                                      float* __restrict__ gb0, float* __restrict__ gw2, float* __restrict__ gb2,
+                                                      float* __restrict__ gw4, float* __restrict__ gb4) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= 497) return;
+    int idx;                       // position inside a partial block
+    float* dst;
+    auto c_idx = [](int base, int t, int row, int col) { return base + (t * 64 + 16 * (row >> 2) + col) * 4 + (row & 3); };   // C layout
+    if (e < 384) { const int row = e / 48, col = e % 48; idx = c_idx(0, col >> 4, row, col & 15); dst = gw2 ? gw2 + e : nullptr; }
+    else if (e < 392) { idx = c_idx(0, 3, e - 384, 0); dst = gb2 ? gb2 + (e - 384) : nullptr; }
+    else if (e < 400) { idx = c_idx(0, 3, 8 + (e - 392), 0); dst = gw4 ? gw4 + (e - 392) : nullptr; }
+    else if (e < 448) { const int h = e - 400; idx = c_idx(1024, h >> 4, h & 15, 0); dst = gw0 ? gw0 + 3 * h : nullptr; }
+    else if (e < 496) { const int h = e - 448; idx = c_idx(1024, h >> 4, h & 15, 1); dst = gb0 ? gb0 + h : nullptr; }
+    else { idx = 1792; dst = gb4; }
+    const float s = chunk_sum_wave(partial + idx, (size_t)L3F_PART, n_waves, lane);
+    if (lane == 0 && dst != nullptr) *dst += s;
+}

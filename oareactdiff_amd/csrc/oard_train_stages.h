@@ -24,7 +24,7 @@ struct TrainWs {
     // recompute of the current layer (tr_recompute), read by the later stages of the same layer
     size_t hid, s1, xh, zm, hm, xln, zq, hq, xq, cr;
     // EquiUpdate adjoint
-    size_t v12, sc, vdot, scal, zx, hx, cvec, dabc, dzx, dscal, dsc, dv12, l3_xa, l3_h1, l3_dz1, l3_h2a, l3_dz2;
+    size_t v12, sc, vdot, scal, zx, hx, cvec, dabc, dzx, dscal, dsc, dv12, l3_h1;      // l3_h1: per-wave partial blocks of k_lin3u_bwd_fused
     // message adjoint / edge stages
     size_t gx, gs_a, gvec_a, dxq, dvec_in, dcd, dcr, dzd1, dz3, mout, dz2, dz1, da, dPQ, dagg;
     // GCL node / pre adjoint
@@ -46,8 +46,7 @@ static TrainWs make_train_ws(const oard_config* c, const TopoDev& td) {
     w.zx = take(N * HP * F); w.hx = take(N * HP * F); w.cvec = take(N * HP * F); w.dabc = take(N * 3 * HP * F); w.dzx = take(N * HP * F);
     w.dscal = take(N * HP * F); w.dsc = take(N * HP * F); w.dv12 = take(3 * N * 2 * HP * F);
     const size_t items = N * HP;
-    w.l3_xa = take(items * 4 * F); w.l3_h1 = take(items * 48 * F); w.l3_dz1 = take(items * 48 * F); w.l3_h2a = take(items * 12 * F);
-    w.l3_dz2 = take(items * 8 * F);
+    w.l3_h1 = take((size_t)512 * 4 * L3F_PART * F);
     w.gx = take(N * HP * F); w.gs_a = take(N * HP * F); w.gvec_a = take(3 * N * HP * F); w.dxq = take(N * 3 * HP * F);
     w.dvec_in = take(3 * N * HP * F); w.dcd = take(A * 3 * HP * F); w.dcr = take(A * 3 * HP * F); w.dzd1 = take(A * d.D1P * F);
     w.dz3 = take(E * d.WP * F); w.mout = take(E * HP * F); w.dz2 = take(E * HP * F); w.dz1 = take(E * HP * F); w.da = take(E * F);
@@ -66,7 +65,8 @@ static TrainWs make_train_ws(const oard_config* c, const TopoDev& td) {
             {WPi, HPi, Er}, {HPi, HPi, Er}, {HPi, WPi, Er},                                             // GCLMessage edge MLP
             {3 * HPi, D1, Ar}, {D1, WPi, Ar}, {3 * HPi, RPi, Ar}, {HPi, HPi, Ar}, {HPi, RPi, Ar},       // dir_proj, rbf_proj, radial_lin
             {3 * HPi, HPi, Nr}, {HPi, HPi, Nr}, {2 * HPi, HPi, 3 * Nr}, {HPi, HPi, 3 * Nr}, {HPi, 16, Nr}, {16, HPi, Nr}, {HPi, PPi, Nr},
-            {48, 4, Ir}, {8, 48, Ir}, {32, 16, Nr}, {16, 32, Nr}};
+            {32, 16, Nr}, {16, 32, Nr}};
+        (void)Ir;
         w.wg_bytes = 0;
         for (const auto& sh : shapes) w.wg_bytes = std::max(w.wg_bytes, oard_wgrad_scratch_bytes(sh.y, sh.x, sh.r));
     }
@@ -282,9 +282,17 @@ static int tr_update_bwd(const TrainCtx& x, int l, const float* ds, const float*
     // d [s_a | scalar] = xvec_proj.0^T dzx:  the s half lands on ds (identity path of s_out = s_a + ...), the scalar half goes to lin3
     rows_dense<HT, EPI_ADD>(x, N, dzx, HP, x.pb + nl.xv0T, HT, gs_a, HP, nullptr, nullptr, 0, HT, ds, HP);
     rows_dense<HT>(x, N, dzx, HP, x.pb + nl.xv0T + (size_t)HT * HT * 256, HT, dscal, HP);
+    // lin3 adjoint + its parameter gradients in one pass (k_lin3u_bwd_fused): per-wave partial blocks, then a fixed-order reduce
+    constexpr int L3_WAVES = 4, L3_BLOCKS = 512;
     { ScopedLaunch sl_(F_NODE, x.st);
-      hipLaunchKernelGGL(k_lin3u_bwd, EW_GRID(NH), 0, x.st, x.wb + lo.l3u, (const float*)sc, (const float*)dscal, NH, dsc, x.f(x.w.l3_xa),
-                         x.f(x.w.l3_h1), x.f(x.w.l3_dz1), x.f(x.w.l3_h2a), x.f(x.w.l3_dz2));
+      static bool l3_attr[64] = {};
+      int dv_ = 0; (void)hipGetDevice(&dv_); dv_ &= 63;
+      const size_t l3_lds = (size_t)L3_WAVES * L3F_WAVE_FLOATS * sizeof(float);
+      if (!l3_attr[dv_]) { TR_TRY(set_lds(k_lin3u_bwd_fused<L3_WAVES>, l3_lds)); l3_attr[dv_] = true; }
+      hipLaunchKernelGGL((k_lin3u_bwd_fused<L3_WAVES>), dim3(L3_BLOCKS), dim3(L3_WAVES * 64), l3_lds, x.st, x.wb + lo.l3u, (const float*)sc,
+                         (const float*)dscal, NH, dsc, x.f(x.w.l3_h1));
+      hipLaunchKernelGGL(k_lin3u_reduce, dim3((unsigned)cdiv(497, 4)), dim3(256), 0, x.st, (const float*)x.f(x.w.l3_h1), L3_BLOCKS * L3_WAVES,
+                         x.g(u + 3), x.g(u + 4), x.g(u + 5), x.g(u + 6), x.g(u + 7), x.g(u + 8));
       hipLaunchKernelGGL(k_upd_dv1, EW_GRID(NH), 0, x.st, (const float*)dsc, x1, N, HP, dv12); }
     rows_dense<2 * HT, EPI_ADD>(x, 3LL * N, dv12, 2 * HP, x.pb + nl.vpT, HT, gvec_a, HP, nullptr, nullptr, 0, 2 * HT, dvec, HP);
     // ---- parameter gradients ----
@@ -292,11 +300,6 @@ static int tr_update_bwd(const TrainCtx& x, int l, const float* ds, const float*
     TR_TRY(wg(x, dzx, HP, HP, H, HP, H, s_a, HP, HP, 0, H, HP, H, N, x.g(u + 1), 2 * H, nullptr));                        // xvec_proj.0[:, 0:H]
     TR_TRY(wg(x, dzx, HP, HP, H, HP, H, scal, HP, HP, 0, H, HP, H, N, x.g(u + 1) ? x.g(u + 1) + H : nullptr, 2 * H, nullptr));   // [:, H:2H]
     TR_TRY(wg(x, dv12, 2 * HP, 2 * HP, H, HP, 2 * H, vec_a, HP, HP, 0, H, HP, H, 3LL * N, x.g(u + 0), H, nullptr));       // vec_proj [2H][H]
-    // lin3 (Linear(3,48) SiLU Linear(48,8) SiLU Linear(8,1)); xa = (x, 1, 0, 0): column 0 of lin3.0.weight and its bias
-    TR_TRY(wg(x, x.f(x.w.l3_dz1), 48, 48, 48, 48, 48, x.f(x.w.l3_xa), 4, 4, 0, 1, 1, 1, NH, x.g(u + 3), 3, x.g(u + 4)));
-    TR_TRY(wg(x, x.f(x.w.l3_dz2), 8, 8, 8, 8, 8, x.f(x.w.l3_h1), 48, 48, 0, 48, 48, 48, NH, x.g(u + 5), 48, x.g(u + 6)));
-    colsum(x, x.f(x.w.l3_h2a), 12, 0, NH, 8, x.g(u + 7));                                                                  // lin3.4.weight [1][8]
-    colsum(x, x.f(x.w.l3_h2a) + 8, 12, 0, NH, 1, x.g(u + 8));                                                              // lin3.4.bias
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
