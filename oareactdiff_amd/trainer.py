@@ -175,7 +175,8 @@ class DDPMTrainer:
     def _fused_forward_backward(self, batch, t_int: Optional[Tensor] = None, draw=None):
         """loss terms + gradients into the bucket: oard_loss_prepare -> oard_forward_train -> oard_loss_terms -> the backward sweep
         (training.backward_sweep) fed with the closed-form d(mean nll)/d(net).  Returns (nll [B], terms [2K, B]) on the device.
-        Same noise stream as DiffusionLoss (per object: randn(n, 3) then randn(n, nf - 3))."""
+        Injected draws (`draw`) follow DiffusionLoss's protocol (per object: randn(n, 3) then randn(n, nf - 3)); the default is ONE
+        device randn for the whole step's noise (same distribution, one launch instead of nine)."""
         import ctypes as C
         from . import _capi, training
         reps, cond = batch
@@ -192,14 +193,19 @@ class DDPMTrainer:
             _capi.check(L.oard_supported(C.byref(cfg)), "oard_supported (hidden_channels/num_radial not built)")
             packed = dyn._get_packed(cfg, stream)
             topo = dyn._get_train_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
-            if draw is None:
-                def draw(shape):
-                    return torch.randn(shape, device=dev)
+            nfs = list(dyn.node_nfs)
             if t_int is None:
                 t_int = torch.randint(0, ls.T + 1, size=(B, 1), device=dev).float()
             t_int = t_int.detach().to(device=dev, dtype=torch.float32).reshape(B).contiguous()
-            nfs = list(dyn.node_nfs)
-            noise = [torch.cat([draw((int(m.numel()), 3)).float(), draw((int(m.numel()), nfs[k] - 3)).float()], dim=1) for k, m in enumerate(masks)]
+            counts = [int(m.numel()) for m in masks]
+            if draw is None:                          # ONE draw for the whole step's noise, viewed per object ([n_k, nf_k] blocks)
+                flat = torch.randn(sum(c * f for c, f in zip(counts, nfs)), device=dev)
+                noise, off = [], 0
+                for c, f in zip(counts, nfs):
+                    noise.append(flat[off: off + c * f].view(c, f))
+                    off += c * f
+            else:                                     # injected draws follow DiffusionLoss's protocol: (n, 3) then (n, nf - 3) per object
+                noise = [torch.cat([draw((c, 3)).float(), draw((c, f - 3)).float()], dim=1).contiguous() for c, f in zip(counts, nfs)]
             gamma = self._gamma_dev
             if gamma is None or gamma.device != dev:
                 gamma = self._gamma_dev = ls.schedule.gamma.to(device=dev, dtype=torch.float32).contiguous()
@@ -242,13 +248,17 @@ class DDPMTrainer:
         finally:
             dyn.nan_check = prev
         K = terms.shape[0] // 2
-        means = torch.cat([nll.mean(0, keepdim=True), terms.mean(dim=1)])          # loss, err_n[k], err_t[k]
-        bad = (~torch.isfinite(means[0])).to(torch.float32)
+        means = torch.cat([nll.unsqueeze(0), terms]).mean(dim=1)                  # loss, err_n[k], err_t[k]
+        # non-finite anywhere (loss, local gradient, the network's device-side flag) -> the bucket's last element, summed by the all-reduce
+        norm = torch.linalg.vector_norm(self.flat_grad, 2.0)
+        bad = (~torch.isfinite(norm + means[0])).to(torch.float32)
         if dyn.nan_seen is not None:
             bad = bad + (dyn.nan_seen[0] != 0).to(torch.float32)
-        self._bucket[-1] = bad + (~torch.isfinite(self.flat_grad.sum())).to(torch.float32)
-        self.all_reduce_gradients()
-        stats = torch.cat([torch.linalg.vector_norm(self.flat_grad, 2.0).reshape(1), self._bucket[-1:], means]).tolist()   # the one host sync
+        self._bucket[-1] = bad
+        if self.world > 1:
+            self.all_reduce_gradients()
+            norm = torch.linalg.vector_norm(self.flat_grad, 2.0)
+        stats = torch.cat([norm.reshape(1), self._bucket[-1:], means]).tolist()        # the one host sync
         grad_norm, flag = stats[0], stats[1]
         info: Dict[str, float] = {}
         for k in range(K):
