@@ -125,7 +125,7 @@ def pmc_traffic(kernel: str, batch: int, atoms: int, tag: str = None):
     (KiB).  Returns (bytes | None, note): None when the workload differs or when the profile was taken on other
     kernel sources than the ones running now (profiles/<tag>_source_stamp.txt vs source_stamp())."""
     import re
-    tag = tag or os.environ.get("OARD_PROFILE_TAG", "round2")
+    tag = tag or os.environ.get("OARD_PROFILE_TAG", "round3")
     if (batch, atoms) != (64, 23):
         return None, "PMC passes exist for B=64 x 23 atoms only"
     stamp_file = os.path.join(ROOT, "profiles", f"{tag}_source_stamp.txt")

@@ -235,7 +235,12 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
     xhp = (C.c_void_p * n_obj)(*[x.data_ptr() for x in st.xh])
     ds = torch.empty(N, HP, device=dev)
     dvec = torch.empty(3 * N, HP, device=dev)
-    dew = torch.zeros(E + 1, WP, device=dev)                # cotangent of the edge state, updated in place layer by layer
+    # cotangent of the edge state, updated in place layer by layer.  Nothing flows into the FINAL edge state: the last layer's kernels
+    # read the inner rows [0, A) as that zero gradient (and the spare row E for their padding columns) and never read the inter-object
+    # rows (their S3 was skipped in the forward), so only those rows are cleared - 0.27 GB instead of 0.83 GB at B = 64
+    dew = torch.empty(E + 1, WP, device=dev)
+    dew[: topo.A].zero_()
+    dew[E:].zero_()
     a = (C.byref(cfg), topo.handle, packed.data_ptr(), pbwd.data_ptr(), tape.buf.data_ptr())
     _capi.check(L.oard_train_tail_backward(*a, go, ds.data_ptr(), dvec.data_ptr(), params, grads, sc.data_ptr(), sc.numel(), stream),
                 "oard_train_tail_backward")
