@@ -1460,6 +1460,7 @@ int oard_train_tail_backward(const oard_config* c, const oard_topology* topo, co
     if (!ds || !dvec) return OARD_EINVAL;
     if (g_poison) HIP_TRY(hipMemsetAsync(scratch, 0xFF, oard_train_scratch_bytes(c, topo), (hipStream_t)stream));   // first call of a sweep
     DISPATCH_DIMS(c, rc = tr_tail_bwd<D>(x, tw, topo, grad_out, ds, dvec));
+    x.join();                   // (a small stage; its operand buffers are reused by nothing until the next sweep, but tests read its gradients right away)
     return rc;
 }
 
@@ -1469,6 +1470,7 @@ int oard_train_init_backward(const oard_config* c, const oard_topology* topo, co
     TRAIN_ENTER();
     if (!xh || !ds0 || !dew || !params) return OARD_EINVAL;
     DISPATCH_DIMS(c, rc = tr_init_bwd<D>(x, tw, topo, xh, ds0, dew));
+    x.join();                   // end of the sweep: every gradient is complete in the caller's stream order
     return rc;
 }
 
@@ -1649,6 +1651,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "npb") == 0) { g_npb = value; return OARD_OK; }
     if (strcmp(name, "wgrad_wgs") == 0) { g_wgrad_wgs = value; return OARD_OK; }
     if (strcmp(name, "wgrad_lds") == 0) { g_wgrad_lds = value; return OARD_OK; }
+    if (strcmp(name, "train_dual") == 0) { g_train_dual = value; return OARD_OK; }
     if (strcmp(name, "small_split") == 0) { g_small_split = value; return OARD_OK; }
 #ifdef OARD_PRIO_BALANCE
     if (strcmp(name, "prio_k") == 0) { HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prio_k), &value, sizeof(int))); return OARD_OK; }

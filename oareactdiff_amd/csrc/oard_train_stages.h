@@ -29,9 +29,11 @@ struct TrainWs {
     size_t gx, gs_a, gvec_a, dxq, dvec_in, dcd, dcr, dzd1, dz3, mout, dz2, dz1, da, dPQ, dagg;
     // GCL node / pre adjoint
     size_t dzq, dxln, lng, dsm, dzm, dxh, t1, t2, dhid, dzh;
-    // column sums, weight-gradient partials
+    size_t lng2, dsn;          // node_pre adjoint: its own LayerNorm product buffer, cotangent of s entering the layer (copy read by the gradient stream)
+    // column sums, weight-gradient partials (used by the gradient stream only)
     size_t csum, cpart, wg;
     size_t wg_bytes, total;
+    size_t layer_bytes;        // everything above lives twice: buffer set l & 1 for layer l (the gradient stream of layer l runs beside the cotangent chain of layer l - 1)
 };
 static TrainWs make_train_ws(const oard_config* c, const TopoDev& td) {
     const RDims d(c->hidden, c->num_radial);
@@ -53,6 +55,9 @@ static TrainWs make_train_ws(const oard_config* c, const TopoDev& td) {
     w.dPQ = take(2 * N * HP * F); w.dagg = take(N * HP * F);
     w.dzq = take(N * HP * F); w.dxln = take(N * HP * F); w.lng = take(N * HP * F); w.dsm = take(N * HP * F); w.dzm = take(N * HP * F);
     w.dxh = take(N * HP * F); w.t1 = take(N * HP * F); w.t2 = take(N * HP * F); w.dhid = take(N * d.PP * F); w.dzh = take(N * d.PP * F);
+    w.lng2 = take(N * HP * F); w.dsn = take(N * HP * F);
+    w.layer_bytes = cur;
+    cur = 2 * w.layer_bytes;
     w.csum = take(4096 * F);
     w.cpart = take(std::max((size_t)cdiv(std::max<size_t>(E, 3 * N), CS_ROWS) * std::max<size_t>(d.WP, 1024),
                             (size_t)cdiv(N * HP, CS_ROWS) * 16) * F);
@@ -75,6 +80,34 @@ static TrainWs make_train_ws(const oard_config* c, const TopoDev& td) {
     return w;
 }
 
+// ---- the two streams of the sweep -------------------------------------------------------------------------------------------------------
+// The cotangent chain (dX kernels) is a sequence of dependent launches, many of them small (276 workgroups of 16 nodes); the weight
+// gradients (GEMMs over the rows, reduces, column sums) only CONSUME what the chain leaves behind.  They run on a second stream, forked
+// by an event after each stage: a layer's weight-gradient GEMMs fill the chip while the next layer's node-side adjoints trickle through.
+// The per-layer scratch exists twice (buffer set = layer & 1) and the chain waits for layer l + 2's gradients before it starts layer l.
+struct TrainStreams {
+    hipStream_t w = nullptr;
+    hipEvent_t pool[32];
+    hipEvent_t layer_done[OARD_MAX_LAYERS + 1];
+    unsigned next = 0;
+    bool ok = false, tried = false;
+};
+int g_train_dual = 1;           // oard_debug_option("train_dual", 0): everything on the caller's stream
+static TrainStreams& train_streams() {
+    static TrainStreams all[64];
+    int d = 0;
+    (void)hipGetDevice(&d);
+    TrainStreams& t = all[d & 63];
+    if (!t.tried) {
+        t.tried = true;
+        bool ok = hipStreamCreateWithFlags(&t.w, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 32; ++i) ok = hipEventCreateWithFlags(&t.pool[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i <= OARD_MAX_LAYERS; ++i) ok = hipEventCreateWithFlags(&t.layer_done[i], hipEventDisableTiming) == hipSuccess;
+        t.ok = ok;
+    }
+    return t;
+}
+
 // ---- context of one sweep ------------------------------------------------------------------------------------------------------------
 struct TrainCtx {
     const oard_config* c;
@@ -91,13 +124,40 @@ struct TrainCtx {
     const float* const* params; // the module's parameters, canonical order (raw nn.Linear layouts), or nullptr
     float* const* grads;        // canonical parameter order; nullptr entries are skipped
     ParamIdx pi;
-    hipStream_t st;
+    hipStream_t st;             // the cotangent chain (the caller's stream)
+    hipStream_t stw;            // weight gradients: reduces, column sums, weight-gradient GEMMs (== st when the split is off)
+    int par = 0;                // buffer set of the per-layer scratch (layer & 1)
     TrainCtx(const oard_config* c_, const TopoDev* tp_, const void* packed, const void* packed_bwd, const void* tape_, void* ws_,
              const float* const* params_, float* const* grads_, hipStream_t st_)
         : c(c_), tp(tp_), wb((const float*)packed), po(make_layout(c_)), pb((const float*)packed_bwd), bo(make_bwd_layout(c_)),
           nb(make_node_bwd_layout(c_, bo.total)), tape((const char*)tape_), to(make_tape(c_, *tp_)), ws((char*)ws_),
-          w(make_train_ws(c_, *tp_)), params(params_), grads(grads_), pi(c_), st(st_) {}
-    float* f(size_t off) const { return (float*)(ws + off); }
+          w(make_train_ws(c_, *tp_)), params(params_), grads(grads_), pi(c_), st(st_), stw(st_) {
+        TrainStreams& ts = train_streams();
+        if (g_train_dual && ts.ok) stw = ts.w;
+    }
+    bool dual() const { return stw != st; }
+    // the gradient stream may start on what the chain has enqueued so far
+    void fork() const {
+        if (!dual()) return;
+        TrainStreams& ts = train_streams();
+        hipEvent_t e = ts.pool[ts.next++ & 31];
+        (void)hipEventRecord(e, st);
+        (void)hipStreamWaitEvent(stw, e, 0);
+    }
+    // the chain waits for everything the gradient stream has been given
+    void join() const {
+        if (!dual()) return;
+        TrainStreams& ts = train_streams();
+        hipEvent_t e = ts.pool[ts.next++ & 31];
+        (void)hipEventRecord(e, stw);
+        (void)hipStreamWaitEvent(st, e, 0);
+    }
+    // layer l's gradient work is complete on the device when ts.layer_done[l] has fired; the chain may not start writing buffer
+    // set l & 1 again (layer l - 2) before that
+    void layer_done(int l) const { if (dual()) (void)hipEventRecord(train_streams().layer_done[l], stw); }
+    void wait_layer(int l) const { if (dual() && l < c->num_layers) (void)hipStreamWaitEvent(st, train_streams().layer_done[l], 0); }
+    TrainCtx on_grad_stream() const { TrainCtx y = *this; y.st = stw; return y; }        // element-wise / dense kernels that only serve a gradient
+    float* f(size_t off) const { return (float*)(ws + off + (off < w.layer_bytes ? (size_t)par * w.layer_bytes : 0)); }
     const float* t(size_t off) const { return (const float*)(tape + off); }
     float* g(int idx) const { return grads ? grads[idx] : nullptr; }
 };
@@ -122,28 +182,28 @@ static void rows_dense(const TrainCtx& x, long long rows, const float* X, int ld
 static void colsum(const TrainCtx& x, const float* X, int ld, long long r0, long long r1, int ncols, float* out, int accumulate = 1,
                    const float* wrow = nullptr, int x_silu = 0, float scale = 1.0f) {
     if (out == nullptr || ncols <= 0) return;
-    ScopedLaunch sl_(F_WGRAD, x.st);
+    ScopedLaunch sl_(F_WGRAD, x.stw);
     float* part = x.f(x.w.cpart);
     if (ncols <= 16 && !x_silu && r1 - r0 > 4 * CS_ROWS) {            // narrow and long: one thread per row slice
         const int nchn = (int)cdiv(r1 - r0, CSN_ROWS);
-        hipLaunchKernelGGL(k_colsum_narrow, dim3((unsigned)nchn), dim3(256), 0, x.st, X, ld, r0, r1, ncols, wrow, part);
-        hipLaunchKernelGGL(k_colsum_fin, dim3((unsigned)cdiv(ncols, 4)), dim3(256), 0, x.st, (const float*)part, nchn, ncols, out, accumulate, scale);
+        hipLaunchKernelGGL(k_colsum_narrow, dim3((unsigned)nchn), dim3(256), 0, x.stw, X, ld, r0, r1, ncols, wrow, part);
+        hipLaunchKernelGGL(k_colsum_fin, dim3((unsigned)cdiv(ncols, 4)), dim3(256), 0, x.stw, (const float*)part, nchn, ncols, out, accumulate, scale);
         return;
     }
     const int nch = (int)std::max<long long>(1, cdiv(std::max<long long>(r1 - r0, 0), CS_ROWS));
     if (r1 > r0)
-        hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)nch, (unsigned)cdiv(ncols, 256)), dim3(256), 0, x.st, X, ld, r0, r1, ncols, wrow,
+        hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)nch, (unsigned)cdiv(ncols, 256)), dim3(256), 0, x.stw, X, ld, r0, r1, ncols, wrow,
                            x_silu, part);
     else
-        (void)hipMemsetAsync(part, 0, (size_t)ncols * sizeof(float), x.st);
-    hipLaunchKernelGGL(k_colsum_fin, dim3((unsigned)cdiv(ncols, 4)), dim3(256), 0, x.st, (const float*)part, nch, ncols, out, accumulate, scale);
+        (void)hipMemsetAsync(part, 0, (size_t)ncols * sizeof(float), x.stw);
+    hipLaunchKernelGGL(k_colsum_fin, dim3((unsigned)cdiv(ncols, 4)), dim3(256), 0, x.stw, (const float*)part, nch, ncols, out, accumulate, scale);
 }
 // weight / bias gradient of one nn.Linear, accumulated into the table entries (skipped when the table has no entry)
 static int wg(const TrainCtx& x, const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, const float* X, int ldX, int ncX,
               int x_silu, int i_len, int i_pad, int MI, long long rows, float* dW, int ldW, float* db) {
     if ((dW == nullptr && db == nullptr) || rows <= 0) return OARD_OK;
     return wgrad_impl(dY, ldY, ncY, o_len, o_pad, MO, X, ldX, ncX, x_silu, i_len, i_pad, MI, rows, dW, ldW, db, 1, x.f(x.w.wg), x.w.wg_bytes,
-                      x.st);
+                      x.stw);
 }
 #define TR_TRY(expr) do { int rc__ = (expr); if (rc__ != OARD_OK) return rc__; } while (0)
 
@@ -291,11 +351,13 @@ static int tr_update_bwd(const TrainCtx& x, int l, const float* ds, const float*
       if (!l3_attr[dv_]) { TR_TRY(set_lds(k_lin3u_bwd_fused<L3_WAVES>, l3_lds)); l3_attr[dv_] = true; }
       hipLaunchKernelGGL((k_lin3u_bwd_fused<L3_WAVES>), dim3(L3_BLOCKS), dim3(L3_WAVES * 64), l3_lds, x.st, x.wb + lo.l3u, (const float*)sc,
                          (const float*)dscal, NH, dsc, x.f(x.w.l3_h1));
-      hipLaunchKernelGGL(k_lin3u_reduce, dim3((unsigned)cdiv(497, 4)), dim3(256), 0, x.st, (const float*)x.f(x.w.l3_h1), L3_BLOCKS * L3_WAVES,
-                         x.g(u + 3), x.g(u + 4), x.g(u + 5), x.g(u + 6), x.g(u + 7), x.g(u + 8));
       hipLaunchKernelGGL(k_upd_dv1, EW_GRID(NH), 0, x.st, (const float*)dsc, x1, N, HP, dv12); }
     rows_dense<2 * HT, EPI_ADD>(x, 3LL * N, dv12, 2 * HP, x.pb + nl.vpT, HT, gvec_a, HP, nullptr, nullptr, 0, 2 * HT, dvec, HP);
-    // ---- parameter gradients ----
+    // ---- parameter gradients (gradient stream) ----
+    x.fork();
+    { ScopedLaunch sl_(F_WGRAD, x.stw);
+      hipLaunchKernelGGL(k_lin3u_reduce, dim3((unsigned)cdiv(497, 4)), dim3(256), 0, x.stw, (const float*)x.f(x.w.l3_h1), L3_BLOCKS * L3_WAVES,
+                         x.g(u + 3), x.g(u + 4), x.g(u + 5), x.g(u + 6), x.g(u + 7), x.g(u + 8)); }
     TR_TRY(wg(x, dabc, 3 * HP, 3 * HP, H, HP, 3 * H, hx, HP, HP, 0, H, HP, H, N, x.g(u + 2), H, nullptr));               // xvec_proj.2 [3H][H]
     TR_TRY(wg(x, dzx, HP, HP, H, HP, H, s_a, HP, HP, 0, H, HP, H, N, x.g(u + 1), 2 * H, nullptr));                        // xvec_proj.0[:, 0:H]
     TR_TRY(wg(x, dzx, HP, HP, H, HP, H, scal, HP, HP, 0, H, HP, H, N, x.g(u + 1) ? x.g(u + 1) + H : nullptr, 2 * H, nullptr));   // [:, H:2H]
@@ -322,6 +384,7 @@ static int tr_msg_bwd(const TrainCtx& x, int l, const float* gs_a, const float* 
     LAUNCH(F_NODE, (k_equi_msg_bwd<D>), N, 256, x.st, tp, x.t(x.to.geo), xq3, vec3, x.t(x.to.cd[l]), cr3, (const float*)gx, HP, gv3,
            x.f(x.w.dcd), x.f(x.w.dcr), dxq, dvec_in, HP);
     const int m = x.pi.msg0 + 9 * l;
+    x.fork();
     TR_TRY(wg(x, x.f(x.w.dcr), 3 * HP, 3 * HP, H, HP, 3 * H, x.t(x.to.rbuf), D::RP, D::RP, 0, D::R, D::R, D::R, tp.A, x.g(m + 6), D::R, nullptr));
     HIP_TRY(hipGetLastError());
     return OARD_OK;
@@ -346,11 +409,12 @@ static int tr_gcl_node_bwd(const TrainCtx& x, int l, const float* gx, const floa
     { ScopedLaunch sl_(F_NODE, x.st);                         // d s_mid = gx + LN_msg^T dxln
       hipLaunchKernelGGL(k_rows_ln_bwd, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, x.st, s_mid, HP, H, HP, x.wb + lo.ln_q_w, (const float*)dxln,
                          gx, dsm, lng, (long long)N); }
-    colsum(x, lng, HP, 0, N, H, x.g(m + 7));                  // message_layers.l.x_layernorm.weight
-    colsum(x, dxln, HP, 0, N, H, x.g(m + 8));                 // .bias
     rows_dense<HT, EPI_MUL_DSILU>(x, N, dsm, HP, x.pb + nl.nm1T, HT, dzm, HP, nullptr, nullptr, 0, HT, x.f(x.w.zm), HP);
     rows_dense<HT, EPI_ADD>(x, N, dzm, HP, x.pb + nl.nm0T, HT, dxh, HP, nullptr, nullptr, 0, HT, dsm, HP);      // residual path + xh half
     rows_dense<HT>(x, N, dzm, HP, x.pb + nl.nm0T + (size_t)HT * HT * 256, HT, dagg, HP);                         // agg half
+    x.fork();
+    colsum(x, lng, HP, 0, N, H, x.g(m + 7));                  // message_layers.l.x_layernorm.weight
+    colsum(x, dxln, HP, 0, N, H, x.g(m + 8));                 // .bias
     TR_TRY(wg(x, dxq, 3 * HP, 3 * HP, H, HP, 3 * H, x.f(x.w.hq), HP, HP, 0, H, HP, H, N, x.g(m + 5), H, nullptr));             // x_proj.2 [3H][H]
     TR_TRY(wg(x, dzq, HP, HP, H, HP, H, x.f(x.w.xln), HP, HP, 0, H, HP, H, N, x.g(m + 4), H, nullptr));                        // x_proj.0
     TR_TRY(wg(x, dsm, HP, HP, H, HP, H, x.f(x.w.hm), HP, HP, 0, H, HP, H, N, x.g(g + 6), H, x.g(g + 7)));                      // node_mlp.1
@@ -371,6 +435,7 @@ static int tr_equi_edge_bwd(const TrainCtx& x, int l, float* dew) {
     const int H = D::H, HP = D::HP, W = D::W;
     const int m = x.pi.msg0 + 9 * l;
     TR_TRY(equi_backward_impl<D>(tp, x.pb + x.bo.layer[l].equi, x.f(x.w.dcd), x.t(x.to.zd1[l]), dew, x.f(x.w.dzd1), x.st));
+    x.fork();
     TR_TRY(wg(x, x.f(x.w.dcd), 3 * HP, 3 * HP, H, HP, 3 * H, x.t(x.to.zd1[l]), D::D1P, D::D1P, 1, 3 * H, 3 * H, 3 * H, tp.A, x.g(m + 2), 3 * H,
               x.g(m + 3)));                                                                                       // dir_proj.2
     TR_TRY(wg(x, x.f(x.w.dzd1), D::D1P, D::D1P, 3 * H, 3 * H, 3 * H, x.t(x.to.ew[l + 1]), D::WP, D::WP, 0, W, W, W, tp.A, x.g(m + 0), W,
@@ -391,6 +456,7 @@ static int tr_gcl_edge_bwd(const TrainCtx& x, int l, const float* dagg, float* d
     float *dz3 = x.f(x.w.dz3), *mout = x.f(x.w.mout), *dz2 = x.f(x.w.dz2), *dz1 = x.f(x.w.dz1), *da = x.f(x.w.da);
     TR_TRY(gcl_backward_impl<D>(x.c, tp, x.pb, x.bo.layer[l], l, x.tape, x.to, dagg, dew, dz3, mout, dz2, da, dz1, x.st));
     LAUNCH(F_GCL_BWD, k_edge_node_sums, N, 64, x.st, tp, (const float*)dz1, HP, dP, dQ);
+    x.fork();
     const long long rows3 = l == NL - 1 ? A : E;          // rows whose forward evaluated edge_out_trans
     TR_TRY(wg(x, dz3, WP, WP, W, W, W, mout, HP, HP, 0, H, H, H, rows3, x.g(g + 8), H, x.g(g + 9)));                               // edge_out_trans
     TR_TRY(wg(x, dz2, HP, HP, H, H, H, x.t(x.to.z1[l]), HP, HP, 1, H, H, H, E, x.g(g + 2), H, x.g(g + 3)));                         // edge_mlp.1
@@ -399,8 +465,8 @@ static int tr_gcl_edge_bwd(const TrainCtx& x, int l, const float* dagg, float* d
     TR_TRY(wg(x, dz1, HP, HP, H, H, H, x.t(x.to.ew[l]), WP, WP, 0, W, W, W, rows1, w1c, 2 * H + W, nullptr));                       // edge_mlp.0[:, 2H:]
     if (l == 0 && E > A && w1c != nullptr) {              // ... whose contribution is outer(sum_e dz1_e, c0row)
         colsum(x, dz1, HP, A, E, H, x.f(x.w.csum), 0);
-        ScopedLaunch sl_(F_WGRAD, x.st);
-        hipLaunchKernelGGL(k_outer_acc, EW_GRID((long long)H * W), 0, x.st, w1c, 2 * H + W, (const float*)x.f(x.w.csum), H, x.wb + x.po.c0row, W, 1);
+        ScopedLaunch sl_(F_WGRAD, x.stw);
+        hipLaunchKernelGGL(k_outer_acc, EW_GRID((long long)H * W), 0, x.stw, w1c, 2 * H + W, (const float*)x.f(x.w.csum), H, x.wb + x.po.c0row, W, 1);
     }
     colsum(x, x.t(x.to.z2[l]), HP, 0, E, H, x.g(g + 10), 1, da, 1);      // att_mlp weight: sum_e da_e SiLU(z2_e)
     colsum(x, da, 1, 0, E, 1, x.g(g + 11));                               // att_mlp bias
@@ -420,26 +486,30 @@ static int tr_pre_bwd(const TrainCtx& x, int l, const float* dxh, const float* d
     const int N = tp.N, HP = D::HP, H = D::H, HT = D::HT, W = D::W;
     const int g = x.pi.gcl0 + 14 * l;
     const float* xh = x.f(x.w.xh);
-    float *t1 = x.f(x.w.t1), *t2 = x.f(x.w.t2), *lng = x.f(x.w.lng), *dhid = x.f(x.w.dhid), *dzh = x.f(x.w.dzh);
+    float *t1 = x.f(x.w.t1), *t2 = x.f(x.w.t2), *lng = x.f(x.w.lng2), *dsn = x.f(x.w.dsn), *dhid = x.f(x.w.dhid), *dzh = x.f(x.w.dzh);
     rows_dense<HT, EPI_ADD>(x, N, dP, HP, x.pb + nl.W1aT, HT, t1, HP, nullptr, nullptr, 0, HT, dxh, HP);
     rows_dense<HT, EPI_ADD>(x, N, dQ, HP, x.pb + nl.W1bT, HT, t2, HP, nullptr, nullptr, 0, HT, t1, HP);
-    { ScopedLaunch sl_(F_NODE, x.st);
+    { ScopedLaunch sl_(F_NODE, x.st);                         // the layer's buffer set keeps ds (the gradient stream reads it while the chain moves on)
       hipLaunchKernelGGL(k_rows_ln_bwd, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, x.st, (const float*)x.f(x.w.s1), HP, H, HP, x.wb + lo.ln_g_w,
-                         (const float*)t2, (const float*)nullptr, ds_in, lng, (long long)N); }
+                         (const float*)t2, (const float*)nullptr, dsn, lng, (long long)N); }
+    HIP_TRY(hipMemcpyAsync(ds_in, dsn, (size_t)N * HP * sizeof(float), hipMemcpyDeviceToDevice, x.st));
+    // ---- parameter gradients (gradient stream) ----
+    x.fork();
     colsum(x, lng, HP, 0, N, H, x.g(g + 12));                 // gcl_layers.l.x_layernorm.weight
     colsum(x, t2, HP, 0, N, H, x.g(g + 13));                  // .bias
     TR_TRY(wg(x, dP, HP, HP, H, HP, H, xh, HP, HP, 0, H, HP, H, N, x.g(g + 0), 2 * H + W, x.g(g + 1)));                      // edge_mlp.0[:, 0:H], bias
     TR_TRY(wg(x, dQ, HP, HP, H, HP, H, xh, HP, HP, 0, H, HP, H, N, x.g(g + 0) ? x.g(g + 0) + H : nullptr, 2 * H + W, nullptr));   // [:, H:2H]
-    // pos_expansion (shared by all layers: its gradient accumulates over l)
+    // pos_expansion (shared by all layers: its gradient accumulates over l); nothing downstream needs its input cotangent
     if (x.g(x.pi.pe0_w) != nullptr || x.g(x.pi.pe1_w) != nullptr) {
-        rows_dense<HT>(x, N, ds_in, HP, x.pb + x.nb.pe1T, D::PB, dhid, D::PP);
-        { ScopedLaunch sl_(F_NODE, x.st);
-          hipLaunchKernelGGL(k_pe_dz, EW_GRID((long long)N * D::PP), 0, x.st, x.wb + x.po.pe0, x.t(x.to.pp0), N, D::H2, D::PP, (const float*)dhid, dzh); }
-        TR_TRY(wg(x, ds_in, HP, HP, H, HP, H, x.f(x.w.hid), D::PP, D::PP, 0, D::H2, D::PP, D::H2, N, x.g(x.pi.pe1_w), D::H2, nullptr));
+        const TrainCtx y = x.on_grad_stream();
+        rows_dense<HT>(y, N, dsn, HP, x.pb + x.nb.pe1T, D::PB, dhid, D::PP);
+        { ScopedLaunch sl_(F_NODE, x.stw);
+          hipLaunchKernelGGL(k_pe_dz, EW_GRID((long long)N * D::PP), 0, x.stw, x.wb + x.po.pe0, x.t(x.to.pp0), N, D::H2, D::PP, (const float*)dhid, dzh); }
+        TR_TRY(wg(x, dsn, HP, HP, H, HP, H, x.f(x.w.hid), D::PP, D::PP, 0, D::H2, D::PP, D::H2, N, x.g(x.pi.pe1_w), D::H2, nullptr));
         if (x.g(x.pi.pe0_w) != nullptr) {                     // mlp.0.weight [H/2][3]: only column 0 sees a non-zero input
             colsum(x, dzh, D::PP, 0, N, D::H2, x.f(x.w.csum), 0, x.t(x.to.pp0));
-            ScopedLaunch sl_(F_WGRAD, x.st);
-            hipLaunchKernelGGL(k_strided_acc, EW_GRID(D::H2), 0, x.st, (const float*)x.f(x.w.csum), D::H2, x.g(x.pi.pe0_w), 3);
+            ScopedLaunch sl_(F_WGRAD, x.stw);
+            hipLaunchKernelGGL(k_strided_acc, EW_GRID(D::H2), 0, x.stw, (const float*)x.f(x.w.csum), D::H2, x.g(x.pi.pe0_w), 3);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -451,7 +521,10 @@ static int tr_pre_bwd(const TrainCtx& x, int l, const float* dxh, const float* d
 // in = cotangent of the edge state leaving the layer, out = entering it.
 // =====================================================================================================================================
 template <class D>
-static int tr_layer_bwd(const TrainCtx& x, int l, float* ds, float* dvec, float* dew) {
+static int tr_layer_bwd(const TrainCtx& x0, int l, float* ds, float* dvec, float* dew) {
+    TrainCtx x = x0;
+    x.par = l & 1;                                            // buffer set of this layer
+    x.wait_layer(l + 2);                                      // ... which layer l + 2's gradients may still be reading
     float *gs_a = x.f(x.w.gs_a), *gvec_a = x.f(x.w.gvec_a), *gx = x.f(x.w.gx), *dxq = x.f(x.w.dxq), *dxh = x.f(x.w.dxh), *dagg = x.f(x.w.dagg);
     float* dP = x.f(x.w.dPQ);
     float* dQ = dP + (size_t)x.tp->N * D::HP;
@@ -462,6 +535,7 @@ static int tr_layer_bwd(const TrainCtx& x, int l, float* ds, float* dvec, float*
     TR_TRY(tr_equi_edge_bwd<D>(x, l, dew));
     TR_TRY(tr_gcl_edge_bwd<D>(x, l, dagg, dew, dP, dQ));
     TR_TRY(tr_pre_bwd<D>(x, l, dxh, dP, dQ, ds));
+    x.layer_done(l);
     return OARD_OK;
 }
 
@@ -572,7 +646,7 @@ __global__ void k_out_du(const float* __restrict__ dv1, const float* __restrict_
 }
 
 struct TrainTail {          // extra scratch of the tail / init stages (after TrainWs.total)
-    size_t u, v1, v2s, zu, hu, xg, hout, dxg, dhout, dv2s, dgate, dzu, dv1, du, zadd, op_dy, op_hid, op_dz, op_x;
+    size_t u, v1, v2s, zu, hu, xg, hout, dxg, dhout, dv2s, dgate, dzu, dv1, du, zadd, op_dy, op_hid, op_dz, op_x, eo_dy, eo_hid, eo_dz, eo_x;
     size_t ynb, nbe, ys, lns, s1v, ne1, dne1, part, zrl, hrl, df, ds1v, dlns, dys, ds0, segS, segG, segSn, segGn, dnbe, ipro, dynb, dhin, dfr,
         dzrl, dc0;
     size_t total;
@@ -588,6 +662,7 @@ static TrainTail make_train_tail(const oard_config* c, const TopoDev& td, size_t
     w.xg = take(N * 16 * F); w.hout = take(N * 16 * F); w.dxg = take(N * 16 * F); w.dhout = take(N * 16 * F); w.dv2s = take(N * 4 * F);
     w.dgate = take(N * F); w.dzu = take(N * HP * F); w.dv1 = take(N * HP * F); w.du = take(3 * N * HP * F); w.zadd = take(3 * N * HP * F);
     w.op_dy = take(N * 16 * F); w.op_hid = take(N * 32 * F); w.op_dz = take(N * 32 * F); w.op_x = take(N * 16 * F);
+    w.eo_dy = take(N * 16 * F); w.eo_hid = take(N * 32 * F); w.eo_dz = take(N * 32 * F); w.eo_x = take(N * 16 * F);     // encoders (the decoders' gradients may still be read)
     w.ynb = take(N * HP * F); w.nbe = take(N * HP * F); w.ys = take(N * HP * F); w.lns = take(N * HP * F); w.s1v = take(N * HP * F);
     w.ne1 = take(3 * N * HP * F); w.dne1 = take(3 * N * HP * F); w.part = take(N * (5 * d.H4 + 1) * F);
     w.zrl = take(A * HP * F); w.hrl = take(A * HP * F); w.df = take(A * HP * F); w.ds1v = take(N * HP * F); w.dlns = take(N * HP * F);
@@ -628,7 +703,8 @@ static int tr_tail_bwd(const TrainCtx& x, const TrainTail& tw, const oard_topolo
       hipLaunchKernelGGL(k_out_du, EW_GRID((long long)N * HP), 0, x.st, (const float*)dv1, (const float*)v1, (const float*)u, (const float*)dv2s,
                          x.wb + x.po.v2p, N, HP, du, zadd); }
     rows_dense<HT, EPI_ADD>(x, 3LL * N, du, HP, x.pb + x.nb.v1pT, HT, dvec, HP, nullptr, nullptr, 0, HT, zadd, HP);
-    // ---- parameter gradients ----
+    // ---- parameter gradients (gradient stream) ----
+    x.fork();
     TR_TRY(wg(x, du, HP, HP, H, HP, H, vec_L, HP, HP, 0, H, HP, H, 3LL * N, x.g(o + 0), H, nullptr));                      // vec1_proj
     colsum(x, vec_L, HP, 0, 3LL * N, H, x.g(o + 1), 1, dv2s);                                                               // vec2_proj [1][H]
     TR_TRY(wg(x, dzu, HP, HP, H, HP, H, s_L, HP, HP, 0, H, HP, H, N, x.g(o + 2), 2 * H, x.g(o + 3)));                       // update_net.0[:, 0:H], bias
@@ -834,13 +910,8 @@ static int tr_init_bwd(const TrainCtx& x, const TrainTail& tw, const oard_topolo
         constexpr int NW = D::HT < 13 ? D::HT : 13;
         LAUNCH(F_INIT, (k_s2v_agg_v1<D, NW>), cdiv(N, 16), NW * 64, x.st, tp16, (const float*)s1v, ew0, geo, ne1);
         rows_dense<D::RB, EPI_SILU>(x, A, rbf, D::RP, x.wb + x.po.rl0, HT, hrl, HP, x.wb + x.po.rl0_b, nullptr, 0, D::RB, nullptr, 0, zrl, HP);
-        // ---- edge scalarisation + lin3 (k_scalarize_bwd): d NE1 and the lin3 gradients ----
+        // ---- edge scalarisation + lin3 (k_scalarize_bwd): d NE1 and the lin3 gradients (per-node partials) ----
         TR_TRY(scalarize_backward_impl<D>(x.c, tp, x.wb, x.tape, x.to, ne1, HP, dew, dne1, part, x.st));
-        const int H4 = D::H4;
-        colsum(x, part, 5 * H4 + 1, 0, N, 3 * H4, x.g(x.pi.lin30_w));
-        colsum(x, part + 3 * H4, 5 * H4 + 1, 0, N, H4, x.g(x.pi.lin30_b));
-        colsum(x, part + 4 * H4, 5 * H4 + 1, 0, N, H4, x.g(x.pi.lin32_w));
-        colsum(x, part + 5 * H4, 5 * H4 + 1, 0, N, 1, x.g(x.pi.lin32_b));
         LAUNCH(F_INIT, (k_s2v_bwd<D>), N, 256, x.st, tp, geo, ew0, (const float*)s1v, (const float*)dne1, dew, df, ds1v);
     } else {
         HIP_TRY(hipMemsetAsync(ds1v, 0, (size_t)NH * sizeof(float), x.st));
@@ -851,7 +922,6 @@ static int tr_init_bwd(const TrainCtx& x, const TrainTail& tw, const oard_topolo
       hipLaunchKernelGGL(k_rows_ln_bwd, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, x.st, (const float*)ys, HP, H, HP, (const float*)nullptr,
                          (const float*)dlns, (const float*)nullptr, dys, (float*)nullptr, (long long)N); }
     rows_dense<HT, EPI_ADD>(x, N, dys, HP, x.pb + x.nb.s2vT, HT, ds0, HP, nullptr, nullptr, 0, HT, ds0_in, HP);
-    TR_TRY(wg(x, dys, HP, HP, H, HP, H, s0, HP, HP, 0, H, HP, H, N, x.g(x.pi.s2v_w), H, x.g(x.pi.s2v_b)));
     // NeighborEmb adjoint
     LAUNCH(F_INIT, k_seg_sums, tp.B, 256, x.st, tp, (const float*)ds0, HP, x.f(tw.segS), x.f(tw.segG));
     LAUNCH(F_INIT, k_seg_sums, tp.B, 256, x.st, tp, (const float*)nbe, HP, x.f(tw.segSn), x.f(tw.segGn));
@@ -860,8 +930,6 @@ static int tr_init_bwd(const TrainCtx& x, const TrainTail& tw, const oard_topolo
     { ScopedLaunch sl_(F_INIT, x.st);
       hipLaunchKernelGGL(k_rows_ln_bwd, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, x.st, (const float*)ynb, HP, H, HP, (const float*)nullptr,
                          (const float*)dnbe, (const float*)nullptr, dynb, (float*)nullptr, (long long)N); }
-    TR_TRY(wg(x, dynb, HP, HP, H, HP, H, hin, 16, 16, 0, C, 16, C, N, x.g(x.pi.nbemb_w), C, x.g(x.pi.nbemb_b)));
-    TR_TRY(wg(x, ds0, HP, HP, H, HP, H, hin, 16, 16, 0, C, 16, C, N, x.g(x.pi.emb_w), C, x.g(x.pi.emb_b)));            // z_emb = embedding(hin)  :744
     // d hin = embedding^T ds0 + neighbor_emb.embedding^T dynb  (only the encoder columns [0, emb) are used)
     rows_dense<HT>(x, N, ds0, HP, x.pb + x.nb.embT, 1, dhin, 16);
     rows_dense<HT, EPI_ADD>(x, N, dynb, HP, x.pb + x.nb.nbembT, 1, dhin, 16, nullptr, nullptr, 0, HT, dhin, 16);
@@ -870,30 +938,42 @@ static int tr_init_bwd(const TrainCtx& x, const TrainTail& tw, const oard_topolo
         { ScopedLaunch sl_(F_INIT, x.st);
           hipLaunchKernelGGL(k_scale_by_env, EW_GRID(A * HP), 0, x.st, (const float*)df, geo, A, HP, dfr); }
         rows_dense<HT, EPI_MUL_DSILU>(x, A, dfr, HP, x.pb + x.nb.rl2T, HT, dzrl, HP, nullptr, nullptr, 0, HT, zrl, HP);
-        TR_TRY(wg(x, dfr, HP, HP, H, HP, H, hrl, HP, HP, 0, H, HP, H, A, x.g(x.pi.rl2_w), H, x.g(x.pi.rl2_b)));
-        TR_TRY(wg(x, dzrl, HP, HP, H, HP, H, rbf, D::RP, D::RP, 0, D::R, D::RP, D::R, A, x.g(x.pi.rl0_w), D::R, x.g(x.pi.rl0_b)));
     }
-    // the constant row of the inter-object edges
-    colsum(x, dew, WP, A, E, W, dc0, 0);
-    colsum(x, ipro, HP, 0, N, H, x.f(x.w.csum), 0);
-    if (H > 256 || x.params == nullptr) return OARD_EINVAL;
-    LAUNCH(F_INIT, k_c0_bwd, 1, 256, x.st, (const float*)dc0, (const float*)x.f(x.w.csum), H, D::H4, x.params[x.pi.lin30_b],
-           x.params[x.pi.lin32_w], x.params[x.pi.rl0_b], x.params[x.pi.rl2_w], x.g(x.pi.lin30_b), x.g(x.pi.lin32_w), x.g(x.pi.lin32_b),
-           x.g(x.pi.rl0_b), x.g(x.pi.rl2_w), x.g(x.pi.rl2_b));
-    // encoders
+    // encoders: per-node adjoint, operands of the weight gradients in reference row order
     TailPtrs tl;
     memset(&tl, 0, sizeof(tl));
     XhPtrs xp;
     memset(&xp, 0, sizeof(xp));
     for (int k = 0; k < x.c->n_obj; ++k) { tl.node_nf[k] = x.c->node_nf[k]; tl.dec[k] = x.po.dec[k]; tl.enc[k] = x.po.enc[k]; xp.p[k] = xh[k]; }
-    LAUNCH(F_INIT, k_prep_bwd, cdiv(N, 128), 128, x.st, tp, tl, xp, x.wb, (const float*)dhin, emb, x.f(tw.op_dy), x.f(tw.op_hid), x.f(tw.op_dz),
-           x.f(tw.op_x));
+    LAUNCH(F_INIT, k_prep_bwd, cdiv(N, 128), 128, x.st, tp, tl, xp, x.wb, (const float*)dhin, emb, x.f(tw.eo_dy), x.f(tw.eo_hid), x.f(tw.eo_dz),
+           x.f(tw.eo_x));
+    // ---- parameter gradients (gradient stream) ----
+    x.fork();
+    if (A > 0) {
+        const int H4 = D::H4;
+        colsum(x, part, 5 * H4 + 1, 0, N, 3 * H4, x.g(x.pi.lin30_w));
+        colsum(x, part + 3 * H4, 5 * H4 + 1, 0, N, H4, x.g(x.pi.lin30_b));
+        colsum(x, part + 4 * H4, 5 * H4 + 1, 0, N, H4, x.g(x.pi.lin32_w));
+        colsum(x, part + 5 * H4, 5 * H4 + 1, 0, N, 1, x.g(x.pi.lin32_b));
+        TR_TRY(wg(x, dfr, HP, HP, H, HP, H, hrl, HP, HP, 0, H, HP, H, A, x.g(x.pi.rl2_w), H, x.g(x.pi.rl2_b)));
+        TR_TRY(wg(x, dzrl, HP, HP, H, HP, H, rbf, D::RP, D::RP, 0, D::R, D::RP, D::R, A, x.g(x.pi.rl0_w), D::R, x.g(x.pi.rl0_b)));
+    }
+    TR_TRY(wg(x, dys, HP, HP, H, HP, H, s0, HP, HP, 0, H, HP, H, N, x.g(x.pi.s2v_w), H, x.g(x.pi.s2v_b)));
+    TR_TRY(wg(x, dynb, HP, HP, H, HP, H, hin, 16, 16, 0, C, 16, C, N, x.g(x.pi.nbemb_w), C, x.g(x.pi.nbemb_b)));
+    TR_TRY(wg(x, ds0, HP, HP, H, HP, H, hin, 16, 16, 0, C, 16, C, N, x.g(x.pi.emb_w), C, x.g(x.pi.emb_b)));            // z_emb = embedding(hin)  :744
+    // the constant row of the inter-object edges
+    colsum(x, dew, WP, A, E, W, dc0, 0);
+    colsum(x, ipro, HP, 0, N, H, x.f(x.w.csum), 0);
+    if (H > 256 || x.params == nullptr) return OARD_EINVAL;
+    LAUNCH(F_INIT, k_c0_bwd, 1, 256, x.stw, (const float*)dc0, (const float*)x.f(x.w.csum), H, D::H4, x.params[x.pi.lin30_b],
+           x.params[x.pi.lin32_w], x.params[x.pi.rl0_b], x.params[x.pi.rl2_w], x.g(x.pi.lin30_b), x.g(x.pi.lin32_w), x.g(x.pi.lin32_b),
+           x.g(x.pi.rl0_b), x.g(x.pi.rl2_w), x.g(x.pi.rl2_b));
     for (int k = 0; k < x.c->n_obj; ++k) {                 // Linear(d, 2d) SiLU Linear(2d, emb)
         const int a = x.c->enc_alias[k], d = x.c->node_nf[k] - 3, q = x.pi.enc0 + 4 * a;
         const long long r0 = topo->obj_start[k], nk = topo->obj_start[k + 1] - r0;
         if (nk <= 0) continue;
-        TR_TRY(wg(x, x.f(tw.op_dz) + r0 * 32, 32, 32, 2 * d, 2 * d, 2 * d, x.f(tw.op_x) + r0 * 16, 16, 16, 0, d, d, d, nk, x.g(q + 0), d, x.g(q + 1)));
-        TR_TRY(wg(x, x.f(tw.op_dy) + r0 * 16, 16, 16, emb, emb, emb, x.f(tw.op_hid) + r0 * 32, 32, 32, 0, 2 * d, 2 * d, 2 * d, nk, x.g(q + 2), 2 * d, x.g(q + 3)));
+        TR_TRY(wg(x, x.f(tw.eo_dz) + r0 * 32, 32, 32, 2 * d, 2 * d, 2 * d, x.f(tw.eo_x) + r0 * 16, 16, 16, 0, d, d, d, nk, x.g(q + 0), d, x.g(q + 1)));
+        TR_TRY(wg(x, x.f(tw.eo_dy) + r0 * 16, 16, 16, emb, emb, emb, x.f(tw.eo_hid) + r0 * 32, 32, 32, 0, 2 * d, 2 * d, 2 * d, nk, x.g(q + 2), 2 * d, x.g(q + 3)));
     }
     HIP_TRY(hipGetLastError());
     return OARD_OK;
