@@ -574,7 +574,11 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_lds(const float* __restrict__ 
             const float* bp = sP + (size_t)buf * WGL_ROWS * PW + 64 * pl + 4 * i;
             const float* bq = sQ + (size_t)buf * WGL_ROWS * QLD + 16 * NT * ql + i;
             bp += (size_t)g * PW; bq += (size_t)g * QLD;
-#pragma unroll 2
+#ifndef OARD_WGL_PIPE
+#ifndef OARD_WGL_UNROLL
+#define OARD_WGL_UNROLL 2
+#endif
+#pragma unroll OARD_WGL_UNROLL
             for (int stp = 0; stp < WGL_ROWS / 4; ++stp, bp += 4 * PW, bq += 4 * QLD) {
                 const f4 a = *reinterpret_cast<const f4*>(bp);
                 float b[NT];
@@ -593,6 +597,39 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_lds(const float* __restrict__ 
                     acc[3][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u], acc[3][u], 0, 0, 0);
                 }
             }
+#else       // the LDS operands of step s + 1 are requested before the MFMAs of step s are issued
+            f4 a = *reinterpret_cast<const f4*>(bp);
+            float b[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) b[u] = bq[16 * u];
+#pragma unroll
+            for (int stp = 0; stp < WGL_ROWS / 4; ++stp) {
+                f4 an = a;
+                float bn[NT];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) bn[u] = b[u];
+                if (stp + 1 < WGL_ROWS / 4) {
+                    an = *reinterpret_cast<const f4*>(bp + (size_t)(stp + 1) * 4 * PW);
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) bn[u] = bq[(size_t)(stp + 1) * 4 * QLD + 16 * u];
+                }
+                if (sums) {
+                    ps += a;
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) qs[u] += b[u];
+                }
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[u], acc[0][u], 0, 0, 0);
+                    acc[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[u], acc[1][u], 0, 0, 0);
+                    acc[2][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[u], acc[2][u], 0, 0, 0);
+                    acc[3][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u], acc[3][u], 0, 0, 0);
+                }
+                a = an;
+#pragma unroll
+                for (int u = 0; u < NT; ++u) b[u] = bn[u];
+            }
+#endif
         }
         if (grp + 1 < ngroups) stash(buf ^ 1);
         __syncthreads();
