@@ -213,9 +213,12 @@ def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
     out = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "batch_per_gpu": B, "loss": info["loss"],
            "grad_norm": info.get("grad_norm"), "trainable_parameters": int(tr.flat_grad.numel()),
            "all_reduce_bytes": int(tr.flat_grad.numel() * 4) if world > 1 else 0, "seconds": dt}
-    # two more steps with per-family kernel timing on rank 0; EVERY rank runs them (each step holds a collective)
+    # two more steps with per-family kernel timing on rank 0; EVERY rank runs them (each step holds a collective).  The timed
+    # steps above run the reverse sweep on two streams (weight-gradient work beside the cotangent chain), where per-launch
+    # event times overlap and do not add up; the family pass runs the sweep on ONE stream (debug option train_dual = 0).
     L_ = _capi.lib()
     if timing:
+        L_.oard_debug_option(b"train_dual", 0)
         L_.oard_timing_reset()
         L_.oard_timing_enable(1)
     for i in range(2):
@@ -223,6 +226,7 @@ def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
     torch.cuda.synchronize(dev)
     if timing:
         L_.oard_timing_enable(0)
+        L_.oard_debug_option(b"train_dual", int(os.environ.get("OARD_TRAIN_DUAL", "1")))
         E, A = edge_counts(B, nf)
         fam = {}
         for f in ("gcl_edge", "equi_edge", "node", "init", "other", "gcl_edge_bwd", "equi_edge_bwd", "wgrad"):
@@ -236,6 +240,7 @@ def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
               "equi_edge_bwd": 2.0 * L * (3 * H * W + 9 * H * H) * A,
               "wgrad": 2.0 * (L * (MAC_GCL_EDGE - H) * E - (MAC_GCL_S1 + MAC_GCL_S3) * (E - A)) + 2.0 * L * (3 * H * W + 9 * H * H) * A}
         out["families_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in fam.items()}
+        out["families_note"] = "kernel times of a single-stream sweep (additive); ms_per_step is the two-stream step"
         out["hip_kernel_ms_per_step"] = round(sum(v["ms_per_step"] for v in fam.values()), 3)
         out["tflops_by_family"] = {k: round(fl[k] / (fam[k]["ms_per_step"] * 1e-3) / 1e12, 1) for k in fl if fam[k]["ms_per_step"] > 0}
         out["algorithmic_flops_per_step"] = sum(fl.values())

@@ -61,10 +61,6 @@ __device__ unsigned long long g_phase_probe[8];
 #define PROBE_END(pf) do {} while (0)
 #endif
 
-#ifdef OARD_PRIO_BALANCE
-__device__ int g_prio_k;
-#endif
-
 // experiment build (-DOARD_TIMELINE): timestamps of one workgroup's waves at the phase barriers and around every MFMA chain
 // (tools/wave_timeline.py): code 1 = after the phase barrier, 2 = chain starts, 3 = chain done, 4 = phase work done
 #ifdef OARD_TIMELINE
@@ -211,7 +207,7 @@ OARD_DEV void chain_kouter(const float* sl, int j0, f4 x, f4 (&acc)[MT], Hook ho
 #endif
 // HALF / PERIOD are per kernel: the EquiMessage kernel (37 live accumulators) spills 330 bytes per lane with the GCL kernel's policy
 // and runs equally fast with all waves issuing every third pair, so it keeps that.
-template <int WAVES, int SLAB, int HALF = OARD_PF_HALF, int PERIOD = OARD_PF_PERIOD>
+template <int WAVES, int SLAB, int HALF = OARD_PF_HALF, int PERIOD = OARD_PF_PERIOD, int RING = 2>
 struct SlabPrefetch {
     static constexpr int IW = (HALF && WAVES >= 8) ? WAVES / 2 : WAVES;               // issuing waves
     static constexpr int KMAX = (SLAB + IW - 1) / IW;          // pieces per issuing wave per phase (upper bound)
@@ -224,7 +220,7 @@ struct SlabPrefetch {
 #endif
     OARD_DEV void begin(const float* stream, float* smem, int phase, int first_chunk, int n_chunks) {
         src = stream + (size_t)first_chunk * 256;
-        dst = smem + (size_t)(phase & 1) * SLAB * 256;
+        dst = smem + (size_t)(RING == 2 ? (phase & 1) : (phase % RING)) * SLAB * 256;
         n = wave < IW ? n_chunks : 0; k = 0; next = 1 + ((IW == WAVES && wave >= WAVES / 2) ? 1 : 0);
     }
     OARD_DEV void one() {
@@ -304,7 +300,15 @@ OARD_DEV float tail_compact(f4 v, int lane) {
     const float t0 = __shfl(v.x, e, 64), t1 = __shfl(v.y, e, 64), t2 = __shfl(v.z, e, 64), t3 = __shfl(v.w, e, 64);
     return g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3));
 }
-template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2>
+// RING = 3 (three slabs, the DMA runs TWO phases ahead): the slab of phase p + 1 has landed and been published by the barrier of
+//   phase p, so a phase starts computing without a barrier; the barrier of phase p (which only has to separate the last reads of
+//   phase p - 1 from the DMA writes of phase p + 2, and to publish phase p + 1) sits behind the OARD_BAR_AT-th MFMA pair of the phase,
+//   where the next A fragments are already requested - no pipeline refill behind it.  Measured (B = 64, isolated launches, per
+//   step): 9.15 -> 8.99 ms with the barrier behind pair 2; behind pair 1 / 4 / 6 / 9: 9.17 / 9.10 / 9.13 / 9.18 ms.
+#ifndef OARD_BAR_AT
+#define OARD_BAR_AT 2
+#endif
+template <class D, int WAVES, int GP, bool DO_S1, bool DO_S3, bool TRAIN, int MINW = 2, int RING = 2>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                                const float* __restrict__ P, const float* __restrict__ Q,
                                                                const float* __restrict__ u0, const float* __restrict__ c0,
@@ -319,13 +323,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
     PROBE_DECL
     TL_DECL
     TL(0);
-#ifdef OARD_PRIO_BALANCE
-    // experiment: the SIMD arbiter favours the older wave of a pair (probe: 93 % of the barrier wait is spent by waves 0..3), so the
-    // younger one runs the first prio_k MFMA pairs of every phase at raised priority
-    const int prio_k = __builtin_amdgcn_readfirstlane(g_prio_k);
-    int prio_left = -1;
-#endif
-    SlabPrefetch<WAVES, S::SLAB> pf;
+    static_assert(RING == 2 || RING == 3, "two slabs (barrier at the phase start) or three (barrier inside the phase)");
+    static_assert(RING == 2 || HT >= 2, "the phase barrier must sit inside the FIRST chain of a phase (S3 stores the previous phase's results behind it)");
+    constexpr int DIST = RING - 1;                             // phases the DMA runs ahead
+    constexpr int BAR_AT = OARD_BAR_AT < HT / 2 ? OARD_BAR_AT : HT / 2;       // a chain over HT chunks has HT / 2 hook calls
+    SlabPrefetch<WAVES, S::SLAB, OARD_PF_HALF, OARD_PF_PERIOD, RING> pf;
     pf.wave = wave;
     pf.lane_off = (unsigned)lane * 16u;              // LDS-DMA source = uniform chunk address (SGPR pair) + this 32-bit lane offset
     auto pf_begin = [&](int p) {                               // p = phase to prefetch
@@ -337,19 +339,16 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
 #ifdef OARD_ABL_BURST
         pf.flush();
 #endif
-#ifdef OARD_PRIO_BALANCE
-        if (wave >= WAVES / 2) { __builtin_amdgcn_s_setprio(1); prio_left = prio_k; }
-#endif
     };
-#ifdef OARD_PRIO_BALANCE
-    auto hook = [&]() { pf.tick(); if (--prio_left == 0) __builtin_amdgcn_s_setprio(0); };
-#else
-    auto hook = [&]() { pf.tick(); };
-#endif
+    // phase protocol: every phase has ONE barrier followed by its post-barrier work `post` (DMA issue for a later phase, edge-state
+    // prefetch, late stores).  RING 2: at the phase start.  RING 3: armed at the phase start (bar_left), run by the OARD_BAR_AT-th hook
+    // call (hooks sit between the MFMA pairs of the chains), or after the chains if the phase had fewer hook calls than that.
+    int bar_left = 0;
+    auto slab_of = [&](int p) -> int { return RING == 2 ? (p & 1) : (p % RING); };
     auto A = [&](int p, int j) -> f4 {
-        return *reinterpret_cast<const f4*>(smem + ((size_t)(p & 1) * S::SLAB + j) * 256 + lane * 4);
+        return *reinterpret_cast<const f4*>(smem + ((size_t)slab_of(p) * S::SLAB + j) * 256 + lane * 4);
     };
-    auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
+    auto SL = [&](int p) -> const float* { return smem + (size_t)slab_of(p) * S::SLAB * 256 + lane * 4; };
 
     // column of this lane; padding columns work on the spare row E of every per-edge buffer (allocated for that
     // purpose), so the kernel has no validity branches and every wave stays in the barrier protocol
@@ -373,6 +372,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
     int p = DO_S1 ? 0 : S::NP1;
     pf_begin(p);
     pf.flush();                                                // burst form (prologue only)
+    if (RING == 3) { pf_begin(p + 1); pf.flush(); PHASE_BARRIER(); }
 
     // ---- S1: h1 += W1c . ew   (K-outer) -------------------------------------------------------------
     f4 h1x = f4zero();                                         // ROWS4: second accumulator of the 4-row tile
@@ -380,20 +380,24 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
     // needs a copy "current = next" per block and phase, and every VALU instruction costs MFMA issue time (tools/micro/mfma_valu.hip).
     f4 xm[GP];
     auto s1_phase = [&](int p1, const f4 (&x)[GP], f4 (&xnext)[GP]) {
-        PHASE_BARRIER();
-        TL(1);
-        pf_begin(p + 1);
-        if (p1 + 1 < S::NP1) {
+        auto post = [&]() {
+            TL(1);
+            pf_begin(p + DIST);
+            if (p1 + 1 < S::NP1) {
 #pragma unroll
-            for (int gg = 0; gg < GP; ++gg) {
-                const int b = (p1 + 1) * GP + gg;
-                if (b < WB) xnext[gg] = ld_edge(erow + 16 * b);
+                for (int gg = 0; gg < GP; ++gg) {
+                    const int b = (p1 + 1) * GP + gg;
+                    if (b < WB) xnext[gg] = ld_edge(erow + 16 * b);
+                }
             }
-        }
+        };
+        auto hook = [&]() { if (RING == 3 && bar_left > 0 && --bar_left == 0) { PHASE_BARRIER(); post(); } pf.tick(); };
+        if (RING == 2) { PHASE_BARRIER(); post(); } else bar_left = BAR_AT;
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg)
             if (p1 * GP + gg < WB) { TL(2); chain_kouter<HT, ROWS4>(SL(p), gg * G1, x[gg], h1, h1x, hook); TL(3); }
         TL(4);
+        if (RING == 3 && bar_left > 0) { bar_left = 0; PHASE_BARRIER(); post(); }
         pf.flush();
         ++p;
     };
@@ -420,14 +424,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
     float m_tail = 0.f;
 #pragma unroll
     for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
-        PHASE_BARRIER();
-        TL(1);
-        pf_begin(p + 1);
-        if (DO_S3 && p2 == S::NP2 - 1) {            // prefetch the old edge-state tiles of S3's first phase
+        auto post = [&]() {
+            TL(1);
+            pf_begin(p + DIST);
+            if (DO_S3 && p2 == S::NP2 - 1) {        // prefetch the old edge-state tiles of S3's first phase
 #pragma unroll
-            for (int gg = 0; gg < GP; ++gg)
-                on[gg] = gg < WB ? (DO_S1 ? ld_edge(erow + 16 * gg) : ld_f4(c0 + 16 * gg + 4 * g)) : f4zero();
-        }
+                for (int gg = 0; gg < GP; ++gg)
+                    on[gg] = gg < WB ? (DO_S1 ? ld_edge(erow + 16 * gg) : ld_f4(c0 + 16 * gg + 4 * g)) : f4zero();
+            }
+        };
+        auto hook = [&]() { if (RING == 3 && bar_left > 0 && --bar_left == 0) { PHASE_BARRIER(); post(); } pf.tick(); };
+        if (RING == 2) { PHASE_BARRIER(); post(); } else bar_left = BAR_AT;
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
             const int tg = p2 * GP + gg;            // compile-time after unrolling
@@ -459,6 +466,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
             }
         }
         TL(4);
+        if (RING == 3 && bar_left > 0) { bar_left = 0; PHASE_BARRIER(); post(); }
         pf.flush();
     }
     // ---- S3: ew += SiLU(W3 m + b3), one output tile per group ----------------------------------------
@@ -474,27 +482,30 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
     f4 pend[GP], pendz[TRAIN ? GP : 1];
     f4 om[GP];
     auto s3_phase = [&](int p3, const f4 (&o)[GP], f4 (&onext)[GP]) {
-        PHASE_BARRIER();
-        TL(1);
-        if (p3 == 0) {
+        auto post = [&]() {
+            TL(1);
+            if (p3 == 0) {
 #pragma unroll
-            for (int t = 0; t < HT; ++t) st_blk(mbuf, eid, D::HP, t, lane, m[t]);
-        } else {
+                for (int t = 0; t < HT; ++t) st_blk(mbuf, eid, D::HP, t, lane, m[t]);
+            } else {
 #pragma unroll
-            for (int gg = 0; gg < GP; ++gg) {                  // (p3-1)*GP+gg < WB always
-                st_f4(orow + 16 * ((p3 - 1) * GP + gg), pend[gg]);
-                if (TRAIN) st_f4(tape.z3 + e * D::WP + 4 * g + 16 * ((p3 - 1) * GP + gg), pendz[gg]);
+                for (int gg = 0; gg < GP; ++gg) {              // (p3-1)*GP+gg < WB always
+                    st_f4(orow + 16 * ((p3 - 1) * GP + gg), pend[gg]);
+                    if (TRAIN) st_f4(tape.z3 + e * D::WP + 4 * g + 16 * ((p3 - 1) * GP + gg), pendz[gg]);
+                }
             }
-        }
-        pf_begin(p + 1);
-        if (p3 + 1 < S::NP3) {
+            pf_begin(p + DIST);
+            if (p3 + 1 < S::NP3) {
 #pragma unroll
-            for (int gg = 0; gg < GP; ++gg) {
-                const int t = (p3 + 1) * GP + gg;
-                if (t < WB)      // !DO_S1: the old state of these rows IS the constant row (never materialised)
-                    onext[gg] = DO_S1 ? ld_edge(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
+                for (int gg = 0; gg < GP; ++gg) {
+                    const int t = (p3 + 1) * GP + gg;
+                    if (t < WB)  // !DO_S1: the old state of these rows IS the constant row (never materialised)
+                        onext[gg] = DO_S1 ? ld_edge(erow + 16 * t) : ld_f4(c0 + 16 * t + 4 * g);
+                }
             }
-        }
+        };
+        auto hook = [&]() { if (RING == 3 && bar_left > 0 && --bar_left == 0) { PHASE_BARRIER(); post(); } pf.tick(); };
+        if (RING == 2) { PHASE_BARRIER(); post(); } else bar_left = BAR_AT;
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
             const int t = p3 * GP + gg;
@@ -507,6 +518,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
             }
         }
         TL(4);
+        if (RING == 3 && bar_left > 0) { bar_left = 0; PHASE_BARRIER(); post(); }
         pf.flush();
         ++p;
     };
@@ -545,6 +557,8 @@ struct EquiStream {
 
 // TRAIN: also stores the pre-activation of dir_proj.0 (zd1 [A+1][D1P]) and dir_proj's output before the product
 // with rbf_proj (cd [A+1][3][HP]) for the backward pass.
+// (Three slabs with the barrier inside the phase, as in k_gcl_edge_v1, were measured here too: 7.09-7.14 ms per step against
+// 7.10-7.13 ms - the phases of this kernel are twice as long and its barrier wait was small to begin with; not kept.)
 template <class D, int WAVES, bool TRAIN>
 __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                              const float* __restrict__ dp0b,

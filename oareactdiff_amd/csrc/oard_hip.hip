@@ -72,6 +72,7 @@ int g_wgrad_wgs = 512;       // workgroups per weight-gradient GEMM (row chunks 
                             // (measured per training step: 384 -> 38.1 ms, 512 -> 30.7, 768 -> 36.0, 1024 -> 33.2, 2048 -> 38.1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
+int g_skip_families = 0;    // timing experiments only (results are garbage): bit f set = launches of family f are dropped
 
 struct ScopedLaunch {
     hipStream_t st; hipEvent_t a; int fam; bool on;
@@ -82,9 +83,9 @@ struct ScopedLaunch {
         if (on) { hipEvent_t b = g_timing.get(); (void)hipEventRecord(b, st); g_timing.recs.push_back({a, b, fam}); }
     }
 };
-#define LAUNCH(fam, kern, grid, block, stream, ...) do { ScopedLaunch sl_(fam, stream); \
+#define LAUNCH(fam, kern, grid, block, stream, ...) do { ScopedLaunch sl_(fam, stream); if (!((g_skip_families >> (fam)) & 1)) \
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), 0, stream, __VA_ARGS__); } while (0)
-#define LAUNCH2(fam, kern, gx, gy, block, stream, ...) do { ScopedLaunch sl_(fam, stream); \
+#define LAUNCH2(fam, kern, gx, gy, block, stream, ...) do { ScopedLaunch sl_(fam, stream); if (!((g_skip_families >> (fam)) & 1)) \
     hipLaunchKernelGGL(kern, dim3((unsigned)(gx), (unsigned)(gy)), dim3(block), 0, stream, __VA_ARGS__); } while (0)
 
 #ifndef OARD_DIMS_LIST      // production (train_ts1x.py:43-56) + the two test widths of the reference's unit tests / goldens
@@ -318,20 +319,29 @@ int set_lds(K kernel, size_t bytes) {
     static bool attr_done_[64] = {}; \
     int dev_ = 0; (void)hipGetDevice(&dev_); dev_ &= 63; \
     if (!attr_done_[dev_]) { int rc_ = set_lds(kern, lds); if (rc_ != OARD_OK) return rc_; attr_done_[dev_] = true; } \
-    ScopedLaunch sl_(fam, stream); \
+    ScopedLaunch sl_(fam, stream); if (!((g_skip_families >> (fam)) & 1)) \
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(block), lds, stream, __VA_ARGS__); } while (0)
 
 #define GCL_CASE(id, WV_, GP_) case id: { \
         LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, WV_, GP_, S1, S3, false>), cdiv(r1 - r0, 16 * WV_), WV_ * 64, \
                    (GclStream<D, GP_>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
+// the throughput shape: 8 waves x 16 edges, two waves per SIMD, three LDS slabs (barrier inside the phase)
+#define GCL_RING3(TRAIN_, tape_) do { \
+        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, TRAIN_, 2, 3>), cdiv(r1 - r0, 16 * 8), 8 * 64, \
+                   (GclStream<D, 2>::LDS_BYTES / 2 * 3), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, tape_); return OARD_OK; } while (0)
 template <class D, bool S1, bool S3>
 int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
                    const float* c0, long long r0, long long r1, const float* ew_in, float* ew_out, float* mbuf, const GclTape* tape, hipStream_t st) {
     if (r1 <= r0) return OARD_OK;
     if (tape) {                  // training-mode forward: one shape (8 waves x 16 edges), pre-activations stored
-        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, true>), cdiv(r1 - r0, 16 * 8), 8 * 64,
-                   (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, *tape);
-        return OARD_OK;
+#ifdef OARD_EXPERIMENTS
+        if (variant == 7) {
+            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, true>), cdiv(r1 - r0, 16 * 8), 8 * 64,
+                       (GclStream<D, 2>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, *tape);
+            return OARD_OK;
+        }
+#endif
+        GCL_RING3(true, *tape);
     }
     if (variant == 2 && cdiv(r1 - r0, 16) * conc <= 1024LL * g_auto_small) variant = 3;
     if ((variant == 2 || variant == 3) && cdiv(r1 - r0, 16) * conc <= 512LL * g_auto_tiny) variant = 6;
@@ -341,9 +351,10 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
         return OARD_OK;
     }
     switch (variant) {
-        GCL_CASE(2, 8, 2)      // 8 waves x 16 edges, two waves per SIMD
+        case 2: GCL_RING3(false, GclTape{});
         GCL_CASE(3, 4, 2)      // 4 waves x 16 edges (two workgroups per CU): small launches
 #ifdef OARD_EXPERIMENTS        // A/B shapes, only in experiment builds (tools/ab_gcl.sh)
+        GCL_CASE(7, 8, 2)      // the throughput shape with two slabs (barrier at the phase start; round 1 / 2)
         case 4: {              // flag pipeline: no workgroup barriers, ring of 4 slabs (oard_edge_fp.h)
             LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_fp<D, 8, 2, S1, S3, false>), cdiv(r1 - r0, 16 * 8), 8 * 64,
                        (GclRing<D, 2, 4>::LDS_BYTES), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{}); return OARD_OK; }
@@ -1643,6 +1654,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "equi_variant") == 0) { g_equi_variant = value; return OARD_OK; }
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
+    if (strcmp(name, "skip_families") == 0) { g_skip_families = value; return OARD_OK; }
     if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
     if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }
     if (strcmp(name, "poison") == 0) { g_poison = value; return OARD_OK; }
@@ -1653,9 +1665,6 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "wgrad_lds") == 0) { g_wgrad_lds = value; return OARD_OK; }
     if (strcmp(name, "train_dual") == 0) { g_train_dual = value; return OARD_OK; }
     if (strcmp(name, "small_split") == 0) { g_small_split = value; return OARD_OK; }
-#ifdef OARD_PRIO_BALANCE
-    if (strcmp(name, "prio_k") == 0) { HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prio_k), &value, sizeof(int))); return OARD_OK; }
-#endif
     return OARD_EINVAL;
 }
 #ifdef OARD_PHASE_PROBE

@@ -16,12 +16,19 @@ template <class D>
 struct ScalarizeBwd {
     static constexpr int H4 = D::H4, HQ = (H4 + 15) / 16;
     static constexpr int NPART = 5 * H4 + 1;      // per-node partial: dw0 [H4][3] | db0 [H4] | dw2 [H4] | db2
+    // rows per lane of hidden block q (a lane (g, j) holds rows 16q + 4g + r): 4, except in a last block with fewer than 4 real
+    // rows (H4 = 49: one row) - its padding rows are not evaluated (13 instead of 16 evaluations per item)
+    static constexpr int R_LAST = (H4 - 16 * (HQ - 1)) < 4 ? (H4 - 16 * (HQ - 1)) : 4;
+    OARD_DEV static constexpr int rows(int q) { return q == HQ - 1 ? R_LAST : 4; }
 };
 
 // ne1: [N][3][ld] (ld >= H), gdew: gradient of the initial edge state, rows = inner edges, row stride WP, columns [0, 2H)
 // dne1: [N][3][ld] out;  part: [N][NPART] out (summed over the node's edges and channels; the caller adds the nodes up)
+#ifndef OARD_SCAL_BWD_MINW
+#define OARD_SCAL_BWD_MINW 2
+#endif
 template <class D, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_scalarize_bwd(TopoDev tp, const float* __restrict__ l3, const float* __restrict__ ne1,
+__global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bwd(TopoDev tp, const float* __restrict__ l3, const float* __restrict__ ne1,
                                                               int ld, const float* __restrict__ geo, const float* __restrict__ gdew,
                                                               float* __restrict__ dne1, float* __restrict__ part) {
     using SB = ScalarizeBwd<D>;
@@ -44,7 +51,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scalarize_bwd(TopoDev tp, const 
 #pragma unroll
     for (int q = 0; q < HQ; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < SB::rows(q); ++r) {
             const int row = 16 * q + 4 * g + r;
             const bool ok = row < H4;
             w2r[q][r] = ok ? w2[row] : 0.f;
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scalarize_bwd(TopoDev tp, const 
 #pragma unroll
     for (int q = 0; q < HQ; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ab0[q][r] = 0.f; aw2[q][r] = 0.f; aw0[q][r][0] = 0.f; aw0[q][r][1] = 0.f; aw0[q][r][2] = 0.f; }
+        for (int r = 0; r < SB::rows(q); ++r) { ab0[q][r] = 0.f; aw2[q][r] = 0.f; aw0[q][r][0] = 0.f; aw0[q][r][1] = 0.f; aw0[q][r][2] = 0.f; }
 
     const int q_grp = tp.node_sample[n] * tp.n_obj + tp.node_obj[n];
     const int g0 = tp.grp_ptr[q_grp], ng = tp.grp_ptr[q_grp + 1] - g0, self = n - g0;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scalarize_bwd(TopoDev tp, const 
                 for (int q = 0; q < HQ; ++q) {
                     const f4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[q], bval, f4zero(), 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < SB::rows(q); ++r) {
                         const float zz = z[r];
                         const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-zz));
                         const float h = zz * sg;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scalarize_bwd(TopoDev tp, const 
 #pragma unroll
     for (int q = 0; q < HQ; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < SB::rows(q); ++r) {
             const float s0 = red16(aw0[q][r][0]), s1 = red16(aw0[q][r][1]), s2 = red16(aw0[q][r][2]);
             const float sb = red16(ab0[q][r]), sw = red16(aw2[q][r]);
             if (j == 0) {
