@@ -6,6 +6,6 @@ for s in "$@"; do
     OARD_TRAIN_DUAL=0 python bench.py --mode train --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); t=d['train_step']
-print('lib $s', 'ms/step', round(d['ms_per_step'],2), 'wgrad', t['families_ms_per_step']['wgrad'], 'loss', round(t['loss'],4))"
+print('lib $s', 'ms/step', round(d['ms_per_step'],2), t['families_ms_per_step'], 'loss', round(t['loss'],4))"
   done
 done
