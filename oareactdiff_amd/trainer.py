@@ -21,6 +21,7 @@ left out of the bucket and never get a gradient, as in the reference.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -69,6 +70,10 @@ class DDPMTrainer:
                                   scales=scales)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # the collectives run with more than one rank - or, for a smoke test of the RCCL path on a one-GPU box, whenever a process
+        # group exists and OARD_FORCE_COLLECTIVES is set (a one-rank broadcast / all-reduce is the identity)
+        self.collectives = self.world > 1 or (dist.is_available() and dist.is_initialized()
+                                              and bool(os.environ.get("OARD_FORCE_COLLECTIVES")))
         # distinct trainable parameters the forward uses, in state-dict order (shared encoders count once)
         seen, self.params, self.names = set(), [], []
         for name, p in dynamics.named_parameters():
@@ -82,7 +87,7 @@ class DDPMTrainer:
         self._bucket = torch.zeros(n + 1, dtype=self.params[0].dtype, device=self.params[0].device)
         self.flat_grad = self._bucket[:n]
         self.skipped_steps = 0
-        if self.world > 1:
+        if self.collectives:
             self.sync_replicas()
         off = 0
         for p in self.params:                          # p.grad = view into the bucket: backward accumulates in place
@@ -123,7 +128,7 @@ class DDPMTrainer:
         """What torch DDP does when it wraps a module (Lightning `DDPStrategy`, train_ts1x.py:197-203): rank 0's parameters
         and buffers are broadcast to every rank, so replicas built from different RNG states - or with a checkpoint loaded
         on rank 0 only - start identical.  One flat broadcast for the parameters, one for the floating-point buffers."""
-        if self.world <= 1:
+        if not self.collectives:
             return
         with torch.no_grad():
             for tensors in (list(self.dynamics.parameters()),
@@ -151,9 +156,10 @@ class DDPMTrainer:
     def all_reduce_gradients(self) -> None:
         """DDP's gradient averaging as one collective over the flat bucket (sum, then / world).  The last element of the
         bucket is the step's non-finite flag: summed with the gradients, > 0 on every rank if any rank raised it."""
-        if self.world > 1:
+        if self.collectives:
             dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat_grad.div_(self.world)
+            if self.world > 1:
+                self.flat_grad.div_(self.world)
 
     def clip_gradients(self, grad_norm: Optional[float] = None) -> Tuple[float, float]:
         """pl_trainer.py:391-418: allow 150 % of the recent mean norm + 3 standard deviations."""
@@ -255,7 +261,7 @@ class DDPMTrainer:
         if dyn.nan_seen is not None:
             bad = bad + (dyn.nan_seen[0] != 0).to(torch.float32)
         self._bucket[-1] = bad
-        if self.world > 1:
+        if self.collectives:
             self.all_reduce_gradients()
             norm = torch.linalg.vector_norm(self.flat_grad, 2.0)
         stats = torch.cat([norm.reshape(1), self._bucket[-1:], means]).tolist()        # the one host sync
