@@ -1,0 +1,177 @@
+// Microbenchmark (run on the GPU box): the LDS -> MFMA chain of the streamed edge kernels in isolation.  One workgroup per CU,
+// 4 or 8 waves (one or two per SIMD); every wave runs output tiles of 13 chunks (6 pairs of 8 MFMAs + a 4-MFMA tail) whose A
+// fragments come from LDS (ds_read_b128, lane-linear 1-KiB chunks) and whose B operands sit in registers.  Variants:
+//   0  the product's chain_tile: fragments of the next pair requested in source order before the current pair's MFMAs, copied at
+//      the end of the iteration (hipcc sinks the reads behind the pair's 7th MFMA and waits for them at the top of the next pair)
+//   1  the same with __builtin_amdgcn_sched_group_barrier pinning "2 DS reads, then 8 MFMAs" per pair
+//   2  ping-pong fragment registers (no copies), reads two pairs ahead pinned the same way
+//   3  no LDS at all (A fragments in registers): the pipe-rate reference
+// HOOK = 1 puts a wave-uniform branch (the LDS-DMA issue hook of the product) behind every pair, which cuts the basic blocks there.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/chain_lds.hip -o tools/micro/chain_lds && tools/micro/chain_lds
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define DEV __device__ __forceinline__
+DEV f4 lds_a(const float* sl, int j) { return *reinterpret_cast<const f4*>(sl + j * 256); }
+DEV void mma_pair(f4 a0, f4 b0, f4& c0, f4 a1, f4 b1, f4& c1) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, c1, 0, 0, 0);
+}
+DEV f4 mma_chunk(f4 a, f4 b, f4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+constexpr int KB = 13;
+struct Hook {
+    int* next; float* sink;
+    DEV void operator()() const { if (--*next == 0) { *next = 1 << 30; asm volatile("s_nop 0" ::: "memory"); } }
+};
+struct NoHook { DEV void operator()() const {} };
+// the product's prefetcher (oard_edge_v1.h SlabPrefetch, waves 0..3 issue one 1-KiB LDS-DMA piece behind every pair): branchy form
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+struct PF {
+    const float* src; float* dst; unsigned lane_off; int n, k, next, wave;
+    DEV void begin(int n_chunks) { n = wave < 4 ? n_chunks : 0; k = 0; next = 1; }
+    DEV void one() {
+        const int j = wave + k * 4;
+        if (j < n) __builtin_amdgcn_global_load_lds((gbl_ptr_t)((const char*)(src + (size_t)j * 256) + lane_off), (lds_ptr_t)(dst + j * 256), 16, 0, 0);
+        ++k;
+    }
+    DEV void tick() { if (--next == 0) { one(); next = 1; } }
+    // straight-line form: the piece is issued under an EXEC mask (all lanes or none), no branch, no memory clobber
+    DEV void one_pred() {
+        const int j = wave + k * 4;
+        const unsigned lds_addr = (unsigned)(unsigned long)(lds_ptr_t)(dst + j * 256);
+        const float* s = src + (size_t)j * 256;
+        unsigned long long sv, msk;
+        asm volatile("s_cmp_lt_i32 %2, %3\n\ts_cselect_b64 %1, -1, 0\n\ts_mov_b32 m0, %4\n\ts_and_saveexec_b64 %0, %1\n\t"
+                     "global_load_lds_dwordx4 %5, %6\n\ts_mov_b64 exec, %0"
+                     : "=&s"(sv), "=&s"(msk) : "s"(__builtin_amdgcn_readfirstlane(j)), "s"(__builtin_amdgcn_readfirstlane(n)),
+                       "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(lane_off), "s"(s) : "m0", "scc");
+        ++k;
+    }
+};
+struct HookPF { PF* pf; DEV void operator()() const { pf->tick(); } };
+struct HookPred { PF* pf; DEV void operator()() const { pf->one_pred(); } };
+
+template <int MODE, class H>
+DEV f4 chain(const float* sl, int j0, const f4 (&in)[KB], f4 init, H hook) {
+    f4 c0 = init, c1 = (f4){0.f, 0.f, 0.f, 0.f};
+    if (MODE == 3) {
+        f4 a0 = init + 1.0f, a1 = init + 2.0f;
+#pragma unroll
+        for (int b = 0; b + 1 < KB; b += 2) { mma_pair(a0, in[b], c0, a1, in[b + 1], c1); hook(); }
+        c0 = mma_chunk(a0, in[KB - 1], c0);
+        return c0 + c1;
+    }
+    if (MODE == 2) {
+        f4 a0 = lds_a(sl, j0), a1 = lds_a(sl, j0 + 1), b0 = lds_a(sl, j0 + 2), b1 = lds_a(sl, j0 + 3);
+#pragma unroll
+        for (int b = 0; b + 1 < KB; b += 4) {
+            // pair b from (a0, a1); request pair b + 4 into (a0, a1) afterwards; pair b + 2 from (b0, b1)
+            mma_pair(a0, in[b], c0, a1, in[b + 1], c1);
+            hook();
+            if (b + 4 < KB) a0 = lds_a(sl, j0 + b + 4);
+            if (b + 5 < KB) a1 = lds_a(sl, j0 + b + 5);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (b + 3 < KB) {
+                mma_pair(b0, in[b + 2], c0, b1, in[b + 3], c1);
+                hook();
+                if (b + 6 < KB) b0 = lds_a(sl, j0 + b + 6);
+                if (b + 7 < KB) b1 = lds_a(sl, j0 + b + 7);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        }
+        // KB = 13: pairs 0..5 consumed chunks 0..11; chunk 12 sits in a0 (requested at b = 8)
+        c0 = mma_chunk(a0, in[KB - 1], c0);
+        return c0 + c1;
+    }
+    f4 a0 = lds_a(sl, j0), a1 = lds_a(sl, j0 + 1);
+#pragma unroll
+    for (int b = 0; b + 1 < KB; b += 2) {
+        f4 n0 = a0, n1 = a1;
+        if (b + 2 < KB) n0 = lds_a(sl, j0 + b + 2);
+        if (b + 3 < KB) n1 = lds_a(sl, j0 + b + 3);
+        mma_pair(a0, in[b], c0, a1, in[b + 1], c1);
+        if (MODE == 1) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+        hook();
+        a0 = n0; a1 = n1;
+    }
+    c0 = mma_chunk(a0, in[KB - 1], c0);
+    return c0 + c1;
+}
+
+template <int MODE, int HOOK>
+__global__ __launch_bounds__(512, 2) void k(float* out, const float* src, int iters, int hook_at) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 28 * 256];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 28 * 256; i += blockDim.x) smem[i] = src[i & 1023];
+    __syncthreads();
+    f4 in[KB];
+    for (int b = 0; b < KB; ++b) in[b] = (f4){src[b], src[b + 1], src[b + 2], src[b + 3]};
+    const float* sl = smem + lane * 4;
+    f4 sum = (f4){0.f, 0.f, 0.f, 0.f};
+    int next = hook_at;
+    PF pf;
+    pf.src = src; pf.dst = smem + 28 * 256; pf.lane_off = lane * 16u; pf.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (HOOK >= 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); pf.begin(28); }
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            f4 z;
+            if (HOOK == 3) z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), HookPF{&pf});
+            else if (HOOK == 2) z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), HookPred{&pf});
+            else if (HOOK) z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), Hook{&next, out});
+            else z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), NoHook{});
+            sum += z;
+        }
+    }
+    const long long t1 = clock64();
+    if (lane == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)out + 1, (unsigned long long)(t1 - t0));
+    if (sum.x == 12345.f) out[0] = sum.y;
+}
+
+template <int MODE, int HOOK>
+void run(int waves_per_simd) {
+    float *out, *src; hipMalloc(&out, 64); hipMalloc(&src, 32 * 1024 * 4);
+    float h[1024]; for (int i = 0; i < 1024; ++i) h[i] = 1e-3f * (i % 7);
+    hipMemcpy(src, h, 4096, hipMemcpyHostToDevice);
+    const int iters = 4000, block = 256 * waves_per_simd;
+    if (block == 256 && HOOK >= 2) return;      // the prefetcher needs the 8-wave workgroup
+    k<MODE, HOOK><<<256, block>>>(out, src, 10, 1 << 30);
+    hipDeviceSynchronize();
+    hipMemset(out, 0, 64);
+    k<MODE, HOOK><<<256, block>>>(out, src, iters, 1 << 30);
+    hipDeviceSynchronize();
+    long long r[2]; hipMemcpy(r, out, 16, hipMemcpyDeviceToHost);
+    const double mfma = (double)iters * 2 * 52 * waves_per_simd;
+    printf("mode %d hook %d waves/SIMD %d: %.1f %% of the 32-cycle MFMA rate (%lld cycles)\n", MODE, HOOK, waves_per_simd,
+           100.0 * 32 * mfma / r[1], r[1]);
+    hipFree(out); hipFree(src);
+}
+int main() {
+    for (int w = 1; w <= 2; ++w) {
+        run<3, 0>(w); run<3, 1>(w);
+        run<0, 0>(w); run<0, 1>(w);
+        run<1, 0>(w); run<1, 1>(w);
+        run<2, 0>(w); run<2, 1>(w);
+        run<0, 3>(w); run<0, 2>(w); run<3, 3>(w); run<3, 2>(w);
+    }
+    return 0;
+}
