@@ -33,9 +33,9 @@ DEV f4 mma_chunk(f4 a, f4 b, f4 c) {
 constexpr int KB = 13;
 struct Hook {
     int* next; float* sink;
-    DEV void operator()() const { if (--*next == 0) { *next = 1 << 30; asm volatile("s_nop 0" ::: "memory"); } }
+    DEV void operator()(int) const { if (--*next == 0) { *next = 1 << 30; asm volatile("s_nop 0" ::: "memory"); } }
 };
-struct NoHook { DEV void operator()() const {} };
+struct NoHook { DEV void operator()(int) const {} };
 // the product's prefetcher (oard_edge_v1.h SlabPrefetch, waves 0..3 issue one 1-KiB LDS-DMA piece behind every pair): branchy form
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -61,8 +61,18 @@ struct PF {
         ++k;
     }
 };
-struct HookPF { PF* pf; DEV void operator()() const { pf->tick(); } };
-struct HookPred { PF* pf; DEV void operator()() const { pf->one_pred(); } };
+struct HookPF { PF* pf; DEV void operator()(int) const { pf->tick(); } };
+// issue points fixed at compile time: behind every EVERY-th pair (pair index b / 2), up to PIECES pieces there; no code elsewhere
+template <int EVERY, int PIECES> struct HookStatic {
+    PF* pf;
+    DEV void operator()(int b) const {
+        if ((b / 2) % EVERY == EVERY - 1) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) pf->one();
+        }
+    }
+};
+struct HookPred { PF* pf; DEV void operator()(int) const { pf->one_pred(); } };
 
 template <int MODE, class H>
 DEV f4 chain(const float* sl, int j0, const f4 (&in)[KB], f4 init, H hook) {
@@ -70,7 +80,7 @@ DEV f4 chain(const float* sl, int j0, const f4 (&in)[KB], f4 init, H hook) {
     if (MODE == 3) {
         f4 a0 = init + 1.0f, a1 = init + 2.0f;
 #pragma unroll
-        for (int b = 0; b + 1 < KB; b += 2) { mma_pair(a0, in[b], c0, a1, in[b + 1], c1); hook(); }
+        for (int b = 0; b + 1 < KB; b += 2) { mma_pair(a0, in[b], c0, a1, in[b + 1], c1); hook(b); }
         c0 = mma_chunk(a0, in[KB - 1], c0);
         return c0 + c1;
     }
@@ -80,14 +90,14 @@ DEV f4 chain(const float* sl, int j0, const f4 (&in)[KB], f4 init, H hook) {
         for (int b = 0; b + 1 < KB; b += 4) {
             // pair b from (a0, a1); request pair b + 4 into (a0, a1) afterwards; pair b + 2 from (b0, b1)
             mma_pair(a0, in[b], c0, a1, in[b + 1], c1);
-            hook();
+            hook(b);
             if (b + 4 < KB) a0 = lds_a(sl, j0 + b + 4);
             if (b + 5 < KB) a1 = lds_a(sl, j0 + b + 5);
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             if (b + 3 < KB) {
                 mma_pair(b0, in[b + 2], c0, b1, in[b + 3], c1);
-                hook();
+                hook(b + 2);
                 if (b + 6 < KB) b0 = lds_a(sl, j0 + b + 6);
                 if (b + 7 < KB) b1 = lds_a(sl, j0 + b + 7);
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
@@ -109,7 +119,7 @@ DEV f4 chain(const float* sl, int j0, const f4 (&in)[KB], f4 init, H hook) {
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
-        hook();
+        hook(b);
         a0 = n0; a1 = n1;
     }
     c0 = mma_chunk(a0, in[KB - 1], c0);
@@ -136,6 +146,10 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* src, int it
         for (int gg = 0; gg < 2; ++gg) {
             f4 z;
             if (HOOK == 3) z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), HookPF{&pf});
+            else if (HOOK == 4) z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), HookStatic<2, 2>{&pf});
+            else if (HOOK == 5) z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), HookStatic<3, 2>{&pf});
+            else if (HOOK == 6) z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), HookStatic<3, 4>{&pf});
+            else if (HOOK == 7) z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), HookStatic<1, 1>{&pf});
             else if (HOOK == 2) z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), HookPred{&pf});
             else if (HOOK) z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), Hook{&next, out});
             else z = chain<MODE>(sl, gg * 14 + 1, in, lds_a(sl, gg * 14), NoHook{});
@@ -172,6 +186,7 @@ int main() {
         run<1, 0>(w); run<1, 1>(w);
         run<2, 0>(w); run<2, 1>(w);
         run<0, 3>(w); run<0, 2>(w); run<3, 3>(w); run<3, 2>(w);
+        run<0, 7>(w); run<0, 4>(w); run<0, 5>(w); run<0, 6>(w);
     }
     return 0;
 }
