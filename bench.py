@@ -509,7 +509,7 @@ def main():
                                "tail of this run is cheaper than the fixed-distribution steps of the headline value (SURVEY 8d)"}
     if rank == 0 and not args.quick and world == 1:
         dyn.nan_check = "async"
-        train, _ = train_leg(dyn, B, nf, dev, None, 1, 3, 2)
+        train, _ = train_leg(dyn, B, nf, dev, None, 1, 10, 3)      # warm-up as in `--mode train`
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
