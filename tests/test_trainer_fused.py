@@ -125,3 +125,29 @@ def test_fused_steps_are_deterministic_and_independent_of_the_stream_split():
         assert other[2] == res[0][2]
         assert torch.equal(other[1], res[0][1]) and torch.equal(other[0], res[0][0])
     assert all(torch.isfinite(torch.tensor(res[0][2])))
+
+
+def test_fused_training_lowers_a_fixed_objective():
+    """End to end: with the same t / noise draws every step (the RNG is re-seeded) the objective is a fixed function of the weights;
+    60 fused steps (HIP forward, sweep, clipping, AdamW kernel, repacked weights every step) must lower it substantially; so must
+    the generic path (autograd through DynamicsFunction + torch.optim.AdamW) on ITS fixed objective (the two paths consume the RNG
+    stream differently, so the objectives are different draws of the same loss)."""
+    c = GradCase("g9_grad_h32")
+    dev = torch.device("cuda:0")
+    B = len(c.meta["sizes"])
+    batch = (c.reps(torch.float32, dev), torch.zeros(B, 1, device=dev))
+    curves = {}
+    for fused in (True, False):
+        tr = _trainer(c, dev, fused, True)
+        tr.opt_config["lr"] = 2e-3
+        for g in tr.optimizer.param_groups:
+            g["lr"] = 2e-3
+        losses = []
+        for step in range(60):
+            torch.manual_seed(11)
+            losses.append(tr.training_step(batch)["loss"])
+        curves[fused] = losses
+    f, g = curves[True], curves[False]
+    print("fixed objective: fused", [round(x, 4) for x in f[::10]], "generic", [round(x, 4) for x in g[::10]])
+    assert all(torch.isfinite(torch.tensor(f))) and f[-1] < 0.7 * f[0], (f[0], f[-1])
+    assert all(torch.isfinite(torch.tensor(g))) and g[-1] < 0.7 * g[0], (g[0], g[-1])
