@@ -337,7 +337,12 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     dry = bool(os.environ.get("OARD_BENCH_DRY"))              # no GPU work: only the launcher / rank / reduction plumbing (CPU test)
-    if world > 1:
+    # OARD_BENCH_FORCE_DIST=1 under the launcher with ONE rank: the process group, the barriers and the MAX-reduce of the N > 1 path
+    # run anyway (RCCL smoke test of exactly this code on a one-GPU box, tests/test_rccl_single_rank.py)
+    force_dist = bool(os.environ.get("OARD_BENCH_FORCE_DIST")) and "MASTER_PORT" in os.environ
+    if force_dist:
+        os.environ["OARD_FORCE_COLLECTIVES"] = "1"            # DDPMTrainer: broadcast / bucket all-reduce with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dry:

@@ -72,3 +72,26 @@ def test_training_step_collectives_over_rccl_one_rank():
     env.pop("OARD_FORCE_COLLECTIVES", None)
     r = subprocess.run([sys.executable, "-c", CHILD], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "RCCL_SINGLE_RANK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("mode", ["sample", "train"])
+def test_bench_launch_line_over_rccl_one_rank(mode):
+    """The driver's launch line with ONE rank and OARD_BENCH_FORCE_DIST=1: bench.py initialises the nccl process group with
+    device_id, and runs the barriers, the MAX all-reduce of the wall clock on a device tensor, (train) the trainer's broadcast and
+    bucket all-reduce, and destroy_process_group - the code of the N > 1 path, over RCCL, on the GPU that is there."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OARD_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "8",
+           "--quick", "--no-cpu-baseline"] + (["--mode", "train"] if mode == "train" else [])
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
