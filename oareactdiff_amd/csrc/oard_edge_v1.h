@@ -559,6 +559,7 @@ struct EquiStream {
 // with rbf_proj (cd [A+1][3][HP]) for the backward pass.
 // (Three slabs with the barrier inside the phase, as in k_gcl_edge_v1, were measured here too: 7.09-7.14 ms per step against
 // 7.10-7.13 ms - the phases of this kernel are twice as long and its barrier wait was small to begin with; not kept.)
+// (Two K blocks of T1 per phase - half of T1's barriers, 74-chunk slabs - : 7.26-7.33 against 7.09-7.11 ms; not kept either.)
 template <class D, int WAVES, bool TRAIN>
 __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                              const float* __restrict__ dp0b,
