@@ -67,6 +67,7 @@ int g_poison = 0;           // 1: fill the workspace with NaN bit patterns befor
 int g_parts = 0;            // sub-batches per topology (0 = auto: 4 for B >= 32, 2 for B >= 16, else 1)
 int g_small_split = 128;     // EquiMessage latency kernel: launches of <= this many 16-edge tiles run one launch per dense stage
                             // (a workgroup = 16 edges x 8 output tiles); 0 = never
+int g_wgrad_shapes = 3;       // bit k: workgroup shape kWglShapes[k] of the LDS-panel kernel may be chosen (A/B: debug option wgrad_shapes)
 int g_wgrad_lds = 256;       // workgroups per weight-gradient GEMM of the LDS-panel kernel (0: always the per-wave-tile kernel k_wgrad)
 int g_wgrad_wgs = 512;       // workgroups per weight-gradient GEMM (row chunks x task groups): one round of 2 x 4 waves per CU
                             // (measured per training step: 384 -> 38.1 ms, 512 -> 30.7, 768 -> 36.0, 1024 -> 33.2, 2048 -> 38.1)
@@ -698,7 +699,10 @@ static int equi_msg_backward_impl(const TopoDev& tp, const char* tape, const Tap
 // plan of the weight-gradient GEMM: a pure function of the shape, so that the summation order (and with it the result,
 // bit for bit) does not depend on anything else.  Q (16-wide tiles, no padding waste) is the narrower operand; when that is
 // dY the kernel produces the transposed product.
-struct WgradPlan { int transposed, NT, nPB, nQG, PP, QP, gy; long long rpc; int n_chunks; int lds; };
+struct WgradPlan { int transposed, NT, nPB, nQG, PP, QP, gy; long long rpc; int n_chunks; int lds, PBW, QGW; };
+// workgroup shapes of the LDS-panel kernel: NT tiles per Q group, PBW P blocks x QGW Q groups = the 8 tasks of a workgroup
+struct WglShape { int NT, PBW, QGW; };
+static const WglShape kWglShapes[2] = {{7, 4, 2}, {8, 4, 2}};
 static WgradPlan wgrad_plan(int ncY, int ncX, long long rows) {
     WgradPlan p;
     p.transposed = ncX > ncY ? 1 : 0;
@@ -712,12 +716,29 @@ static WgradPlan wgrad_plan(int ncY, int ncX, long long rows) {
     want = std::min(want, std::max<long long>(1, cdiv(rows, rows < 16384 ? 128 : 64)));      // short contractions: fewer, longer chunks (the partials dominate)
     p.rpc = align_up((size_t)cdiv(std::max<long long>(rows, 1), want), 4 * OARD_WG_PD);
     p.n_chunks = (int)cdiv(std::max<long long>(rows, 1), p.rpc);
-    // long contractions with at least two Q groups: the LDS-panel kernel (k_wgrad_lds), one 8-wave workgroup per CU and round;
-    // a workgroup owns 4 P blocks x 2 Q groups of a row chunk
-    p.lds = (g_wgrad_lds > 0 && rows >= 16384 && p.nQG >= 2) ? 1 : 0;
-    if (p.lds && (long long)p.nPB * p.nQG * 4 < cdiv(p.nPB, 4) * cdiv(p.nQG, 2) * 8 * 3) p.lds = 0;     // < 75 % of the wave slots would hold a task
+    // long contractions with at least two Q groups: the LDS-panel kernel (k_wgrad_lds), one 8-wave workgroup per CU and round; a
+    // workgroup owns PBW P blocks x QGW Q groups of a row chunk.  Of the shapes that fill >= 85 % of their wave slots with tasks the
+    // one that executes the fewest padded columns (P slots x 64) x (Q slots x 16 NT) is taken: 684 x 196 -> NT 7 (768 x 224);
+    // 684 x 588 -> NT 7 (768 x 672: 0.83 ms; NT 8, fewer padded Q tiles but a sixth, empty group slot: 768 x 768, 0.92 ms);
+    // 588 x 588 (83 % of the slots) stays on the per-wave kernel (0.86 ms; here 0.93).  Workgroups of 2 P blocks x 4 Q groups with
+    // NT 5 / 6 were measured too (684 x 588: 0.83 ms, 588 x 588: 0.96 ms): no better, not instantiated.
+    p.lds = 0; p.PBW = 4; p.QGW = 2;
+    if (g_wgrad_lds > 0 && rows >= 16384) {
+        long long best = -1;
+        for (int k = 0; k < 2; ++k) {
+            if (!((g_wgrad_shapes >> k) & 1)) continue;
+            const WglShape& c = kWglShapes[k];
+            const long long nQG = cdiv(nQT, c.NT);
+            if (nQG < 2) continue;
+            const long long sP = cdiv(p.nPB, c.PBW) * c.PBW, sQ = cdiv(nQG, c.QGW) * c.QGW;
+            if ((long long)p.nPB * nQG * 20 < sP * sQ * 17) continue;     // < 85 % of the wave slots would hold a task
+            const long long cost = sP * 64 * sQ * c.NT * 16;
+            if (best < 0 || cost < best) { best = cost; p.lds = 1; p.NT = c.NT; p.PBW = c.PBW; p.QGW = c.QGW; p.nQG = (int)nQG; }
+        }
+        if (p.lds) p.QP = p.nQG * p.NT * 16;
+    }
     if (p.lds) {
-        const long long tiles = cdiv(p.nPB, 4) * cdiv(p.nQG, 2);
+        const long long tiles = cdiv(p.nPB, p.PBW) * cdiv(p.nQG, p.QGW);
         long long w2 = std::max<long long>(1, g_wgrad_lds / tiles);
         w2 = std::min(w2, std::max<long long>(1, cdiv(rows, 4 * WGL_ROWS)));
         p.rpc = align_up((size_t)cdiv(rows, w2), WGL_ROWS);
@@ -1393,11 +1414,14 @@ static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, i
     float* psum = (db && !p.transposed) ? bpartial : nullptr;
     float* qsum = (db && p.transposed) ? bpartial : nullptr;
     if (p.lds) {
-#define WGL_LAUNCH(SILU_, NT_) do { constexpr size_t lds_ = (size_t)(2 * WGL_ROWS * 256 + 2 * WGL_ROWS * (16 * NT_ * 2 + 16)) * sizeof(float); \
-        LAUNCH_LDS(F_WGRAD, (k_wgrad_lds<SILU_, NT_, 4, 2>), p.n_chunks * p.gy, 512, lds_, st, Pm, ldP, ncP, Qm, ldQ, ncQ, 0LL, (long long)rows, \
-                   p.rpc, p.nPB, p.nQG, partial, psum, qsum); } while (0)
-        if (p.NT == 7) { if (x_silu) WGL_LAUNCH(true, 7); else WGL_LAUNCH(false, 7); }
-        else { if (x_silu) WGL_LAUNCH(true, 8); else WGL_LAUNCH(false, 8); }
+#define WGL_LAUNCH(SILU_, NT_, PBW_, QGW_) do { \
+        constexpr size_t lds_ = (size_t)(2 * WGL_ROWS * 64 * PBW_ + 2 * WGL_ROWS * (16 * NT_ * QGW_ + 16)) * sizeof(float); \
+        LAUNCH_LDS(F_WGRAD, (k_wgrad_lds<SILU_, NT_, PBW_, QGW_>), p.n_chunks * p.gy, 512, lds_, st, Pm, ldP, ncP, Qm, ldQ, ncQ, 0LL, \
+                   (long long)rows, p.rpc, p.nPB, p.nQG, partial, psum, qsum); } while (0)
+#define WGL_SHAPE(NT_, PBW_, QGW_) do { if (x_silu) WGL_LAUNCH(true, NT_, PBW_, QGW_); else WGL_LAUNCH(false, NT_, PBW_, QGW_); } while (0)
+        if (p.NT == 7) WGL_SHAPE(7, 4, 2);
+        else WGL_SHAPE(8, 4, 2);
+#undef WGL_SHAPE
 #undef WGL_LAUNCH
     } else {
         ScopedLaunch sl_(F_WGRAD, st);
@@ -1663,6 +1687,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "npb") == 0) { g_npb = value; return OARD_OK; }
     if (strcmp(name, "wgrad_wgs") == 0) { g_wgrad_wgs = value; return OARD_OK; }
     if (strcmp(name, "wgrad_lds") == 0) { g_wgrad_lds = value; return OARD_OK; }
+    if (strcmp(name, "wgrad_shapes") == 0) { g_wgrad_shapes = value & 3; return OARD_OK; }
     if (strcmp(name, "train_dual") == 0) { g_train_dual = value; return OARD_OK; }
     if (strcmp(name, "small_split") == 0) { g_small_split = value; return OARD_OK; }
     return OARD_EINVAL;
