@@ -452,7 +452,8 @@ def main():
     # per-kernel durations (HIP events on the launch stream), outside the timed region
     E, A = edge_counts(B, nf)
     roof = None
-    if rank == 0:
+    skip = set(filter(None, os.environ.get("OARD_BENCH_SKIP", "").split(",")))     # debugging: legs to leave out ("roofline", "sampler")
+    if rank == 0 and "roofline" not in skip:
         # Kernels are timed in isolation on the WHOLE batch (one sub-batch, nothing overlapping): that is the
         # figure a roofline fraction is about.  The timed region above runs the default schedule (4 concurrent
         # sub-batches), which is faster than the sum of the isolated kernels.
@@ -492,7 +493,7 @@ def main():
     # the real sampling loop (row N1): a genuine ancestral sampling run of T steps (T+1 network calls + fused sampler
     # kernel + RNG), timed end to end: the BASELINE metric's reactions/s, MEASURED (T = 1000 unless --quick)
     sampler_leg = train = None
-    if rank == 0 and world == 1 and not os.environ.get("OARD_BENCH_ALLOW_NAN"):      # N > 1: the other ranks wait in a barrier meanwhile
+    if rank == 0 and world == 1 and "sampler" not in skip and not os.environ.get("OARD_BENCH_ALLOW_NAN"):      # N > 1: the other ranks wait in a barrier meanwhile
         from oareactdiff_amd.sampler import DiffusionSampler
         frag = [torch.full((B,), nf, dtype=torch.long) for _ in range(3)]
         h0 = [x[:, 3:].clone() for x in inputs[0]]
@@ -514,6 +515,17 @@ def main():
                                "tail of this run is cheaper than the fixed-distribution steps of the headline value (SURVEY 8d)"}
     if rank == 0 and not args.quick and world == 1:
         dyn.nan_check = "async"
+        if os.environ.get("OARD_BENCH_EMPTY_CACHE", "1") != "0":
+            # the training step walks ~25 GB of tape / scratch per step; carved out of the caching allocator's left-overs of the legs
+            # above (next to their workspaces and topologies) it runs 5-8 % slower than `--mode train` does on fresh allocations
+            # (83 vs 77 ms measured), so the leg gets what that mode has: a fresh module and an allocator that starts empty
+            smp = warm = graphs = inputs = None
+            del dyn
+            torch.cuda.empty_cache()
+            dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
+                               condition_nf=1, device=dev)
+            dyn.load_state_dict(synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg), strict=True)
+            dyn.nan_check = "async"
         train, _ = train_leg(dyn, B, nf, dev, None, 1, 10, 3)      # warm-up as in `--mode train`
 
     if rank == 0:
