@@ -2,7 +2,6 @@
 graph) against the generic formulation (DiffusionLoss under torch autograd + torch.optim.AdamW) on recorded training steps of the
 reference (tests/golden/g9_grad_*.npz): same per-sample nll, same logged terms, same gradient bucket; the AdamW kernel against
 torch.optim.AdamW(amsgrad) on random gradients, with and without the clipping factor."""
-import ctypes as C
 
 import pytest
 import torch
