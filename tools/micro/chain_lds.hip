@@ -126,6 +126,69 @@ DEV f4 chain(const float* sl, int j0, const f4 (&in)[KB], f4 init, H hook) {
     return c0 + c1;
 }
 
+// WIDE: one wave per SIMD working on 32 columns - every A fragment feeds two B operands (16 MFMAs per pair of chunks)
+template <class H>
+DEV void chain_wide(const float* sl, int j0, const f4 (&in0)[KB], const f4 (&in1)[KB], f4 init, H hook, f4& r0, f4& r1) {
+    f4 c0 = init, c1 = (f4){0.f, 0.f, 0.f, 0.f}, d0 = init, d1 = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 a0 = lds_a(sl, j0), a1 = lds_a(sl, j0 + 1);
+#pragma unroll
+    for (int b = 0; b + 1 < KB; b += 2) {
+        f4 n0 = a0, n1 = a1;
+        if (b + 2 < KB) n0 = lds_a(sl, j0 + b + 2);
+        if (b + 3 < KB) n1 = lds_a(sl, j0 + b + 3);
+        mma_pair(a0, in0[b], c0, a1, in0[b + 1], c1);
+        mma_pair(a0, in1[b], d0, a1, in1[b + 1], d1);
+        hook(b);
+        a0 = n0; a1 = n1;
+    }
+    c0 = mma_chunk(a0, in0[KB - 1], c0);
+    d0 = mma_chunk(a0, in1[KB - 1], d0);
+    r0 = c0 + c1; r1 = d0 + d1;
+}
+template <int HOOK>
+__global__ __launch_bounds__(256, 1) void kw(float* out, const float* src, int iters) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 28 * 256];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 28 * 256; i += blockDim.x) smem[i] = src[i & 1023];
+    __syncthreads();
+    f4 in0[KB], in1[KB];
+    for (int b = 0; b < KB; ++b) { in0[b] = (f4){src[b], src[b + 1], src[b + 2], src[b + 3]}; in1[b] = in0[b] * 1.5f; }
+    const float* sl = smem + lane * 4;
+    f4 sum = (f4){0.f, 0.f, 0.f, 0.f};
+    PF pf;
+    pf.src = src; pf.dst = smem + 28 * 256; pf.lane_off = lane * 16u; pf.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (HOOK) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); pf.begin(28); }
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            f4 z0, z1;
+            if (HOOK) chain_wide(sl, gg * 14 + 1, in0, in1, lds_a(sl, gg * 14), HookPF{&pf}, z0, z1);
+            else chain_wide(sl, gg * 14 + 1, in0, in1, lds_a(sl, gg * 14), NoHook{}, z0, z1);
+            sum += z0 + z1;
+        }
+    }
+    const long long t1 = clock64();
+    if (lane == 0 && blockIdx.x == 0) atomicMax((unsigned long long*)out + 1, (unsigned long long)(t1 - t0));
+    if (sum.x == 12345.f) out[0] = sum.y;
+}
+template <int HOOK>
+void run_wide() {
+    float *out, *src; hipMalloc(&out, 64); hipMalloc(&src, 32 * 1024 * 4);
+    float h[1024]; for (int i = 0; i < 1024; ++i) h[i] = 1e-3f * (i % 7);
+    hipMemcpy(src, h, 4096, hipMemcpyHostToDevice);
+    const int iters = 4000;
+    kw<HOOK><<<256, 256>>>(out, src, 10);
+    hipDeviceSynchronize();
+    hipMemset(out, 0, 64);
+    kw<HOOK><<<256, 256>>>(out, src, iters);
+    hipDeviceSynchronize();
+    long long r[2]; hipMemcpy(r, out, 16, hipMemcpyDeviceToHost);
+    const double mfma = (double)iters * 2 * 104;
+    printf("wide wave (32 columns, one wave per SIMD) hook %d: %.1f %% of the 32-cycle MFMA rate (%lld cycles)\n", HOOK, 100.0 * 32 * mfma / r[1], r[1]);
+    hipFree(out); hipFree(src);
+}
+
 template <int MODE, int HOOK>
 __global__ __launch_bounds__(512, 2) void k(float* out, const float* src, int iters, int hook_at) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 28 * 256];
@@ -180,6 +243,7 @@ void run(int waves_per_simd) {
     hipFree(out); hipFree(src);
 }
 int main() {
+    run_wide<0>(); run_wide<1>();
     for (int w = 1; w <= 2; ++w) {
         run<3, 0>(w); run<3, 1>(w);
         run<0, 0>(w); run<0, 1>(w);
