@@ -12,6 +12,7 @@
 
 #include "oard_kernels.h"
 #include "oard_edge_v1.h"
+#include "oard_edge_b3.h"     // split-precision (3 x bf16, fp32 accumulate) variant of the GCL edge kernel: optional (debug option gcl_b3)
 #ifdef OARD_EXPERIMENTS
 #include "oard_edge_fp.h"     // barrier-free variant of the GCL kernel: measured slower (profiles/round2_gcl_phase_study.txt), experiment builds only
 #endif
@@ -73,6 +74,8 @@ int g_wgrad_wgs = 512;       // workgroups per weight-gradient GEMM (row chunks 
                             // (measured per training step: 384 -> 38.1 ms, 512 -> 30.7, 768 -> 36.0, 1024 -> 33.2, 2048 -> 38.1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
+int g_gcl_b3 = 0;           // 1: the throughput shape of the GCL edge stage runs in split precision (oard_edge_b3.h; inference only).  Read when
+                            //    the weights are packed (the bf16 stream is only built then) and when the stage is launched
 int g_skip_families = 0;    // timing experiments only (results are garbage): bit f set = launches of family f are dropped
 
 struct ScopedLaunch {
@@ -175,6 +178,10 @@ PackOff make_layout(const oard_config* c) {
         lo.l3u = take(593);
         lo.gcl_stream = take((size_t)(d.WB * d.HT + (d.HT + 1) * (d.HT + 1) + d.WB * (d.HT + 1)) * 256);
         lo.equi_stream = take((size_t)(d.WB * d.D1T + 3 * d.HT * (1 + d.D1T + d.RB)) * 256);
+        {   // GclB3Stream<D>::CHUNKS
+            const int nbh = (d.HT + 1) / 2, nbw = (d.WB + 1) / 2;
+            lo.gcl_b3 = take((size_t)(nbw * 3 * d.HT + (d.HT + 1) * (1 + 3 * nbh) + d.WB * (1 + 3 * nbh)) * 256);
+        }
     }
     po.total = cur;
     return po;
@@ -352,7 +359,13 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
         return OARD_OK;
     }
     switch (variant) {
-        case 2: GCL_RING3(false, GclTape{});
+        case 2:
+            if (g_gcl_b3) {
+                LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_b3<D, S1, S3>), cdiv(r1 - r0, 16 * 8), 8 * 64, (GclB3Stream<D>::LDS_BYTES), st, tp,
+                           wb + lo.gcl_b3, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf);
+                return OARD_OK;
+            }
+            GCL_RING3(false, GclTape{});
         GCL_CASE(3, 4, 2)      // 4 waves x 16 edges (two workgroups per CU): small launches
 #ifdef OARD_EXPERIMENTS        // A/B shapes, only in experiment builds (tools/ab_gcl.sh)
         GCL_CASE(7, 8, 2)      // the throughput shape with two slabs (barrier at the phase start; round 1 / 2)
@@ -857,6 +870,24 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
                        (float*)packed + po.c0row, H, d.H4, d.WP);
     hipLaunchKernelGGL(k_u0, dim3((unsigned)cdiv(d.HP, 64)), dim3(64), 0, st, params[pi.gcl0 + 0],
                        (const float*)packed + po.c0row, (float*)packed + po.u0, H, W, d.HP);
+    if (g_gcl_b3) {          // the split-precision stream of the GCL kernel, from the natural fp32 packs made above (oard_edge_b3.h)
+        const int nbh = (d.HT + 1) / 2, nbw = (d.WB + 1) / 2, G1 = 3 * d.HT, G2 = 1 + 3 * nbh;
+        const size_t G2f = (size_t)(d.HT + 1) * 256;                              // group stride of the fp32 stream's S2 / S3 (bias chunk first)
+        for (int l = 0; l < c->num_layers; ++l) {
+            const LayerOff& lo = po.layer[l];
+            const size_t s1 = lo.gcl_b3, s2 = s1 + (size_t)nbw * G1 * 256, s3 = s2 + (size_t)(d.HT + 1) * G2 * 256;
+            const size_t f2 = lo.gcl_stream + (size_t)d.WB * d.HT * 256, f3 = f2 + (size_t)(d.HT + 1) * G2f;
+            B3Jobs jb;
+            jb.j[0] = B3Job{lo.W1c, d.WB, d.HT, nbw, 0, s1, (size_t)3 * 256, (size_t)G1 * 256};                // S1: K-outer
+            jb.j[1] = B3Job{lo.W2, d.HT, d.HT, nbh, 0, s2 + 256, (size_t)G2 * 256, (size_t)3 * 256};           // S2: W2 tiles
+            jb.j[2] = B3Job{lo.watt, d.HT, 1, nbh, 1, s2 + (size_t)d.HT * G2 * 256 + 256, (size_t)G2 * 256, (size_t)3 * 256};   // gate row
+            jb.j[3] = B3Job{lo.W3, d.HT, d.WB, nbh, 0, s3 + 256, (size_t)G2 * 256, (size_t)3 * 256};           // S3: W3 tiles
+            const long long work = std::max<long long>((long long)d.HT * nbw, (long long)d.WB * nbh) * 64;
+            hipLaunchKernelGGL(k_pack_b3, dim3((unsigned)cdiv(work, 256), 4), dim3(256), 0, st, jb, (float*)packed);
+            hipLaunchKernelGGL(k_copy_chunks, dim3((unsigned)(d.HT + 1)), dim3(256), 0, st, (float*)packed, f2, G2f, s2, (size_t)G2 * 256, d.HT + 1);
+            hipLaunchKernelGGL(k_copy_chunks, dim3((unsigned)d.WB), dim3(256), 0, st, (float*)packed, f3, G2f, s3, (size_t)G2 * 256, d.WB);
+        }
+    }
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
@@ -1679,6 +1710,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
     if (strcmp(name, "skip_families") == 0) { g_skip_families = value; return OARD_OK; }
+    if (strcmp(name, "gcl_b3") == 0) { g_gcl_b3 = value != 0; return OARD_OK; }
     if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
     if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }
     if (strcmp(name, "poison") == 0) { g_poison = value; return OARD_OK; }

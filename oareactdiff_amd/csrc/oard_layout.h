@@ -41,6 +41,7 @@ struct LayerOff {
     size_t vp, xv0, xv2, l3u;   // l3u raw: w0[48*3] b0[48] w2[8*48] b2[8] w4[8] b4[1]
     // LDS weight streams of the two hot edge kernels, chunks in consumption order (oard_edge_v1.h)
     size_t gcl_stream, equi_stream;
+    size_t gcl_b3;              // split-precision stream of the GCL kernel (oard_edge_b3.h); built only when that kernel is enabled
 };
 struct PackOff {
     size_t emb, emb_b, nbemb, nbemb_b, s2v, s2v_b, rl0, rl0_b, rl2, rl2_b;
