@@ -323,7 +323,7 @@ def main():
                     help="sample: one denoising call per step (BASELINE configs 2/3); train: one training step (config 4)")
     ap.add_argument("--quick", action="store_true", help="skip the full T=1000 sampling run and the training leg")
     ap.add_argument("--precision", choices=("f32", "bf16x3"), default="f32",
-                    help="bf16x3: the SECOND line - the GCL edge stage on the split-precision kernel (three bf16 terms per fp32 value, six "
+                    help="bf16x3: the SECOND line - the two edge stages on the split-precision kernels (three bf16 terms per fp32 value, six "
                          "bf16 MFMAs per K block, fp32 accumulation: fp32-grade results, csrc/oard_edge_b3.h); inference only; the "
                          "fp32 kernels stay the default and the headline")
     ap.add_argument("--no-graph", action="store_true", help="launch-bound batches (B <= 8): eager launches instead of hipGraph replay")
@@ -371,6 +371,7 @@ def main():
         if args.mode == "train":
             sys.exit("bench.py: --precision bf16x3 is an inference formulation (no tape / backward kernels)")
         _capi.check(_capi.lib().oard_debug_option(b"gcl_b3", 1), "gcl_b3")       # read when the weights are packed and at every launch
+        _capi.check(_capi.lib().oard_debug_option(b"equi_b3", 1), "equi_b3")
     dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
                        condition_nf=1, device=dev)
     dyn.load_state_dict(synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg), strict=True)
@@ -498,9 +499,9 @@ def main():
                 "other_kernel": {"kernel": "k_" + oth, "achieved": flops[oth] / (fam[oth]["ms_per_step"] * 1e-3) / 1e12,
                                  "algorithmic_flops_per_step": flops[oth], "kernel_ms_per_step": fam[oth]["ms_per_step"]}}
         if args.precision == "bf16x3":
-            roof["precision_note"] = ("the gcl_edge family runs on bf16 MFMAs (v_mfma_f32_16x16x32_bf16, dense peak ~2.5 PFLOP/s; six instructions per "
+            roof["precision_note"] = ("the gcl_edge and equi_edge families run on bf16 MFMAs (v_mfma_f32_16x16x32_bf16, dense peak ~2.5 PFLOP/s; six instructions per "
                                       "16 x 16 x 32 block of the fp32 product): its 'achieved' counts the ALGORITHMIC fp32 FLOPs per second, not "
-                                      "executed bf16 FLOPs; `peak` / `frac` refer to the fp32 kernel named in `kernel`")
+                                      "executed bf16 FLOPs, against the fp32 MFMA peak (so `frac` may exceed what an fp32 kernel can reach)")
 
     # the real sampling loop (row N1): a genuine ancestral sampling run of T steps (T+1 network calls + fused sampler
     # kernel + RNG), timed end to end: the BASELINE metric's reactions/s, MEASURED (T = 1000 unless --quick)
@@ -547,7 +548,7 @@ def main():
             "metric": "denoising_steps_per_sec", "value": value, "unit": "reaction-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32 via bf16x3 (GCL edge stage: 3 bf16 terms per value, 6 bf16 MFMAs per K block, fp32 accumulate; everything else f32)",
+            "dtype": "f32" if args.precision == "f32" else "f32 via bf16x3 (the two edge stages: 3 bf16 terms per value, 6 bf16 MFMAs per K block, fp32 accumulate; everything else f32)",
             "data": "synthetic",
             "config": {"workload": f"EGNNDynamics.forward (LEFTNet H=196 R=96 L=6), B={B} reactions/GPU x 3 objects x "
                                    f"{nf} atoms, complete graph per reaction (N={B * 3 * nf}, E={E}), T=1000 sampler step shape",

@@ -71,7 +71,7 @@ OARD_DEV f4 chain_tile_b3(const float* sl, int j0, const bf8 (&Bh)[NB], const bf
 // K-outer: acc[t] += the six products of tile t's chunks (slots j0 + 3 t ..) with one K block of the B operand; tiles in pairs so
 // that consecutive MFMAs never depend on each other
 template <int MT, class Hook>
-OARD_DEV void chain_kouter_b3(const float* sl, int j0, bf8 xh, bf8 xm, bf8 xl, f4 (&acc)[MT], Hook hook) {
+OARD_DEV void chain_kouter_b3(const float* sl, int j0, bf8 xh, bf8 xm, bf8 xl, f4* acc, Hook hook) {
     bf8 ah0 = lds_b3(sl, j0), am0 = lds_b3(sl, j0 + 1), al0 = lds_b3(sl, j0 + 2);
     bf8 ah1 = ah0, am1 = am0, al1 = al0;
     if (MT > 1) { ah1 = lds_b3(sl, j0 + 3); am1 = lds_b3(sl, j0 + 4); al1 = lds_b3(sl, j0 + 5); }
@@ -257,6 +257,149 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
     for (int gg = 0; gg < GP; ++gg) {
         const int t = (S::NP3 - 1) * GP + gg;
         if (t < WB) st_f4(orow + 16 * t, pend[gg]);
+    }
+}
+
+// =====================================================================================================================================
+// EquiMessage edge part in split precision (inner edges): q[a][third][feature] = dir_proj(ew) * rbf_proj(rbf), as k_equi_edge_v1.
+// Every stage runs K-OUTER, so that only ONE K block of the B operand is held as bf16 terms at a time:
+//   T1   d1[37 tiles] = dp0b + dir_proj.0 . ew           22 K blocks of the edge state
+//        d1 = SiLU(d1) goes to a scratch array in the wave's own lane order (fp32, 1 KiB per tile) - 37 tiles of d1 as three bf16 terms
+//        (228 registers) next to 39 output accumulators do not fit, d1 in fp32 next to them neither
+//   T2a  cr[39 tiles] = rbf_proj . rbf                     3 K blocks; stored to q (its final place), re-read at the end
+//   T2b  cd[39 tiles] = dp2b + dir_proj.2 . d1            19 K blocks, each read back from the scratch array one phase ahead
+//   q = cd * cr
+// A K block's chunks (tiles x 3) exceed an LDS slab, so a K block is two phases (tile halves); two slabs, barrier at the phase start.
+// Stream: T1 = NBW x (D1T x 3);  T2a = NBR x (NO x 3);  T2b = NBD x (NO x 3)   (NO = 3 HT output tiles, third-major).
+// =====================================================================================================================================
+template <class D>
+struct EquiB3Stream {
+    static constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT, NO = 3 * HT;
+    static constexpr int NBW = (WB + 1) / 2, NBR = (RB + 1) / 2, NBD = (D1T + 1) / 2;
+    static constexpr int H1A = (D1T + 1) / 2, H1B = D1T - H1A;         // tile halves of T1 (19 + 18)
+    static constexpr int H2A = (NO + 1) / 2, H2B = NO - H2A;           // of T2 (20 + 19)
+    static constexpr int G1 = 3 * D1T, G2 = 3 * NO;
+    static constexpr int SLAB = 3 * (H1A > H2A ? H1A : H2A);
+    static constexpr int C1 = NBW * G1, C2A = NBR * G2, C2B = NBD * G2, CHUNKS = C1 + C2A + C2B;
+    static constexpr int NPH = 2 * (NBW + NBR + NBD);
+    static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
+};
+
+template <class D>
+__global__ __launch_bounds__(512, 2) void k_equi_edge_b3(TopoDev tp, const float* __restrict__ stream, const float* __restrict__ dp0b,
+                                                         const float* __restrict__ dp2b, const float* __restrict__ ew,
+                                                         const float* __restrict__ rbuf, float* __restrict__ qbuf,
+                                                         float* __restrict__ d1s) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using S = EquiB3Stream<D>;
+    constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT, NO = S::NO, WAVES = 8;
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SlabPrefetch<WAVES, S::SLAB, 0, 2> pf;
+    pf.wave = wave;
+    pf.lane_off = (unsigned)lane * 16u;
+    // phase p: (stage, K block kb, half h) -> chunk range
+    auto pf_begin = [&](int p) {
+        int start = 0, n = 0;
+        if (p < 2 * S::NBW) { const int kb = p >> 1, h = p & 1; start = kb * S::G1 + (h ? 3 * S::H1A : 0); n = 3 * (h ? S::H1B : S::H1A); }
+        else if (p < 2 * (S::NBW + S::NBR)) { const int q = p - 2 * S::NBW, kb = q >> 1, h = q & 1;
+                                              start = S::C1 + kb * S::G2 + (h ? 3 * S::H2A : 0); n = 3 * (h ? S::H2B : S::H2A); }
+        else if (p < S::NPH) { const int q = p - 2 * (S::NBW + S::NBR), kb = q >> 1, h = q & 1;
+                               start = S::C1 + S::C2A + kb * S::G2 + (h ? 3 * S::H2A : 0); n = 3 * (h ? S::H2B : S::H2A); }
+        pf.begin(stream, smem, p, start, n);
+    };
+    auto hook = [&]() { pf.tick(); };
+    auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
+
+    const long long wt = (long long)blockIdx.x * WAVES + wave;           // this wave's 16-edge tile
+    const long long c = wt * 16 + (lane & 15);
+    const size_t a = (size_t)(c < tp.A ? c : tp.A);                       // padding columns use the spare entry A
+    const float* erow = ew + (c < tp.A ? a : (size_t)tp.E) * D::WP + 4 * g;
+    const float* rrow = rbuf + a * D::RP + 4 * g;
+    float* d1w = d1s + (size_t)wt * D1T * 256 + lane * 4;                 // [tile t][lane]: this lane's f4 of d1 tile t
+    auto ld_pair = [&](const float* row, int kb, int nblk, f4& x, f4& y) {
+        x = ld_f4(row + 32 * kb);
+        y = (2 * kb + 1 < nblk) ? ld_f4(row + 32 * kb + 16) : f4zero();
+    };
+    int p = 0;
+    f4 xa, xb;
+    ld_pair(erow, 0, WB, xa, xb);
+    pf_begin(0);
+    pf.flush();
+    {   // ---- T1 ----
+        f4 d1[D1T];
+#pragma unroll
+        for (int t = 0; t < D1T; ++t) d1[t] = ld_vec(dp0b, t, lane);
+        for (int kb = 0; kb < S::NBW; ++kb) {
+            bf8 xh, xm, xl;
+            split3(xa, xb, xh, xm, xl);
+            phase_barrier();
+            pf_begin(p + 1);
+            if (kb + 1 < S::NBW) ld_pair(erow, kb + 1, WB, xa, xb);
+            chain_kouter_b3<S::H1A>(SL(p), 0, xh, xm, xl, d1, hook);
+            pf.flush();
+            ++p;
+            phase_barrier();
+            pf_begin(p + 1);
+            chain_kouter_b3<S::H1B>(SL(p), 0, xh, xm, xl, d1 + S::H1A, hook);
+            pf.flush();
+            ++p;
+        }
+#pragma unroll
+        for (int t = 0; t < D1T; ++t) st_f4(d1w + t * 256, silu4(d1[t]));
+    }
+    f4 acc[NO];
+    {   // ---- T2a: cr = rbf_proj . rbf ----
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] = f4zero();
+        ld_pair(rrow, 0, RB, xa, xb);
+        for (int kb = 0; kb < S::NBR; ++kb) {
+            bf8 xh, xm, xl;
+            split3(xa, xb, xh, xm, xl);
+            phase_barrier();
+            pf_begin(p + 1);
+            if (kb + 1 < S::NBR) ld_pair(rrow, kb + 1, RB, xa, xb);
+            else { xa = ld_f4(d1w); xb = (D1T > 1) ? ld_f4(d1w + 256) : f4zero(); }      // first K block of T2b (d1 tiles 0, 1)
+            chain_kouter_b3<S::H2A>(SL(p), 0, xh, xm, xl, acc, hook);
+            pf.flush();
+            ++p;
+            phase_barrier();
+            pf_begin(p + 1);
+            chain_kouter_b3<S::H2B>(SL(p), 0, xh, xm, xl, acc + S::H2A, hook);
+            pf.flush();
+            ++p;
+        }
+    }
+    float* qrow = qbuf + a * (size_t)(3 * D::HP) + 4 * g;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {                                        // cr -> q (re-read below), accumulators <- bias of dir_proj.2
+        st_f4(qrow + (o / HT) * D::HP + 16 * (o % HT), acc[o]);
+        acc[o] = ld_vec(dp2b, o, lane);
+    }
+    {   // ---- T2b: cd = dp2b + dir_proj.2 . d1 ----
+        for (int kb = 0; kb < S::NBD; ++kb) {
+            bf8 xh, xm, xl;
+            split3(xa, xb, xh, xm, xl);
+            phase_barrier();
+            pf_begin(p + 1);
+            if (kb + 1 < S::NBD) {
+                xa = ld_f4(d1w + (2 * kb + 2) * 256);
+                xb = (2 * kb + 3 < D1T) ? ld_f4(d1w + (2 * kb + 3) * 256) : f4zero();
+            }
+            chain_kouter_b3<S::H2A>(SL(p), 0, xh, xm, xl, acc, hook);
+            pf.flush();
+            ++p;
+            phase_barrier();
+            pf_begin(p + 1);
+            chain_kouter_b3<S::H2B>(SL(p), 0, xh, xm, xl, acc + S::H2A, hook);
+            pf.flush();
+            ++p;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        float* q = qrow + (o / HT) * D::HP + 16 * (o % HT);
+        st_f4(q, acc[o] * ld_f4(q));
     }
 }
 

@@ -76,6 +76,7 @@ int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
 int g_gcl_b3 = 0;           // 1: the throughput shape of the GCL edge stage runs in split precision (oard_edge_b3.h; inference only).  Read when
                             //    the weights are packed (the bf16 stream is only built then) and when the stage is launched
+int g_equi_b3 = 0;          // the same for the EquiMessage edge stage (k_equi_edge_b3)
 int g_skip_families = 0;    // timing experiments only (results are garbage): bit f set = launches of family f are dropped
 
 struct ScopedLaunch {
@@ -181,6 +182,8 @@ PackOff make_layout(const oard_config* c) {
         {   // GclB3Stream<D>::CHUNKS
             const int nbh = (d.HT + 1) / 2, nbw = (d.WB + 1) / 2;
             lo.gcl_b3 = take((size_t)(nbw * 3 * d.HT + (d.HT + 1) * (1 + 3 * nbh) + d.WB * (1 + 3 * nbh)) * 256);
+            // EquiB3Stream<D>::CHUNKS
+            lo.equi_b3 = take((size_t)(nbw * 3 * d.D1T + ((d.RB + 1) / 2 + (d.D1T + 1) / 2) * 9 * d.HT) * 256);
         }
     }
     po.total = cur;
@@ -306,6 +309,7 @@ static WsOff make_ws(const oard_config* c, const TopoDev& td) {
     w.dpos = take(N * 3 * 4); w.hout = take(N * 16 * 4);
     // scratch of the stage-split latency edge kernels: only topologies small enough to ever take that path (the launch-shape
     // thresholds are run-time options, so the launch re-checks that the buffers exist)
+    w.d1s = take((size_t)cdiv((long long)td.A, 128) * 8 * d.D1T * 1024);
     w.small_a = w.small_b = 0;
     if (E <= (size_t)OARD_SMALL_MAX_EDGES) {
         w.small_a = take(A * d.D1P * 4);
@@ -407,7 +411,7 @@ int launch_gcl_v1(int variant, int conc, const TopoDev& tp, const float* wb, con
                    tp, stream, dp0b, ew, rbuf, qbuf, nullptr, nullptr); return OARD_OK; }
 template <class D>
 int launch_equi_v1(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* dp0b, const float* ew,
-                   const float* rbuf, float* qbuf, float* zd1, float* cd, hipStream_t st) {
+                   const float* rbuf, float* qbuf, float* zd1, float* cd, hipStream_t st, float* d1s = nullptr) {
     if (zd1) {                   // training-mode forward
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, 8, true>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiStream<D>::LDS_BYTES), st,
                    tp, stream, dp0b, ew, rbuf, qbuf, zd1, cd);
@@ -426,6 +430,11 @@ int launch_equi_v1(int variant, int conc, const TopoDev& tp, const float* wb, co
         }
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_small<D, 8>), cdiv(tp.A, 16), 512, (EquiSmall<D>::LDS_BYTES), st,
                    tp, wb, lo, ew, rbuf, qbuf);
+        return OARD_OK;
+    }
+    if (variant == 2 && g_equi_b3 && d1s) {      // split precision (oard_edge_b3.h): the throughput shape only
+        LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_b3<D>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiB3Stream<D>::LDS_BYTES), st, tp, wb + lo.equi_b3,
+                   dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s);
         return OARD_OK;
     }
     switch (variant) {
@@ -593,7 +602,8 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
         } else {
             if (A > 0) {
                 int rc = launch_equi_v1<D>(equi_variant, topo->conc, tp, wb, lo, wb + lo.equi_stream, wb + lo.dp0b, ew_out, rbuf, vmsg,
-                                           train ? (float*)(tape + to.zd1[l]) : nullptr, train ? (float*)(tape + to.cd[l]) : nullptr, st);
+                                           train ? (float*)(tape + to.zd1[l]) : nullptr, train ? (float*)(tape + to.cd[l]) : nullptr, st,
+                                           train ? nullptr : (float*)(ws + w.d1s));
                 if (rc != OARD_OK) return rc;
             }
             if (nv1 && rows) {
@@ -886,6 +896,20 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
             hipLaunchKernelGGL(k_pack_b3, dim3((unsigned)cdiv(work, 256), 4), dim3(256), 0, st, jb, (float*)packed);
             hipLaunchKernelGGL(k_copy_chunks, dim3((unsigned)(d.HT + 1)), dim3(256), 0, st, (float*)packed, f2, G2f, s2, (size_t)G2 * 256, d.HT + 1);
             hipLaunchKernelGGL(k_copy_chunks, dim3((unsigned)d.WB), dim3(256), 0, st, (float*)packed, f3, G2f, s3, (size_t)G2 * 256, d.WB);
+        }
+    }
+    if (g_equi_b3) {         // the split-precision stream of the EquiMessage kernel: three K-outer sections
+        const int nbw = (d.WB + 1) / 2, nbr = (d.RB + 1) / 2, nbd = (d.D1T + 1) / 2, NO = 3 * d.HT, G1 = 3 * d.D1T, G2 = 3 * NO;
+        for (int l = 0; l < c->num_layers; ++l) {
+            const LayerOff& lo = po.layer[l];
+            const size_t t1 = lo.equi_b3, t2a = t1 + (size_t)nbw * G1 * 256, t2b = t2a + (size_t)nbr * G2 * 256;
+            B3Jobs jb;
+            jb.j[0] = B3Job{lo.dp0, d.WB, d.D1T, nbw, 0, t1, (size_t)3 * 256, (size_t)G1 * 256};
+            jb.j[1] = B3Job{lo.rbfp, d.RB, NO, nbr, 0, t2a, (size_t)3 * 256, (size_t)G2 * 256};
+            jb.j[2] = B3Job{lo.dp2, d.D1T, NO, nbd, 0, t2b, (size_t)3 * 256, (size_t)G2 * 256};
+            jb.j[3] = B3Job{0, 0, 0, 0, 0, 0, 0, 0};
+            const long long work = std::max<long long>((long long)d.D1T * nbw, (long long)NO * nbd) * 64;
+            hipLaunchKernelGGL(k_pack_b3, dim3((unsigned)cdiv(work, 256), 3), dim3(256), 0, st, jb, (float*)packed);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1711,6 +1735,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
     if (strcmp(name, "skip_families") == 0) { g_skip_families = value; return OARD_OK; }
     if (strcmp(name, "gcl_b3") == 0) { g_gcl_b3 = value != 0; return OARD_OK; }
+    if (strcmp(name, "equi_b3") == 0) { g_equi_b3 = value != 0; return OARD_OK; }
     if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
     if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }
     if (strcmp(name, "poison") == 0) { g_poison = value; return OARD_OK; }

@@ -41,7 +41,7 @@ struct LayerOff {
     size_t vp, xv0, xv2, l3u;   // l3u raw: w0[48*3] b0[48] w2[8*48] b2[8] w4[8] b4[1]
     // LDS weight streams of the two hot edge kernels, chunks in consumption order (oard_edge_v1.h)
     size_t gcl_stream, equi_stream;
-    size_t gcl_b3;              // split-precision stream of the GCL kernel (oard_edge_b3.h); built only when that kernel is enabled
+    size_t gcl_b3, equi_b3;     // split-precision streams of the two edge kernels (oard_edge_b3.h); built only when those kernels are enabled
 };
 struct PackOff {
     size_t emb, emb_b, nbemb, nbemb_b, s2v, s2v_b, rl0, rl0_b, rl2, rl2_b;
@@ -101,5 +101,6 @@ struct oard_topology {
 struct WsOff {
     size_t pos, pf64, pf32, x1, pp0, labels, hin, zemb, nb, s, s1, ne1, xh, P, Q, xq, vec, vec2, v2buf, sc0, vdot,
         geo, d64, rbuf, ew, mbuf, xmsg, vmsg, dpos, hout, total;   // xmsg..vmsg double as qbuf [A][3][HP] (v1)
+    size_t d1s;                    // split-precision EquiMessage kernel: SiLU(d1) in wave-tile order, [ceil(A / 128) * 8][D1T][256] floats
     size_t small_a, small_b;       // stage-split EquiMessage latency path: d1 [A+1][D1P]; 0 = not allocated (large topologies)
 };

@@ -1,4 +1,4 @@
-"""The optional split-precision GCL edge kernel (csrc/oard_edge_b3.h: every fp32 value as three bf16 terms, six bf16 MFMAs per
+"""The optional split-precision edge kernels (GCL and EquiMessage, csrc/oard_edge_b3.h: every fp32 value as three bf16 terms, six bf16 MFMAs per
 K block, fp32 accumulation) against the same bar as the fp32 kernel: the reference evaluated in float64, <= 1e-5 of the largest
 output, on every golden case in the throughput launch shapes and inside the B = 64 launch bench.py times.  The option is read when
 the weights are packed, so every case builds a fresh module inside the option's scope.  (OARD_GCL_B3=1 runs the WHOLE GPU suite on
@@ -19,7 +19,7 @@ def test_split_precision_forward_matches_reference_f64(name):
     c = Case(name)
     with torch.no_grad():
         out32, _ = _dyn(c, dev)(*_args(c, dev))                       # the fp32 kernels (suite default)
-        with debug_options(gcl_b3=1):
+        with debug_options(gcl_b3=1, equi_b3=1):
             out, _ = _dyn(c, dev)(*_args(c, dev))
     v, h = c.split([o.cpu() for o in out])
     v32, h32 = c.split([o.cpu() for o in out32])
@@ -39,7 +39,7 @@ def test_split_precision_benched_launch(parts):
     dev = torch.device("cuda:0")
     c = Case("g2_prod_b2_n23")
     B, nf = 64, 23
-    with debug_options(parts=parts, gcl_b3=1):
+    with debug_options(parts=parts, gcl_b3=1, equi_b3=1):
         dyn, _, _ = _prod_dynamics(dev, c.cfg)
         cm, nfs, ei, masks = make_topology(B, nf)
         xh = make_inputs(B, nf, masks, 99, "cpu")
