@@ -18,7 +18,8 @@ def test_split_precision_forward_matches_reference_f64(name):
     dev = torch.device("cuda:0")
     c = Case(name)
     with torch.no_grad():
-        out32, _ = _dyn(c, dev)(*_args(c, dev))                       # the fp32 kernels (suite default)
+        with debug_options(gcl_b3=0, equi_b3=0):
+            out32, _ = _dyn(c, dev)(*_args(c, dev))                   # the fp32 kernels
         with debug_options(gcl_b3=1, equi_b3=1):
             out, _ = _dyn(c, dev)(*_args(c, dev))
     v, h = c.split([o.cpu() for o in out])
