@@ -21,6 +21,12 @@
 #include "oard_edge_v1.h"
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+#ifndef OARD_B3_HALF
+#define OARD_B3_HALF 1          // LDS-DMA issue policy of k_gcl_edge_b3 (see SlabPrefetch): waves 0..3 only / every hook
+#endif
+#ifndef OARD_B3_PERIOD
+#define OARD_B3_PERIOD 1
+#endif
 
 template <class D>
 struct GclB3Stream {
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
     static_assert(HT >= 2, "the phase barrier sits inside the first chain of a phase");
     const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SlabPrefetch<WAVES, S::SLAB, 1, 1, 3> pf;
+    SlabPrefetch<WAVES, S::SLAB, OARD_B3_HALF, OARD_B3_PERIOD, 3> pf;
     pf.wave = wave;
     pf.lane_off = (unsigned)lane * 16u;
     auto pf_begin = [&](int p) {
