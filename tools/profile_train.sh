@@ -10,19 +10,19 @@ unset OARD_PARTS
 T="python bench.py --mode train --warmup 1"
 python bench.py --mode train --steps 10 --warmup 3 > gpurun_out/${tag}_train_bench_line.json 2>/dev/null
 export OARD_TRAIN_DUAL=0
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_ttrace -o t -- $T --steps 3 > gpurun_out/${tag}_ttrace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_ttrace -o t -- $T --steps 3 > gpurun_out/${tag}_ttrace.log 2>&1
 python tools/prof_summary.py gpurun_out/${tag}_ttrace/t_results.db > gpurun_out/${tag}_train_kernel_trace_summary.txt
 grep '"metric"' gpurun_out/${tag}_ttrace.log | tail -1 > gpurun_out/${tag}_train_bench_line_under_profiler.json
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_ttrace13 -o t -- $T --steps 13 > gpurun_out/${tag}_ttrace13.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_ttrace13 -o t -- $T --steps 13 > gpurun_out/${tag}_ttrace13.log 2>&1
 python tools/prof_summary.py gpurun_out/${tag}_ttrace13/t_results.db > gpurun_out/${tag}_train_kernel_trace_summary_13steps.txt
 python tools/launch_diff.py gpurun_out/${tag}_train_kernel_trace_summary.txt gpurun_out/${tag}_train_kernel_trace_summary_13steps.txt 10 > gpurun_out/${tag}_train_launches_per_step.txt
 rm -rf gpurun_out/${tag}_ttrace gpurun_out/${tag}_ttrace13
 TK="k_wgrad k_gcl_edge_bwd k_equi_edge_bwd k_gcl_edge_v1 k_equi_edge_v1"
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT -d gpurun_out/${tag}_tsq -o p -- $T --steps 3 > gpurun_out/${tag}_tsq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT -d gpurun_out/${tag}_tsq -o p -- $T --steps 3 > gpurun_out/${tag}_tsq.log 2>&1
 python tools/pmc_summary.py gpurun_out/${tag}_tsq/p_results.db --per-forward 1 $TK > gpurun_out/${tag}_train_pmc_sq.txt
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_tfetch -o p -- $T --steps 3 > gpurun_out/${tag}_tfetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_tfetch -o p -- $T --steps 3 > gpurun_out/${tag}_tfetch.log 2>&1
 python tools/pmc_summary.py gpurun_out/${tag}_tfetch/p_results.db --per-forward 1 $TK > gpurun_out/${tag}_train_pmc_fetch.txt
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${tag}_twrite -o p -- $T --steps 3 > gpurun_out/${tag}_twrite.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${tag}_twrite -o p -- $T --steps 3 > gpurun_out/${tag}_twrite.log 2>&1
 python tools/pmc_summary.py gpurun_out/${tag}_twrite/p_results.db --per-forward 1 $TK > gpurun_out/${tag}_train_pmc_write.txt
 rm -rf gpurun_out/${tag}_tsq gpurun_out/${tag}_tfetch gpurun_out/${tag}_twrite
 cat gpurun_out/${tag}_train_launches_per_step.txt | head -30; cat gpurun_out/${tag}_train_pmc_sq.txt gpurun_out/${tag}_train_pmc_fetch.txt gpurun_out/${tag}_train_pmc_write.txt
