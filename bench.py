@@ -370,12 +370,12 @@ def main():
     if args.precision == "bf16x3":
         if args.mode == "train":
             sys.exit("bench.py: --precision bf16x3 is an inference formulation (no tape / backward kernels)")
-        _capi.check(_capi.lib().oard_debug_option(b"gcl_b3", 1), "gcl_b3")       # read when the weights are packed and at every launch
-        _capi.check(_capi.lib().oard_debug_option(b"equi_b3", 1), "equi_b3")
     dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
                        condition_nf=1, device=dev)
     dyn.load_state_dict(synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg), strict=True)
     dyn.nan_check = "async"                 # no host sync inside the step
+    if args.precision == "bf16x3":
+        dyn.edge_precision = "bf16x3"       # the split-precision edge kernels for this module's inference calls
     cm, nfs, ei, masks = make_topology(B, nf)
     cm, nfs, ei = cm.to(dev), nfs.to(dev), ei.to(dev)
     # a few fixed-distribution input sets, resident in HBM, cycled per step (fresh noise each step)

@@ -141,6 +141,12 @@ class EGNNDynamics(nn.Module):
         #: "async": no host sync; the device-side flag of the last call is kept in `self.last_status` and OR-ed into
         #: the sticky flag `self.nan_seen` (reset it with `reset_nan_seen()`; the sampling loops read it once at the end).
         self.nan_check = "sync"
+        #: Arithmetic of the two MFMA edge stages in INFERENCE calls.  None: whatever the library options say (default fp32; the
+        #: environment switches OARD_GCL_B3 / OARD_EQUI_B3).  "f32": the fp32 kernels.  "bf16x3": the split-precision kernels
+        #: (csrc/oard_edge_b3.h: three bf16 terms per fp32 value, six bf16 MFMAs per K block, fp32 accumulation - fp32-grade
+        #: results, ~1.3 x the step rate at B = 64).  The choice is applied before every call (the library options are
+        #: process-wide) and is part of the packed-weights key.  Training calls always use fp32.
+        self.edge_precision: Optional[str] = None
         self.last_status: Optional[Tensor] = None
         self.nan_seen: Optional[Tensor] = None
         self._packed: Optional[Tensor] = None
@@ -182,10 +188,16 @@ class EGNNDynamics(nn.Module):
 
     def _get_packed(self, cfg: _capi.OardConfig, stream: int) -> Tensor:
         tensors = self._ordered_tensors()
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        L = _capi.lib()
+        if self.edge_precision is not None:
+            if self.edge_precision not in ("f32", "bf16x3"):
+                raise ValueError("edge_precision must be None, 'f32' or 'bf16x3'")
+            b3 = 1 if self.edge_precision == "bf16x3" else 0
+            _capi.check(L.oard_debug_option(b"gcl_b3", b3), "gcl_b3")
+            _capi.check(L.oard_debug_option(b"equi_b3", b3), "equi_b3")
+        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.edge_precision,)
         if self._packed is not None and key == self._packed_key:
             return self._packed
-        L = _capi.lib()
         dev = tensors[0].device
         for t in tensors:
             if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():

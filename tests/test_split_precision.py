@@ -57,3 +57,28 @@ def test_split_precision_benched_launch(parts):
         v, h = c.split([o[slot0 * nf:(slot0 + 2) * nf].cpu() for o in out])
         print(f"parts={parts} slots {slot0},{slot0 + 1}: vel {rel(v, rv):.2e} h {rel(h, rh):.2e}")
         assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
+
+
+def test_edge_precision_attribute_switches_kernels_per_module():
+    """`EGNNDynamics.edge_precision`: "bf16x3" / "f32" select the kernels for that module's calls (and repack its weights when the
+    choice changes); two modules with different choices can be used alternately."""
+    from oareactdiff_amd import _capi
+    dev = torch.device("cuda:0")
+    c = Case("g2_prod_b2_n23")
+    a, b = _dyn(c, dev), _dyn(c, dev)
+    a.edge_precision, b.edge_precision = "bf16x3", "f32"
+    try:
+        with torch.no_grad():
+            oa1, _ = a(*_args(c, dev)); ob1, _ = b(*_args(c, dev)); oa2, _ = a(*_args(c, dev)); ob2, _ = b(*_args(c, dev))
+            b.edge_precision = "bf16x3"
+            ob3, _ = b(*_args(c, dev))
+    finally:
+        _capi.lib().oard_debug_option(b"gcl_b3", 0)
+        _capi.lib().oard_debug_option(b"equi_b3", 0)
+    assert all(torch.equal(x, y) for x, y in zip(oa1, oa2)) and all(torch.equal(x, y) for x, y in zip(ob1, ob2))
+    assert not all(torch.equal(x, y) for x, y in zip(oa1, ob1))          # different kernels
+    assert all(torch.equal(x, y) for x, y in zip(oa1, ob3))              # same kernels, same weights -> same bits
+    rv, rh = c.split(c.ref64)
+    for o in (oa1, ob1):
+        v, h = c.split([x.cpu() for x in o])
+        assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
