@@ -367,15 +367,13 @@ def main():
 
     cfg = dict(PRODUCTION_LEFTNET_CONFIG)
     B, nf = args.batch, args.atoms
-    if args.precision == "bf16x3":
-        if args.mode == "train":
-            sys.exit("bench.py: --precision bf16x3 is an inference formulation (no tape / backward kernels)")
     dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
                        condition_nf=1, device=dev)
     dyn.load_state_dict(synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg), strict=True)
     dyn.nan_check = "async"                 # no host sync inside the step
     if args.precision == "bf16x3":
         dyn.edge_precision = "bf16x3"       # the split-precision edge kernels for this module's inference calls
+        dyn.train_edge_precision = "bf16x3" # ... and for its training-mode forward (--mode train; the backward stays fp32)
     cm, nfs, ei, masks = make_topology(B, nf)
     cm, nfs, ei = cm.to(dev), nfs.to(dev), ei.to(dev)
     # a few fixed-distribution input sets, resident in HBM, cycled per step (fresh noise each step)
@@ -394,7 +392,9 @@ def main():
             E, A = edge_counts(B, nf)
             out = {"metric": "training_steps_per_sec", "value": world * B * args.steps / dt, "unit": "reaction-steps/s",
                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": "f32" if args.precision == "f32" else "f32; the training-mode forward's two edge stages via bf16x3 (3 bf16 terms per value, fp32 accumulate), backward f32",
+                   "data": "synthetic",
                    "config": {"workload": f"DDPMTrainer.training_step (loss, HIP backward, gradient all-reduce, adaptive clip, "
                                           f"AdamW amsgrad), LEFTNet H=196 R=96 L=6, B={B} reactions/GPU x 3 objects x {nf} atoms "
                                           f"(N={B * 3 * nf}, E={E}), pos_only training as train_ts1x.py",

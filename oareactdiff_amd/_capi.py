@@ -131,7 +131,7 @@ def lib() -> C.CDLL:
     for env, opt in (("OARD_GCL_VARIANT", b"gcl_variant"), ("OARD_EQUI_VARIANT", b"equi_variant"),
                      ("OARD_NODE_VARIANT", b"node_variant"), ("OARD_GCL_SKIP", b"gcl_skip"), ("OARD_PARTS", b"parts"), ("OARD_SEQUENTIAL", b"sequential"), ("OARD_POISON", b"poison"), ("OARD_AUTO_SMALL", b"auto_small"), ("OARD_AUTO_TINY", b"auto_tiny"), ("OARD_NPB", b"npb"),
                      ("OARD_WGRAD_WGS", b"wgrad_wgs"), ("OARD_WGRAD_LDS", b"wgrad_lds"), ("OARD_WGRAD_SHAPES", b"wgrad_shapes"), ("OARD_TRAIN_DUAL", b"train_dual"), ("OARD_SMALL_SPLIT", b"small_split"),
-                     ("OARD_SKIP_FAMILIES", b"skip_families"), ("OARD_GCL_B3", b"gcl_b3"), ("OARD_EQUI_B3", b"equi_b3")):
+                     ("OARD_SKIP_FAMILIES", b"skip_families"), ("OARD_GCL_B3", b"gcl_b3"), ("OARD_EQUI_B3", b"equi_b3"), ("OARD_TRAIN_B3", b"train_b3")):
         if os.environ.get(env):
             check(L.oard_debug_option(opt, int(os.environ[env])), f"oard_debug_option({opt.decode()})")
     _lib = L

@@ -106,12 +106,13 @@ OARD_DEV void chain_kouter_b3(const float* sl, int j0, bf8 xh, bf8 xm, bf8 xl, f
     }
 }
 
-// Columns are the physical rows [r0, r1); DO_S1 / DO_S3 as in k_gcl_edge_v1.
-template <class D, bool DO_S1, bool DO_S3>
+// Columns are the physical rows [r0, r1); DO_S1 / DO_S3 / TRAIN (new state to ew_out != ew_in, pre-activations to the tape) as in
+// k_gcl_edge_v1.
+template <class D, bool DO_S1, bool DO_S3, bool TRAIN = false>
 __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float* __restrict__ stream, const float* __restrict__ P,
                                                         const float* __restrict__ Q, const float* __restrict__ u0,
                                                         const float* __restrict__ c0, long long r0, long long r1, const float* ew_in,
-                                                        float* ew_out, float* __restrict__ mbuf) {
+                                                        float* ew_out, float* __restrict__ mbuf, GclTape tape) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = GclB3Stream<D>;
     constexpr int HT = D::HT, WB = D::WB, NBH = S::NBH, G1 = S::G1, G2 = S::G2, GP = S::GP, WAVES = 8;
@@ -175,6 +176,10 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
             pf.flush();
         }
     }
+    if (TRAIN) {
+#pragma unroll
+        for (int t = 0; t < HT; ++t) st_blk(tape.z1, e, D::HP, t, lane, h1[t]);
+    }
 #pragma unroll
     for (int t = 0; t < HT; ++t) h1[t] = silu4(h1[t]);
     bf8 bh[NBH], bm[NBH], bl[NBH];
@@ -207,8 +212,14 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
                     for (int b = 0; b < NBH; ++b) split3(m[2 * b], (2 * b + 1 < HT) ? m[2 * b + 1] : f4zero(), bh[b], bm[b], bl[b]);
                 }
                 const f4 acc = chain_tile_b3<NBH>(SL(p), gg * G2 + 1, bh, bm, bl, bias, hook);
-                if (tg < HT) m[tg] = silu4(acc);
-                else gate = silu1(__shfl(acc.x, lane & 15, 64));
+                if (tg < HT) {
+                    if (TRAIN) st_blk(tape.z2, e, D::HP, tg, lane, acc);
+                    m[tg] = silu4(acc);
+                } else {
+                    const float av = __shfl(acc.x, lane & 15, 64);
+                    if (TRAIN && g == 0) tape.att[e] = av;
+                    gate = silu1(av);
+                }
             }
         }
         if (bar_left > 0) { bar_left = 0; phase_barrier(); post(); }
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
         for (int t = 0; t < HT; ++t) st_blk(mbuf, eid, D::HP, t, lane, m[t] * gate);
         return;
     }
-    f4 pend[GP], om[GP];
+    f4 pend[GP], om[GP], pendz[TRAIN ? GP : 1];
     auto s3_phase = [&](int p3, const f4 (&o)[GP], f4 (&onext)[GP]) {
         auto post = [&]() {
             if (p3 == 0) {
@@ -228,7 +239,10 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
                 for (int t = 0; t < HT; ++t) st_blk(mbuf, eid, D::HP, t, lane, m[t] * gate);
             } else {
 #pragma unroll
-                for (int gg = 0; gg < GP; ++gg) st_f4(orow + 16 * ((p3 - 1) * GP + gg), pend[gg]);
+                for (int gg = 0; gg < GP; ++gg) {
+                    st_f4(orow + 16 * ((p3 - 1) * GP + gg), pend[gg]);
+                    if (TRAIN) st_f4(tape.z3 + e * D::WP + 4 * g + 16 * ((p3 - 1) * GP + gg), pendz[gg]);
+                }
             }
             pf_begin(p + 2);
             if (p3 + 1 < S::NP3) {
@@ -247,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
             if (t < WB) {
                 const f4 bias = A(p, gg * G2);
                 const f4 z = chain_tile_b3<NBH>(SL(p), gg * G2 + 1, bh, bm, bl, f4zero(), hook) * gate + bias;
+                if (TRAIN) pendz[gg] = z;
                 pend[gg] = o[gg] + silu4(z);
             }
         }
@@ -262,7 +277,10 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
 #pragma unroll
     for (int gg = 0; gg < GP; ++gg) {
         const int t = (S::NP3 - 1) * GP + gg;
-        if (t < WB) st_f4(orow + 16 * t, pend[gg]);
+        if (t < WB) {
+            st_f4(orow + 16 * t, pend[gg]);
+            if (TRAIN) st_f4(tape.z3 + e * D::WP + 4 * g + 16 * t, pendz[gg]);
+        }
     }
 }
 
@@ -291,11 +309,12 @@ struct EquiB3Stream {
     static constexpr size_t LDS_BYTES = (size_t)2 * SLAB * 1024;
 };
 
-template <class D>
+// TRAIN: zd1 (pre-activation of dir_proj.0, [A+1][D1P]) and cd (dir_proj's output before the product, [A+1][3][HP]) go to the tape.
+template <class D, bool TRAIN = false>
 __global__ __launch_bounds__(512, 2) void k_equi_edge_b3(TopoDev tp, const float* __restrict__ stream, const float* __restrict__ dp0b,
                                                          const float* __restrict__ dp2b, const float* __restrict__ ew,
                                                          const float* __restrict__ rbuf, float* __restrict__ qbuf,
-                                                         float* __restrict__ d1s) {
+                                                         float* __restrict__ d1s, float* __restrict__ zd1, float* __restrict__ cdbuf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = EquiB3Stream<D>;
     constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT, NO = S::NO, WAVES = 8;
@@ -351,6 +370,10 @@ __global__ __launch_bounds__(512, 2) void k_equi_edge_b3(TopoDev tp, const float
             pf.flush();
             ++p;
         }
+        if (TRAIN) {
+#pragma unroll
+            for (int t = 0; t < D1T; ++t) st_blk(zd1, a, D::D1P, t, lane, d1[t]);
+        }
 #pragma unroll
         for (int t = 0; t < D1T; ++t) st_f4(d1w + t * 256, silu4(d1[t]));
     }
@@ -405,6 +428,7 @@ __global__ __launch_bounds__(512, 2) void k_equi_edge_b3(TopoDev tp, const float
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
         float* q = qrow + (o / HT) * D::HP + 16 * (o % HT);
+        if (TRAIN) st_f4(cdbuf + a * (size_t)(3 * D::HP) + 4 * g + (o / HT) * D::HP + 16 * (o % HT), acc[o]);
         st_f4(q, acc[o] * ld_f4(q));
     }
 }

@@ -76,6 +76,7 @@ int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
 int g_gcl_b3 = 0;           // 1: the throughput shape of the GCL edge stage runs in split precision (oard_edge_b3.h; inference only).  Read when
                             //    the weights are packed (the bf16 stream is only built then) and when the stage is launched
+int g_train_b3 = 0;         // 1: the TRAINING-mode forward runs both edge stages on the split-precision kernels too (optional; the backward is fp32)
 int g_equi_b3 = 0;          // the same for the EquiMessage edge stage (k_equi_edge_b3)
 int g_skip_families = 0;    // timing experiments only (results are garbage): bit f set = launches of family f are dropped
 
@@ -345,6 +346,11 @@ template <class D, bool S1, bool S3>
 int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
                    const float* c0, long long r0, long long r1, const float* ew_in, float* ew_out, float* mbuf, const GclTape* tape, hipStream_t st) {
     if (r1 <= r0) return OARD_OK;
+    if (tape && g_train_b3) {    // training-mode forward in split precision (optional)
+        LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_b3<D, S1, S3, true>), cdiv(r1 - r0, 16 * 8), 8 * 64, (GclB3Stream<D>::LDS_BYTES), st, tp,
+                   wb + lo.gcl_b3, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, *tape);
+        return OARD_OK;
+    }
     if (tape) {                  // training-mode forward: one shape (8 waves x 16 edges), pre-activations stored
 #ifdef OARD_EXPERIMENTS
         if (variant == 7) {
@@ -366,7 +372,7 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
         case 2:
             if (g_gcl_b3) {
                 LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_b3<D, S1, S3>), cdiv(r1 - r0, 16 * 8), 8 * 64, (GclB3Stream<D>::LDS_BYTES), st, tp,
-                           wb + lo.gcl_b3, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf);
+                           wb + lo.gcl_b3, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{});
                 return OARD_OK;
             }
             GCL_RING3(false, GclTape{});
@@ -412,6 +418,11 @@ int launch_gcl_v1(int variant, int conc, const TopoDev& tp, const float* wb, con
 template <class D>
 int launch_equi_v1(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* dp0b, const float* ew,
                    const float* rbuf, float* qbuf, float* zd1, float* cd, hipStream_t st, float* d1s = nullptr) {
+    if (zd1 && g_train_b3 && d1s) {      // training-mode forward in split precision (optional)
+        LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_b3<D, true>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiB3Stream<D>::LDS_BYTES), st, tp, wb + lo.equi_b3,
+                   dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s, zd1, cd);
+        return OARD_OK;
+    }
     if (zd1) {                   // training-mode forward
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, 8, true>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiStream<D>::LDS_BYTES), st,
                    tp, stream, dp0b, ew, rbuf, qbuf, zd1, cd);
@@ -434,7 +445,7 @@ int launch_equi_v1(int variant, int conc, const TopoDev& tp, const float* wb, co
     }
     if (variant == 2 && g_equi_b3 && d1s) {      // split precision (oard_edge_b3.h): the throughput shape only
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_b3<D>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiB3Stream<D>::LDS_BYTES), st, tp, wb + lo.equi_b3,
-                   dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s);
+                   dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s, nullptr, nullptr);
         return OARD_OK;
     }
     switch (variant) {
@@ -603,7 +614,7 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
             if (A > 0) {
                 int rc = launch_equi_v1<D>(equi_variant, topo->conc, tp, wb, lo, wb + lo.equi_stream, wb + lo.dp0b, ew_out, rbuf, vmsg,
                                            train ? (float*)(tape + to.zd1[l]) : nullptr, train ? (float*)(tape + to.cd[l]) : nullptr, st,
-                                           train ? nullptr : (float*)(ws + w.d1s));
+                                           (float*)(ws + w.d1s));
                 if (rc != OARD_OK) return rc;
             }
             if (nv1 && rows) {
@@ -880,7 +891,7 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
                        (float*)packed + po.c0row, H, d.H4, d.WP);
     hipLaunchKernelGGL(k_u0, dim3((unsigned)cdiv(d.HP, 64)), dim3(64), 0, st, params[pi.gcl0 + 0],
                        (const float*)packed + po.c0row, (float*)packed + po.u0, H, W, d.HP);
-    if (g_gcl_b3) {          // the split-precision stream of the GCL kernel, from the natural fp32 packs made above (oard_edge_b3.h)
+    if (g_gcl_b3 || g_train_b3) {          // the split-precision stream of the GCL kernel, from the natural fp32 packs made above (oard_edge_b3.h)
         const int nbh = (d.HT + 1) / 2, nbw = (d.WB + 1) / 2, G1 = 3 * d.HT, G2 = 1 + 3 * nbh;
         const size_t G2f = (size_t)(d.HT + 1) * 256;                              // group stride of the fp32 stream's S2 / S3 (bias chunk first)
         for (int l = 0; l < c->num_layers; ++l) {
@@ -898,7 +909,7 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
             hipLaunchKernelGGL(k_copy_chunks, dim3((unsigned)d.WB), dim3(256), 0, st, (float*)packed, f3, G2f, s3, (size_t)G2 * 256, d.WB);
         }
     }
-    if (g_equi_b3) {         // the split-precision stream of the EquiMessage kernel: three K-outer sections
+    if (g_equi_b3 || g_train_b3) {         // the split-precision stream of the EquiMessage kernel: three K-outer sections
         const int nbw = (d.WB + 1) / 2, nbr = (d.RB + 1) / 2, nbd = (d.D1T + 1) / 2, NO = 3 * d.HT, G1 = 3 * d.D1T, G2 = 3 * NO;
         for (int l = 0; l < c->num_layers; ++l) {
             const LayerOff& lo = po.layer[l];
@@ -1736,6 +1747,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "skip_families") == 0) { g_skip_families = value; return OARD_OK; }
     if (strcmp(name, "gcl_b3") == 0) { g_gcl_b3 = value != 0; return OARD_OK; }
     if (strcmp(name, "equi_b3") == 0) { g_equi_b3 = value != 0; return OARD_OK; }
+    if (strcmp(name, "train_b3") == 0) { g_train_b3 = value != 0; return OARD_OK; }
     if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
     if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }
     if (strcmp(name, "poison") == 0) { g_poison = value; return OARD_OK; }

@@ -145,8 +145,11 @@ class EGNNDynamics(nn.Module):
         #: environment switches OARD_GCL_B3 / OARD_EQUI_B3).  "f32": the fp32 kernels.  "bf16x3": the split-precision kernels
         #: (csrc/oard_edge_b3.h: three bf16 terms per fp32 value, six bf16 MFMAs per K block, fp32 accumulation - fp32-grade
         #: results, ~1.3 x the step rate at B = 64).  The choice is applied before every call (the library options are
-        #: process-wide) and is part of the packed-weights key.  Training calls always use fp32.
+        #: process-wide) and is part of the packed-weights key.
         self.edge_precision: Optional[str] = None
+        #: The same choice for the TRAINING-mode forward (tape written; the backward kernels and weight-gradient GEMMs stay fp32).
+        #: None: the library option (default fp32; OARD_TRAIN_B3).
+        self.train_edge_precision: Optional[str] = None
         self.last_status: Optional[Tensor] = None
         self.nan_seen: Optional[Tensor] = None
         self._packed: Optional[Tensor] = None
@@ -195,7 +198,11 @@ class EGNNDynamics(nn.Module):
             b3 = 1 if self.edge_precision == "bf16x3" else 0
             _capi.check(L.oard_debug_option(b"gcl_b3", b3), "gcl_b3")
             _capi.check(L.oard_debug_option(b"equi_b3", b3), "equi_b3")
-        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.edge_precision,)
+        if self.train_edge_precision is not None:
+            if self.train_edge_precision not in ("f32", "bf16x3"):
+                raise ValueError("train_edge_precision must be None, 'f32' or 'bf16x3'")
+            _capi.check(L.oard_debug_option(b"train_b3", 1 if self.train_edge_precision == "bf16x3" else 0), "train_b3")
+        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.edge_precision, self.train_edge_precision)
         if self._packed is not None and key == self._packed_key:
             return self._packed
         dev = tensors[0].device

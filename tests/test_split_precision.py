@@ -82,3 +82,12 @@ def test_edge_precision_attribute_switches_kernels_per_module():
     for o in (oa1, ob1):
         v, h = c.split([x.cpu() for x in o])
         assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
+
+
+@pytest.mark.parametrize("name", ["g9_grad_h32", "g9_grad_prod_l2", "g9_grad_prod_n23"])
+def test_split_precision_training_forward_gradients(name):
+    """The optional split-precision TRAINING-mode forward (tape written by k_gcl_edge_b3 / k_equi_edge_b3<TRAIN>; fp32 backward): the
+    training step's loss and gradients against the reference's float64 autograd with the tolerances of tests/test_grad.py."""
+    from test_grad import test_hip_training_step_gradients_match_reference_f64 as run_case
+    with debug_options(train_b3=1):
+        run_case(name)
