@@ -189,10 +189,16 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
     // ---- S2: m0 = SiLU(W2 h1 + b2); gate = SiLU(watt . m0 + batt) ------------------------------------------
     f4 m[HT];
     f4 on[GP];
+    f4 pz2[TRAIN ? GP : 1];                             // TRAIN: z2 tiles of the previous phase, stored behind the next barrier
     float gate = 0.f;
 #pragma unroll
     for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
         auto post = [&]() {
+            if (TRAIN && p2 > 0) {
+#pragma unroll
+                for (int gg = 0; gg < GP; ++gg)
+                    if ((p2 - 1) * GP + gg < HT) st_blk(tape.z2, e, D::HP, (p2 - 1) * GP + gg, lane, pz2[gg]);
+            }
             pf_begin(p + 2);
             if (DO_S3 && p2 == S::NP2 - 1) {
 #pragma unroll
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
                 }
                 const f4 acc = chain_tile_b3<NBH>(SL(p), gg * G2 + 1, bh, bm, bl, bias, hook);
                 if (tg < HT) {
-                    if (TRAIN) st_blk(tape.z2, e, D::HP, tg, lane, acc);
+                    if (TRAIN) pz2[gg] = acc;
                     m[tg] = silu4(acc);
                 } else {
                     const float av = __shfl(acc.x, lane & 15, 64);
@@ -224,6 +230,11 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_b3(TopoDev tp, const float*
         }
         if (bar_left > 0) { bar_left = 0; phase_barrier(); post(); }
         pf.flush();
+    }
+    if (TRAIN) {                                        // z2 tiles of the last S2 phase
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg)
+            if ((S::NP2 - 1) * GP + gg < HT) st_blk(tape.z2, e, D::HP, (S::NP2 - 1) * GP + gg, lane, pz2[gg]);
     }
     // ---- S3: ew += SiLU(gate (W3 m0) + b3) -------------------------------------------------------------------
     if (!DO_S3) {

@@ -421,11 +421,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
     // ---- S2: m = SiLU(W2 h1 + b2); gate = SiLU(watt . m + batt) (the gate is the last group, fed with m) ----
     f4 m[HT];
     f4 on[GP];
+    f4 pz2[TRAIN ? GP : 1];                         // TRAIN: z2 tiles of the previous phase, stored behind the next barrier
     float m_tail = 0.f;
 #pragma unroll
     for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
         auto post = [&]() {
             TL(1);
+            if (TRAIN && p2 > 0) {
+#pragma unroll
+                for (int gg = 0; gg < GP; ++gg)
+                    if ((p2 - 1) * GP + gg < HT) st_blk(tape.z2, e, D::HP, (p2 - 1) * GP + gg, lane, pz2[gg]);
+            }
             pf_begin(p + DIST);
             if (DO_S3 && p2 == S::NP2 - 1) {        // prefetch the old edge-state tiles of S3's first phase
 #pragma unroll
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
                 }
                 TL(3);
                 if (tg < HT) {
-                    if (TRAIN) st_blk(tape.z2, e, D::HP, tg, lane, acc);
+                    if (TRAIN) pz2[gg] = acc;
                     m[tg] = silu4(acc);
                     if (TAIL1 && tg == HT - 1) m_tail = tail_compact(m[HT - 1], lane);
                 } else {
@@ -468,6 +474,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_gcl_edge_v1(TopoDev tp, co
         TL(4);
         if (RING == 3 && bar_left > 0) { bar_left = 0; PHASE_BARRIER(); post(); }
         pf.flush();
+    }
+    if (TRAIN) {                                    // z2 tiles of the last S2 phase
+#pragma unroll
+        for (int gg = 0; gg < GP; ++gg)
+            if ((S::NP2 - 1) * GP + gg < HT) st_blk(tape.z2, e, D::HP, (S::NP2 - 1) * GP + gg, lane, pz2[gg]);
     }
     // ---- S3: ew += SiLU(W3 m + b3), one output tile per group ----------------------------------------
     // stores are issued one phase late (right after the next barrier) so that the barrier's vmcnt(0)
