@@ -3,7 +3,8 @@
 // are below 2^-24 of the product, i.e. the result carries fp32 accuracy (emulated on the 684 x 196 product: 2.7e-7 of the largest
 // output, plain fp32 6.5e-7) - at 6 x 16 cycles per 16 x 16 x 32 block instead of 8 x 32 cycles on
 // v_mfma_f32_16x16x4_f32.  This is an OPTIONAL second formulation (debug option gcl_b3, bench.py --precision bf16x3); the fp32
-// kernel of oard_edge_v1.h stays the default and the headline.  Inference only.
+// kernel of oard_edge_v1.h stays the default and the headline.  <TRAIN> variants write the tape of the training-mode forward
+// (debug option train_b3); the backward kernels are fp32.
 //
 // Same structure as k_gcl_edge_v1<.., RING = 3> (8 waves x 16 edges, weights streamed through three LDS slabs by LDS-DMA, one barrier
 // per phase behind the second hook of the phase, edge-state blocks prefetched one phase ahead, stores one phase late).  What changes:
