@@ -112,6 +112,47 @@ def test_restricted_unpickler_executes_nothing(tmp_path):
     assert not os.path.exists(os.path.join(tmp_path, "pwned"))
 
 
+def _op_global(mod, name):
+    return b"c" + mod.encode() + b"\n" + name.encode() + b"\n"
+
+
+def _op_str(s):
+    b = s.encode()
+    return b"X" + len(b).to_bytes(4, "little") + b
+
+
+def test_restricted_unpickler_has_no_getattr_gadget(tmp_path):
+    """Round-3 advisor finding: with `builtins.getattr` on the allow-list a hand-built stream could walk
+    getattr(torch.Tensor, '__reduce_ex__') -> '__globals__' -> ['__builtins__'] -> ['eval'] and run code.  `getattr` / `object` now
+    resolve to placeholders, and nothing the stream COMPUTES may be called."""
+    from oareactdiff_amd.checkpoint import Placeholder, restricted_pickle
+    pwned = os.path.join(tmp_path, "pwned")
+    # getattr(torch.Tensor, "__reduce_ex__")
+    chain = _op_global("builtins", "getattr") + b"(" + _op_global("torch", "Tensor") + _op_str("__reduce_ex__") + b"tR"
+    # getattr(<that>, "__globals__")
+    chain = _op_global("builtins", "getattr") + b"(" + chain + _op_str("__globals__") + b"tR"
+    stream = b"\x80\x02" + chain + b"."
+    out = restricted_pickle.loads(stream)
+    assert isinstance(out, Placeholder) and type(out).__name__ == "getattr"        # inert: nothing was looked up
+    # calling something that is not an allow-listed global (here: a bound method smuggled in through a placeholder's arguments)
+    # is refused outright
+    evil = b"\x80\x02" + _op_global("collections", "OrderedDict") + b")R" + _op_str("x") + b"\x85R."   # OrderedDict()("x")
+    with pytest.raises(pickle.UnpicklingError):
+        restricted_pickle.loads(evil)
+    # BUILD on a class object (monkey-patching torch.Tensor through the slot-state form) is refused
+    patch = b"\x80\x02" + _op_global("torch", "Tensor") + b"N}" + _op_str("__add__") + _op_global("torch", "Size") + b"s\x86b."
+    with pytest.raises(pickle.UnpicklingError):
+        restricted_pickle.loads(patch)
+    # the os.system-through-eval stream of the finding, end to end
+    ev = (_op_global("builtins", "getattr") + b"(" + _op_global("builtins", "object") + _op_str("__subclasses__") + b"tR")
+    restricted_pickle.loads(b"\x80\x02" + ev + b".")
+    import builtins as _b
+    for name in ("getattr", "object", "eval", "exec", "__import__", "open", "compile"):
+        cls = restricted_pickle.loads(b"\x80\x02" + _op_global("builtins", name) + b".")
+        assert isinstance(cls, type) and issubclass(cls, Placeholder) and cls is not getattr(_b, name)
+    assert not os.path.exists(pwned)
+
+
 def test_checkpoint_of_another_model_is_rejected(tmp_path):
     from oareactdiff_amd.checkpoint import dynamics_from_checkpoint
     c = Case("g3_cutoff_ragged")
