@@ -11,10 +11,12 @@
  * synchronises the stream or the device except oard_topology_create (host work + uploads);
  * all `*_dev` pointers are device pointers on the current HIP device; float tensors are
  * contiguous row-major fp32; the library never touches torch.
- * Threading: one host thread per process drives the library (one process per GPU is the deployment model:
- * torch.distributed / RCCL).  The debug options, the timing facility and the per-call-site launch attributes are
- * process-global and not thread-safe; the launch attributes are tracked per device, so a process may move between
- * devices, but concurrent calls from several threads are not supported.
+ * Threading: calls on DISTINCT (topology, workspace, tape, scratch) objects may run concurrently from several host threads /
+ * on several streams: everything a call needs travels in its arguments (oard_config incl. the precision bits, the packed
+ * blob, the topology, caller-owned buffers).  Process-global and NOT thread-safe are only the debugging facilities:
+ * oard_debug_option / oard_debug_stop_after (A/B switches, read at launch time) and the oard_timing_* event recorder
+ * (keep it disabled when calling from several threads).  One process per GPU remains the deployment model
+ * (torch.distributed / RCCL).
  */
 #ifndef OARD_H
 #define OARD_H
@@ -53,7 +55,17 @@ typedef struct oard_config {
     int32_t pos_dim;         /* must be 3                                           */
     float   cutoff;
     int32_t reflect_equiv;   /* must be 1 (production setting)                      */
+    int32_t precision;       /* OARD_PREC_* bits: arithmetic of the two MFMA edge stages (0 = fp32 everywhere).  A property of
+                                the call, not of the process: oard_pack_weights builds the bf16 streams for the bits set, and
+                                oard_forward / oard_forward_train must be given the blob packed with the same bits. */
 } oard_config;
+
+/* Split precision (csrc/oard_edge_b3.h): every fp32 value as three bf16 terms, six bf16 MFMAs per K block, fp32 accumulation -
+ * fp32-grade results (parity <= 1e-5 against the float64 reference like the fp32 kernels).  No counterpart in the reference (which
+ * is fp32 torch); the fp32 kernels are the default. */
+#define OARD_PREC_GCL_BF16X3 1    /* GCLMessage edge stage of inference calls (throughput launch shape)          */
+#define OARD_PREC_EQUI_BF16X3 2   /* EquiMessage edge stage of inference calls                                   */
+#define OARD_PREC_TRAIN_BF16X3 4  /* both edge stages of the training-mode forward (the backward stays fp32)      */
 
 /* Library / ABI version (major*1000 + minor). */
 int oard_version(void);
@@ -91,8 +103,11 @@ int64_t oard_topology_num_nodes(const oard_topology* topo);
 int64_t oard_topology_num_edges(const oard_topology* topo);        /* sum n_s (n_s - 1)         */
 int64_t oard_topology_num_inner_edges(const oard_topology* topo);  /* same-object ordered pairs */
 int64_t oard_topology_num_samples(const oard_topology* topo);
-/* Writes 1 to *ok_dev iff edge_index_dev ([2,E] int64, row-major) is exactly the edge list
- * get_edges_index(combined_mask, remove_self_edge=True) would produce for this topology. */
+/* Writes 1 to *ok_dev iff edge_index_dev ([2,E] int64, row-major, reference node ids) is the edge SET
+ * get_edges_index(combined_mask, remove_self_edge=True) would produce for this topology (utils/_graph_tools.py:30-36),
+ * in any order: every ordered pair of distinct nodes of one sample exactly once.  EGNNDynamics.forward accepts any edge_index
+ * (egnn_dynamics.py:63-72); its outputs are per node, so any ordering of the complete set is the same computation.
+ * Synchronises the stream (once per topology). */
 int oard_topology_check_edge_index(const oard_topology* topo, const int64_t* edge_index_dev,
                                    int64_t n_edges, int32_t* ok_dev, oard_stream_t stream);
 

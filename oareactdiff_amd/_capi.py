@@ -12,6 +12,7 @@ OARD_OK, OARD_EINVAL, OARD_ENOTCOMPLETE, OARD_EHIP, OARD_ENOMEM = 0, -1, -2, -3,
 ERRORS = {OARD_EINVAL: "invalid argument / unsupported configuration", OARD_ENOTCOMPLETE: "topology is not complete-per-sample",
           OARD_EHIP: "HIP runtime error", OARD_ENOMEM: "workspace too small"}
 
+PREC_GCL_BF16X3, PREC_EQUI_BF16X3, PREC_TRAIN_BF16X3 = 1, 2, 4      # oard_config.precision bits
 TAP_S, TAP_VEC, TAP_EDGE, TAP_POS_FRAME, TAP_DPOS, TAP_HOUT, TAP_LABELS, TAP_NE1 = 1, 2, 3, 4, 5, 6, 7, 8
 
 EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_bytes", "oard_pack_weights",
@@ -40,7 +41,7 @@ class OardConfig(C.Structure):
         ("hidden", C.c_int32), ("num_radial", C.c_int32), ("num_layers", C.c_int32), ("in_hidden", C.c_int32),
         ("n_obj", C.c_int32), ("node_nf", C.c_int32 * OARD_MAX_OBJECTS), ("enc_alias", C.c_int32 * OARD_MAX_OBJECTS),
         ("condition_nf", C.c_int32), ("condition_time", C.c_int32), ("pos_dim", C.c_int32), ("cutoff", C.c_float),
-        ("reflect_equiv", C.c_int32),
+        ("reflect_equiv", C.c_int32), ("precision", C.c_int32),
     ]
 
 
@@ -131,7 +132,7 @@ def lib() -> C.CDLL:
     for env, opt in (("OARD_GCL_VARIANT", b"gcl_variant"), ("OARD_EQUI_VARIANT", b"equi_variant"),
                      ("OARD_NODE_VARIANT", b"node_variant"), ("OARD_GCL_SKIP", b"gcl_skip"), ("OARD_PARTS", b"parts"), ("OARD_SEQUENTIAL", b"sequential"), ("OARD_POISON", b"poison"), ("OARD_AUTO_SMALL", b"auto_small"), ("OARD_AUTO_TINY", b"auto_tiny"), ("OARD_NPB", b"npb"),
                      ("OARD_WGRAD_WGS", b"wgrad_wgs"), ("OARD_WGRAD_LDS", b"wgrad_lds"), ("OARD_WGRAD_SHAPES", b"wgrad_shapes"), ("OARD_TRAIN_DUAL", b"train_dual"), ("OARD_SMALL_SPLIT", b"small_split"),
-                     ("OARD_SKIP_FAMILIES", b"skip_families"), ("OARD_GCL_B3", b"gcl_b3"), ("OARD_EQUI_B3", b"equi_b3"), ("OARD_TRAIN_B3", b"train_b3")):
+                     ("OARD_SKIP_FAMILIES", b"skip_families")):
         if os.environ.get(env):
             check(L.oard_debug_option(opt, int(os.environ[env])), f"oard_debug_option({opt.decode()})")
     _lib = L

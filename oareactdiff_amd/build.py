@@ -42,9 +42,25 @@ def dims_define(spec: str) -> str:
     return "-DOARD_DIMS_LIST=" + "".join(f"X({h},{r})" for h, r in pairs)
 
 
+def _dims_file() -> str:
+    return LIB + ".dims"
+
+
+def _built_dims() -> str:
+    """The OARD_DIMS the library on disk was compiled with (side file written next to it; absent = unknown -> rebuild)."""
+    try:
+        with open(_dims_file()) as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     dims = os.environ.get("OARD_DIMS", DEFAULT_DIMS)
-    if not force and not _stale() and dims == DEFAULT_DIMS:
+    dims_define(dims)                                    # validate before deciding anything
+    # a library built with other widths is stale whatever its timestamp says (a non-default OARD_DIMS build used to leave a
+    # liboard_hip.so without 196x96 that the next default build() kept)
+    if not force and not _stale() and _built_dims() == dims:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
@@ -54,6 +70,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, cwd=CSRC, check=True)
+    with open(_dims_file(), "w") as f:
+        f.write(dims + "\n")
     return LIB
 
 

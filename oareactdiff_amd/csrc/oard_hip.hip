@@ -74,10 +74,9 @@ int g_wgrad_wgs = 512;       // workgroups per weight-gradient GEMM (row chunks 
                             // (measured per training step: 384 -> 38.1 ms, 512 -> 30.7, 768 -> 36.0, 1024 -> 33.2, 2048 -> 38.1)
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
-int g_gcl_b3 = 0;           // 1: the throughput shape of the GCL edge stage runs in split precision (oard_edge_b3.h; inference only).  Read when
-                            //    the weights are packed (the bf16 stream is only built then) and when the stage is launched
-int g_train_b3 = 0;         // 1: the TRAINING-mode forward runs both edge stages on the split-precision kernels too (optional; the backward is fp32)
-int g_equi_b3 = 0;          // the same for the EquiMessage edge stage (k_equi_edge_b3)
+// Arithmetic of the two MFMA edge stages: oard_config::precision (OARD_PREC_* bits, include/oard.h) - a property of the CALL, read
+// when the weights are packed (the bf16 streams are only built for the bits set) and when the stages are launched.  There is no
+// process-wide precision state: two modules with different precision may run from two threads / on two streams.
 int g_skip_families = 0;    // timing experiments only (results are garbage): bit f set = launches of family f are dropped
 
 struct ScopedLaunch {
@@ -112,6 +111,7 @@ bool config_ok(const oard_config* c) {
     if (c->in_hidden < 1 || c->in_hidden > 16) return false;
     if (c->n_obj < 1 || c->n_obj > OARD_MAX_OBJECTS) return false;
     if (c->pos_dim != 3 || c->reflect_equiv != 1) return false;
+    if (c->precision & ~(OARD_PREC_GCL_BF16X3 | OARD_PREC_EQUI_BF16X3 | OARD_PREC_TRAIN_BF16X3)) return false;
     const int emb = c->in_hidden - (c->condition_time ? 1 : 0) - (c->condition_nf > 0 ? c->condition_nf : 0);
     if (emb < 1) return false;
     for (int k = 0; k < c->n_obj; ++k) {
@@ -343,10 +343,10 @@ int set_lds(K kernel, size_t bytes) {
         LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, TRAIN_, 2, 3>), cdiv(r1 - r0, 16 * 8), 8 * 64, \
                    (GclStream<D, 2>::LDS_BYTES / 2 * 3), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, tape_); return OARD_OK; } while (0)
 template <class D, bool S1, bool S3>
-int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
+int launch_gcl_v1s(int prec, int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
                    const float* c0, long long r0, long long r1, const float* ew_in, float* ew_out, float* mbuf, const GclTape* tape, hipStream_t st) {
     if (r1 <= r0) return OARD_OK;
-    if (tape && g_train_b3) {    // training-mode forward in split precision (optional)
+    if (tape && (prec & OARD_PREC_TRAIN_BF16X3)) {    // training-mode forward in split precision (optional)
         LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_b3<D, S1, S3, true>), cdiv(r1 - r0, 16 * 8), 8 * 64, (GclB3Stream<D>::LDS_BYTES), st, tp,
                    wb + lo.gcl_b3, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, *tape);
         return OARD_OK;
@@ -370,7 +370,7 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
     }
     switch (variant) {
         case 2:
-            if (g_gcl_b3) {
+            if (prec & OARD_PREC_GCL_BF16X3) {
                 LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_b3<D, S1, S3>), cdiv(r1 - r0, 16 * 8), 8 * 64, (GclB3Stream<D>::LDS_BYTES), st, tp,
                            wb + lo.gcl_b3, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{});
                 return OARD_OK;
@@ -400,25 +400,25 @@ int launch_gcl_v1s(int variant, int conc, const TopoDev& tp, const float* wb, co
 // one GCL edge pass of layer l: inner edges always run every stage; inter-object edges skip S1 in the first
 // layer (constant initial state) and S3 in the last (their updated state is never read)
 template <class D>
-int launch_gcl_v1(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
+int launch_gcl_v1(int prec, int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
                   const float* c0, bool first, bool last, const float* ew_in, float* ew_out, float* mbuf, const GclTape* tape, hipStream_t st) {
     const long long A = tp.A, E = tp.E;
     int rc;
     const bool skip = g_gcl_skip || tape;
-    if (!skip || (!first && !last)) return launch_gcl_v1s<D, true, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, E, ew_in, ew_out, mbuf, tape, st);
-    rc = launch_gcl_v1s<D, true, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, A, ew_in, ew_out, mbuf, tape, st);
+    if (!skip || (!first && !last)) return launch_gcl_v1s<D, true, true>(prec, variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, E, ew_in, ew_out, mbuf, tape, st);
+    rc = launch_gcl_v1s<D, true, true>(prec, variant, conc, tp, wb, lo, stream, P, Q, u0, c0, 0, A, ew_in, ew_out, mbuf, tape, st);
     if (rc != OARD_OK) return rc;
-    if (first && last) return launch_gcl_v1s<D, false, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew_in, ew_out, mbuf, tape, st);
-    if (first) return launch_gcl_v1s<D, false, true>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew_in, ew_out, mbuf, tape, st);
-    return launch_gcl_v1s<D, true, false>(variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew_in, ew_out, mbuf, tape, st);
+    if (first && last) return launch_gcl_v1s<D, false, false>(prec, variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew_in, ew_out, mbuf, tape, st);
+    if (first) return launch_gcl_v1s<D, false, true>(prec, variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew_in, ew_out, mbuf, tape, st);
+    return launch_gcl_v1s<D, true, false>(prec, variant, conc, tp, wb, lo, stream, P, Q, u0, c0, A, E, ew_in, ew_out, mbuf, tape, st);
 }
 #define EQUI_CASE(id, WV_) case id: { \
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV_, false>), cdiv(tp.A, 16 * WV_), WV_ * 64, (EquiStream<D>::LDS_BYTES), st, \
                    tp, stream, dp0b, ew, rbuf, qbuf, nullptr, nullptr); return OARD_OK; }
 template <class D>
-int launch_equi_v1(int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* dp0b, const float* ew,
+int launch_equi_v1(int prec, int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* dp0b, const float* ew,
                    const float* rbuf, float* qbuf, float* zd1, float* cd, hipStream_t st, float* d1s = nullptr) {
-    if (zd1 && g_train_b3 && d1s) {      // training-mode forward in split precision (optional)
+    if (zd1 && (prec & OARD_PREC_TRAIN_BF16X3) && d1s) {      // training-mode forward in split precision (optional)
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_b3<D, true>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiB3Stream<D>::LDS_BYTES), st, tp, wb + lo.equi_b3,
                    dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s, zd1, cd);
         return OARD_OK;
@@ -443,7 +443,7 @@ int launch_equi_v1(int variant, int conc, const TopoDev& tp, const float* wb, co
                    tp, wb, lo, ew, rbuf, qbuf);
         return OARD_OK;
     }
-    if (variant == 2 && g_equi_b3 && d1s) {      // split precision (oard_edge_b3.h): the throughput shape only
+    if (variant == 2 && (prec & OARD_PREC_EQUI_BF16X3) && d1s) {      // split precision (oard_edge_b3.h): the throughput shape only
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_b3<D>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiB3Stream<D>::LDS_BYTES), st, tp, wb + lo.equi_b3,
                    dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s, nullptr, nullptr);
         return OARD_OK;
@@ -592,7 +592,7 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
             } else {
                 GclTape gt{};
                 if (train) gt = GclTape{(float*)(tape + to.z1[l]), (float*)(tape + to.z2[l]), (float*)(tape + to.att[l]), (float*)(tape + to.z3[l])};
-                int rc = launch_gcl_v1<D>(gcl_variant, topo->conc, tp, wb, lo, wb + lo.gcl_stream, P, Q, wb + po.u0, wb + po.c0row, l == 0,
+                int rc = launch_gcl_v1<D>(c->precision, gcl_variant, topo->conc, tp, wb, lo, wb + lo.gcl_stream, P, Q, wb + po.u0, wb + po.c0row, l == 0,
                                           l == c->num_layers - 1, ew_in, ew_out, mbuf, train ? &gt : nullptr, st);
                 if (rc != OARD_OK) return rc;
             }
@@ -612,7 +612,7 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                    s, vcur, v2buf, scal, vdot);
         } else {
             if (A > 0) {
-                int rc = launch_equi_v1<D>(equi_variant, topo->conc, tp, wb, lo, wb + lo.equi_stream, wb + lo.dp0b, ew_out, rbuf, vmsg,
+                int rc = launch_equi_v1<D>(c->precision, equi_variant, topo->conc, tp, wb, lo, wb + lo.equi_stream, wb + lo.dp0b, ew_out, rbuf, vmsg,
                                            train ? (float*)(tape + to.zd1[l]) : nullptr, train ? (float*)(tape + to.cd[l]) : nullptr, st,
                                            (float*)(ws + w.d1s));
                 if (rc != OARD_OK) return rc;
@@ -891,7 +891,7 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
                        (float*)packed + po.c0row, H, d.H4, d.WP);
     hipLaunchKernelGGL(k_u0, dim3((unsigned)cdiv(d.HP, 64)), dim3(64), 0, st, params[pi.gcl0 + 0],
                        (const float*)packed + po.c0row, (float*)packed + po.u0, H, W, d.HP);
-    if (g_gcl_b3 || g_train_b3) {          // the split-precision stream of the GCL kernel, from the natural fp32 packs made above (oard_edge_b3.h)
+    if (c->precision & (OARD_PREC_GCL_BF16X3 | OARD_PREC_TRAIN_BF16X3)) {          // the split-precision stream of the GCL kernel, from the natural fp32 packs made above (oard_edge_b3.h)
         const int nbh = (d.HT + 1) / 2, nbw = (d.WB + 1) / 2, G1 = 3 * d.HT, G2 = 1 + 3 * nbh;
         const size_t G2f = (size_t)(d.HT + 1) * 256;                              // group stride of the fp32 stream's S2 / S3 (bias chunk first)
         for (int l = 0; l < c->num_layers; ++l) {
@@ -909,7 +909,7 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
             hipLaunchKernelGGL(k_copy_chunks, dim3((unsigned)d.WB), dim3(256), 0, st, (float*)packed, f3, G2f, s3, (size_t)G2 * 256, d.WB);
         }
     }
-    if (g_equi_b3 || g_train_b3) {         // the split-precision stream of the EquiMessage kernel: three K-outer sections
+    if (c->precision & (OARD_PREC_EQUI_BF16X3 | OARD_PREC_TRAIN_BF16X3)) {         // the split-precision stream of the EquiMessage kernel: three K-outer sections
         const int nbw = (d.WB + 1) / 2, nbr = (d.RB + 1) / 2, nbd = (d.D1T + 1) / 2, NO = 3 * d.HT, G1 = 3 * d.D1T, G2 = 3 * NO;
         for (int l = 0; l < c->num_layers; ++l) {
             const LayerOff& lo = po.layer[l];
@@ -1076,6 +1076,19 @@ int oard_topology_create_parts(const oard_config* c, const int64_t* cm, const in
     n_parts = std::max(1, std::min(std::min(n_parts, OARD_MAX_PARTS), B));
     oard_topology* tp = new oard_topology();
     tp->n_obj = n_obj; tp->B = B; tp->n_parts = n_parts;
+    {   // reference-order tables of oard_topology_check_edge_index: sample, rank inside the sample, first edge id of every node
+        std::vector<int> tab(2 * (size_t)N), seen(B, 0);
+        for (int r = 0; r < N; ++r) { tab[r] = dense[r]; tab[(size_t)N + r] = seen[dense[r]]++; }
+        const size_t b_int = 2 * (size_t)N * sizeof(int), b_all = align_up(b_int, 8) + (size_t)N * sizeof(long long);
+        if (hipMalloc(&tp->ref_block, b_all) != hipSuccess) { delete tp; return OARD_EHIP; }
+        if (hipMemcpy(tp->ref_block, tab.data(), b_int, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy((char*)tp->ref_block + align_up(b_int, 8), ref_ptr_ref.data(), (size_t)N * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess) {
+            oard_topology_destroy(tp); return OARD_EHIP;
+        }
+        tp->ref_sample = (const int*)tp->ref_block; tp->ref_rank = tp->ref_sample + N;
+        tp->ref_ptr = (const long long*)((char*)tp->ref_block + align_up(b_int, 8));
+        tp->N_ref = N;
+    }
     for (int k = 0; k <= n_obj && k <= OARD_MAX_OBJECTS; ++k) tp->obj_start[k] = obj_start[k];
     for (int p = 0; p < n_parts; ++p) {
         const int lo = (int)((long long)B * p / n_parts), hi = (int)((long long)B * (p + 1) / n_parts);
@@ -1107,6 +1120,7 @@ void oard_topology_destroy(oard_topology* tp) {
         if (tp->ev_join[p]) (void)hipEventDestroy(tp->ev_join[p]);
     }
     if (tp->ev_fork) (void)hipEventDestroy(tp->ev_fork);
+    if (tp->ref_block) (void)hipFree(tp->ref_block);
     delete tp;
 }
 int64_t oard_topology_num_nodes(const oard_topology* tp) { return tp ? tp->N : 0; }
@@ -1114,6 +1128,10 @@ int64_t oard_topology_num_edges(const oard_topology* tp) { return tp ? tp->E : 0
 int64_t oard_topology_num_inner_edges(const oard_topology* tp) { return tp ? tp->A : 0; }
 int64_t oard_topology_num_samples(const oard_topology* tp) { return tp ? tp->B : 0; }
 
+// Outputs are per node and every segmented sum runs in the library's own (implicit) edge order, so ANY ordering of the complete
+// edge set is the same computation (egnn_dynamics.py:63-72 accepts any edge_index; utils/_graph_tools.py:30-36 builds the complete
+// per-sample graph).  Set check: every given pair must be a valid ordered pair (same sample, i != j) and hit its id - first id of
+// node i + rank of j among the other nodes of the sample - exactly once in a bitmap; with n_edges == E that is a permutation.
 int oard_topology_check_edge_index(const oard_topology* tp, const int64_t* ei, int64_t n_edges, int32_t* ok,
                                    oard_stream_t stream) {
     if (!tp || !ok) return OARD_EINVAL;
@@ -1123,11 +1141,19 @@ int oard_topology_check_edge_index(const oard_topology* tp, const int64_t* ei, i
     HIP_TRY(hipStreamSynchronize(st));      // `one` lives on this stack frame
     if (one && tp->E > 0) {
         if (!ei) return OARD_EINVAL;
-        for (int p = 0; p < tp->n_parts; ++p)
-            if (tp->parts[p].d.E > 0)
-                hipLaunchKernelGGL(k_check_edges, dim3((unsigned)cdiv(tp->parts[p].d.E, 256)), dim3(256), 0, st,
-                                   tp->parts[p].d, (const long long*)ei, (long long)n_edges, (int*)ok);
-        HIP_TRY(hipGetLastError());
+        unsigned* bitmap = nullptr;
+        const size_t words = (size_t)cdiv(tp->E, 32);
+        HIP_TRY(hipMalloc(&bitmap, words * sizeof(unsigned)));
+        hipError_t e1 = hipMemsetAsync(bitmap, 0, words * sizeof(unsigned), st);
+        if (e1 == hipSuccess) {
+            hipLaunchKernelGGL(k_check_edge_set, dim3((unsigned)cdiv(n_edges, 256)), dim3(256), 0, st, tp->ref_sample, tp->ref_rank,
+                               tp->ref_ptr, tp->N_ref, (const long long*)ei, (long long)n_edges, bitmap, (int*)ok);
+            e1 = hipGetLastError();
+        }
+        const hipError_t e2 = hipStreamSynchronize(st);
+        (void)hipFree(bitmap);
+        HIP_TRY(e1);
+        HIP_TRY(e2);
     }
     return OARD_OK;
 }
@@ -1745,9 +1771,6 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
     if (strcmp(name, "skip_families") == 0) { g_skip_families = value; return OARD_OK; }
-    if (strcmp(name, "gcl_b3") == 0) { g_gcl_b3 = value != 0; return OARD_OK; }
-    if (strcmp(name, "equi_b3") == 0) { g_equi_b3 = value != 0; return OARD_OK; }
-    if (strcmp(name, "train_b3") == 0) { g_train_b3 = value != 0; return OARD_OK; }
     if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
     if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }
     if (strcmp(name, "poison") == 0) { g_poison = value; return OARD_OK; }

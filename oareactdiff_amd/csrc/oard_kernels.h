@@ -198,12 +198,18 @@ __global__ void k_u0(const float* __restrict__ w_edge_mlp0 /*[H][2H+W]*/, const 
 // =====================================================================================================
 // topology check: is edge_index exactly get_edges_index(combined_mask, remove_self_edge=True)?
 // =====================================================================================================
-__global__ void k_check_edges(TopoDev tp, const long long* __restrict__ ei, long long n_edges, int* ok) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= tp.E) return;
-    const int s = tp.edge_src[e], t = tp.edge_tgt[e];
-    const long long rp = tp.ref_edge_ptr[s] + (e - tp.edge_ptr[s]);
-    if (rp >= n_edges || ei[rp] != tp.node_ref[s] || ei[n_edges + rp] != tp.node_ref[t]) atomicAnd(ok, 0);
+// edge_index ([2, n_edges] int64, reference node ids) is a permutation of the complete per-sample edge set: see
+// oard_topology_check_edge_index.  One thread per given edge; a repeated id finds its bit already set.
+__global__ void k_check_edge_set(const int* __restrict__ ref_sample, const int* __restrict__ ref_rank, const long long* __restrict__ ref_ptr,
+                                 int n_nodes, const long long* __restrict__ ei, long long n_edges, unsigned* bitmap, int* ok) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_edges) return;
+    const long long i = ei[p], j = ei[n_edges + p];
+    if (i < 0 || j < 0 || i >= n_nodes || j >= n_nodes || i == j || ref_sample[i] != ref_sample[j]) { atomicAnd(ok, 0); return; }
+    const int ri = ref_rank[i], rj = ref_rank[j];
+    const long long id = ref_ptr[i] + rj - (rj > ri ? 1 : 0);
+    const unsigned bit = 1u << (id & 31);
+    if (atomicOr(bitmap + (id >> 5), bit) & bit) atomicAnd(ok, 0);
 }
 
 // =====================================================================================================

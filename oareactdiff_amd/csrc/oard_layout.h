@@ -95,6 +95,12 @@ struct oard_topology {
     int obj_start[OARD_MAX_OBJECTS + 1] = {};   // reference (object-major) row ranges of the objects
     hipStream_t side[OARD_MAX_PARTS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[OARD_MAX_PARTS] = {};
+    // reference-order tables (whole batch) for oard_topology_check_edge_index: dense sample id, rank of the node inside its sample,
+    // first reference-order edge id of the node
+    void* ref_block = nullptr;
+    const int *ref_sample = nullptr, *ref_rank = nullptr;
+    const long long* ref_ptr = nullptr;
+    int N_ref = 0;
 };
 
 // ---- workspace carving (byte offsets) --------------------------------------------------------------

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
@@ -141,14 +142,15 @@ class EGNNDynamics(nn.Module):
         #: "async": no host sync; the device-side flag of the last call is kept in `self.last_status` and OR-ed into
         #: the sticky flag `self.nan_seen` (reset it with `reset_nan_seen()`; the sampling loops read it once at the end).
         self.nan_check = "sync"
-        #: Arithmetic of the two MFMA edge stages in INFERENCE calls.  None: whatever the library options say (default fp32; the
-        #: environment switches OARD_GCL_B3 / OARD_EQUI_B3).  "f32": the fp32 kernels.  "bf16x3": the split-precision kernels
-        #: (csrc/oard_edge_b3.h: three bf16 terms per fp32 value, six bf16 MFMAs per K block, fp32 accumulation - fp32-grade
-        #: results, ~1.3 x the step rate at B = 64).  The choice is applied before every call (the library options are
-        #: process-wide) and is part of the packed-weights key.
+        #: Arithmetic of the two MFMA edge stages in INFERENCE calls.  "f32": the fp32 kernels.  "bf16x3": the split-precision
+        #: kernels (csrc/oard_edge_b3.h: three bf16 terms per fp32 value, six bf16 MFMAs per K block, fp32 accumulation - fp32-grade
+        #: results, ~1.3 x the step rate at B = 64).  None: the process default `default_edge_precision()` (fp32 unless the environment
+        #: says OARD_GCL_B3=1 / OARD_EQUI_B3=1 - read per call, so that the answer never depends on what another module did).
+        #: The choice travels with every library call (`oard_config.precision`) and is part of the packed-weights key: modules
+        #: with different settings can run side by side, also from different threads / streams.
         self.edge_precision: Optional[str] = None
         #: The same choice for the TRAINING-mode forward (tape written; the backward kernels and weight-gradient GEMMs stay fp32).
-        #: None: the library option (default fp32; OARD_TRAIN_B3).
+        #: None: fp32 unless OARD_TRAIN_B3=1.
         self.train_edge_precision: Optional[str] = None
         self.last_status: Optional[Tensor] = None
         self.nan_seen: Optional[Tensor] = None
@@ -175,7 +177,24 @@ class EGNNDynamics(nn.Module):
         cfg.pos_dim = self.pos_dim
         cfg.cutoff = float(self.model_config.get("cutoff", 10.0))
         cfg.reflect_equiv = 1
+        cfg.precision = self._precision_bits()
         return cfg
+
+    def _precision_bits(self) -> int:
+        """`oard_config.precision` (OARD_PREC_* of include/oard.h) from `edge_precision` / `train_edge_precision`; None resolves to the
+        environment's default at THIS call - never to state left behind by another module."""
+        for v in (self.edge_precision, self.train_edge_precision):
+            if v not in (None, "f32", "bf16x3"):
+                raise ValueError("edge_precision / train_edge_precision must be None, 'f32' or 'bf16x3'")
+        env = lambda n: os.environ.get(n, "0") not in ("", "0")
+        bits = 0
+        if self.edge_precision == "bf16x3" or (self.edge_precision is None and env("OARD_GCL_B3")):
+            bits |= _capi.PREC_GCL_BF16X3
+        if self.edge_precision == "bf16x3" or (self.edge_precision is None and env("OARD_EQUI_B3")):
+            bits |= _capi.PREC_EQUI_BF16X3
+        if self.train_edge_precision == "bf16x3" or (self.train_edge_precision is None and env("OARD_TRAIN_B3")):
+            bits |= _capi.PREC_TRAIN_BF16X3
+        return bits
 
     def _ordered_tensors(self) -> List[Tensor]:
         """Tensors in the canonical order of include/oard.h (== state_spec order); encoder/decoder
@@ -192,17 +211,7 @@ class EGNNDynamics(nn.Module):
     def _get_packed(self, cfg: _capi.OardConfig, stream: int) -> Tensor:
         tensors = self._ordered_tensors()
         L = _capi.lib()
-        if self.edge_precision is not None:
-            if self.edge_precision not in ("f32", "bf16x3"):
-                raise ValueError("edge_precision must be None, 'f32' or 'bf16x3'")
-            b3 = 1 if self.edge_precision == "bf16x3" else 0
-            _capi.check(L.oard_debug_option(b"gcl_b3", b3), "gcl_b3")
-            _capi.check(L.oard_debug_option(b"equi_b3", b3), "equi_b3")
-        if self.train_edge_precision is not None:
-            if self.train_edge_precision not in ("f32", "bf16x3"):
-                raise ValueError("train_edge_precision must be None, 'f32' or 'bf16x3'")
-            _capi.check(L.oard_debug_option(b"train_b3", 1 if self.train_edge_precision == "bf16x3" else 0), "train_b3")
-        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.edge_precision, self.train_edge_precision)
+        key = tuple((t.data_ptr(), t._version) for t in tensors) + (cfg.precision,)
         if self._packed is not None and key == self._packed_key:
             return self._packed
         dev = tensors[0].device
@@ -528,7 +537,7 @@ class _Topology:
         for c in self.obj_counts:
             starts.append(starts[-1] + c)
         self.obj_masks = [combined_mask.detach()[starts[k]: starts[k + 1]].to(torch.int64) for k in range(n_obj)]
-        # the kernels assume the complete-per-sample graph in the reference's edge order: verify once
+        # the kernels assume the complete-per-sample graph (any ordering of its edge list: outputs are per node): verify once
         ei = edge_index.detach()
         if ei.dim() != 2 or ei.shape[0] != 2 or ei.dtype != torch.int64 or ei.device != dev:
             raise _capi.OardError("edge_index must be an int64 [2, E] tensor on the same device")
@@ -540,7 +549,7 @@ class _Topology:
             L.oard_topology_destroy(h)
             self.handle = None
             raise _capi.OardError(
-                "edge_index is not get_edges_index(combined_mask, remove_self_edge=True): the MI355X backend "
+                "edge_index is not (a permutation of) get_edges_index(combined_mask, remove_self_edge=True): the MI355X backend "
                 "implements the complete-graph-per-sample topology the diffusion sampler/trainer uses")
 
     def __del__(self):

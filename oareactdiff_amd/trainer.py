@@ -20,6 +20,7 @@ left out of the bucket and never get a gradient, as in the reference.
 """
 from __future__ import annotations
 
+import copy
 import math
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -94,8 +95,12 @@ class DDPMTrainer:
             p.grad = self.flat_grad[off: off + p.numel()].view_as(p)
             off += p.numel()
         self.opt_config = dict(DEFAULT_OPTIMIZER, **(optimizer_config or {}))
-        self.fused = (hasattr(dynamics, "_get_packed_bwd") and self.params[0].device.type == "cuda" and loss_type == "l2"
-                      and self.params[0].dtype == torch.float32) if fused is None else bool(fused)
+        can_fuse = (hasattr(dynamics, "_get_packed_bwd") and self.params[0].device.type == "cuda" and loss_type == "l2"
+                    and self.params[0].dtype == torch.float32)
+        if fused and not can_fuse:                     # the fused kernels implement the l2 objective in float32 on the HIP module only
+            raise ValueError("fused=True needs the HIP EGNNDynamics on a ROCm device, float32 parameters and loss_type='l2' "
+                             f"(got loss_type={loss_type!r}, dtype={self.params[0].dtype}, device={self.params[0].device})")
+        self.fused = can_fuse if fused is None else bool(fused)
         if self.fused:
             # the HIP module: (1) its backward accumulates straight into the .grad views of the bucket; (2) the parameters
             # themselves become views of ONE flat buffer, so that AdamW is a single kernel over it (oard_adamw_step) and
@@ -112,12 +117,51 @@ class DDPMTrainer:
             self.exp_avg_sq = torch.zeros_like(self.flat_param)
             self.max_exp_avg_sq = torch.zeros_like(self.flat_param)
             self.opt_step = 0
-        self.optimizer = torch.optim.AdamW(self.params, **self.opt_config)      # the generic path's optimiser (CPU / non-HIP module)
+        # `trainer.optimizer` is what the reference's configure_optimizers returns (pl_trainer.py:149-151): the generic path steps it;
+        # the fused path runs oard_adamw_step on the flat buffers but reads lr / betas / eps / weight_decay / amsgrad from
+        # `optimizer.param_groups[0]` at EVERY step, so an LR scheduler attached to it (or an edit of the group) takes effect in
+        # both modes.  The fused moments live in `exp_avg` / `exp_avg_sq` / `max_exp_avg_sq` / `opt_step`: see state_dict().
+        self.optimizer = torch.optim.AdamW(self.params, **self.opt_config)
         self._gamma_dev = None
         self.clip_grad = clip_grad
         if clip_grad:                                  # pl_trainer.py:143-146
             self.gradnorm_queue = Queue()
             self.gradnorm_queue.add(3000)
+
+    # ---- resume: what Lightning's checkpoint keeps of the reference trainer (`optimizer_states`, pl_trainer.py:149-151; the clipping
+    # history `gradnorm_queue` is NOT checkpointed by the reference and restarts at [3000], :143-146 - it is kept here) -------------
+    def state_dict(self) -> Dict:
+        """Everything a bit-identical continuation of the training needs besides the module's own state_dict(): the optimiser state
+        (fused: flat AdamW moments + step counter + the hyper-parameters of `optimizer.param_groups`; generic: torch's), the clipping
+        history and the skipped-step counter."""
+        sd: Dict = {"fused": bool(self.fused), "names": list(self.names), "skipped_steps": int(self.skipped_steps),
+                    "gradnorm_queue": list(self.gradnorm_queue.items) if self.clip_grad else None}
+        if self.fused:
+            sd["opt_step"] = int(self.opt_step)
+            sd["param_groups"] = [{k: v for k, v in g.items() if k != "params"} for g in self.optimizer.param_groups]
+            for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                sd[k] = getattr(self, k).detach().clone()
+        else:
+            sd["optimizer"] = copy.deepcopy(self.optimizer.state_dict())     # a snapshot: torch hands out the live moment tensors
+        return sd
+
+    def load_state_dict(self, sd: Dict) -> None:
+        if list(sd["names"]) != list(self.names):
+            raise ValueError("trainer state belongs to a different parameter list")
+        if bool(sd["fused"]) != bool(self.fused):
+            raise ValueError(f"trainer state was saved with fused={sd['fused']}, this trainer runs fused={self.fused}")
+        self.skipped_steps = int(sd["skipped_steps"])
+        if self.clip_grad and sd.get("gradnorm_queue") is not None:
+            self.gradnorm_queue.items = [float(x) for x in sd["gradnorm_queue"]]
+        if self.fused:
+            self.opt_step = int(sd["opt_step"])
+            for g, saved in zip(self.optimizer.param_groups, sd["param_groups"]):
+                g.update(saved)
+            with torch.no_grad():
+                for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                    getattr(self, k).copy_(sd[k].to(self.flat_param.device))
+        else:
+            self.optimizer.load_state_dict(sd["optimizer"])
 
     # pl_trainer.py:208-282
     def compute_loss(self, batch, training: bool = True, **kw) -> Tuple[Tensor, Dict[str, float]]:
@@ -288,7 +332,7 @@ class DDPMTrainer:
                 else:
                     self.gradnorm_queue.add(grad_norm)
                 info["grad_norm"], info["max_grad_norm"] = grad_norm, max_norm
-            o = self.opt_config
+            o = self.optimizer.param_groups[0]
             self.opt_step += 1
             stream = torch.cuda.current_stream(self.flat_grad.device).cuda_stream
             with torch.cuda.device(self.flat_grad.device):

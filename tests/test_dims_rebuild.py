@@ -55,6 +55,31 @@ def test_dims_define():
             dims_define(bad)
 
 
+def test_library_built_with_other_widths_is_stale(tmp_path, monkeypatch):
+    """Round-3 advisor finding: a non-default OARD_DIMS build overwrote liboard_hip.so and the next default build() kept it (newer
+    than the sources).  The widths a library was built with are recorded next to it; a mismatch means rebuild."""
+    from oareactdiff_amd import build as B
+    lib = os.path.join(tmp_path, "liboard_x.so")
+    calls = []
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        open(lib, "w").close()
+    monkeypatch.setattr(B, "LIB", lib)
+    monkeypatch.setattr(B.subprocess, "run", fake_run)
+    monkeypatch.setenv("OARD_DIMS", "64x16")
+    B.build()
+    assert len(calls) == 1 and B._built_dims() == "64x16"
+    B.build()
+    assert len(calls) == 1                                   # same widths, library newer than the sources: kept
+    monkeypatch.delenv("OARD_DIMS")
+    B.build()
+    assert len(calls) == 2 and B._built_dims() == B.DEFAULT_DIMS and any("X(196,96)" in a for a in calls[1])
+    os.remove(lib + ".dims")
+    B.build()
+    assert len(calls) == 3                                   # unknown widths: rebuilt
+
+
 @pytest.mark.gpu
 def test_rebuild_with_another_width_matches_the_oracle(tmp_path):
     lib = os.path.join(tmp_path, "liboard_dims.so")

@@ -108,6 +108,44 @@ def test_rejects_non_complete_topology():
             dyn(*a)
 
 
+@pytest.mark.parametrize("name", ["g1_wrapper_small", "g3_cutoff_ragged"])
+def test_any_ordering_of_the_complete_edge_set_is_accepted(name):
+    """`EGNNDynamics.forward` takes any `edge_index` (egnn_dynamics.py:63-72); outputs are per node, so a PERMUTATION of the edge
+    list `get_edges_index` builds (utils/_graph_tools.py:30-36) is the same computation: bit-identical outputs.  A duplicated, a
+    missing, a self or a cross-sample edge is still refused."""
+    from oareactdiff_amd._capi import OardError
+    dev = torch.device("cuda:0")
+    c = Case(name)
+    dyn = _dyn(c, dev)
+    a = list(_args(c, dev))
+    E = a[1].shape[1]
+    with torch.no_grad():
+        want, _ = dyn(*a)
+        for seed in (0, 1):
+            perm = torch.randperm(E, generator=torch.Generator().manual_seed(seed)).to(dev)
+            b = list(a)
+            b[1] = a[1][:, perm].contiguous()
+            got, _ = dyn(*b)
+            assert all(torch.equal(x, y) for x, y in zip(got, want))
+        b[1] = a[1].flip(1).contiguous()                    # reversed order
+        got, _ = dyn(*b)
+        assert all(torch.equal(x, y) for x, y in zip(got, want))
+    bad = []
+    dup = a[1].clone(); dup[:, 1] = dup[:, 0]; bad.append(dup)                      # one edge twice, one missing (same count)
+    slf = a[1].clone(); slf[1, 0] = slf[0, 0]; bad.append(slf)                      # a self edge
+    cm = c.combined_mask
+    other = int((cm != cm[int(a[1][0, 0])]).nonzero()[0]) if len(torch.unique(cm)) > 1 else None
+    if other is not None:
+        crs = a[1].clone(); crs[1, 0] = other; bad.append(crs)                      # an edge between two samples
+    oob = a[1].clone(); oob[1, 0] = cm.numel(); bad.append(oob)                     # node id out of range
+    for ei in bad:
+        b = list(a)
+        b[1] = ei
+        with pytest.raises(OardError):
+            with torch.no_grad():
+                dyn(*b)
+
+
 def _random_case(sizes, pos_scale, seed, cfg):
     """Ragged synthetic batch (reactions of different atom counts), production feature layout."""
     from oareactdiff_amd.graph_tools import get_edges_index, get_mask_for_frag, get_n_frag_switch

@@ -1,8 +1,13 @@
 """The optional split-precision edge kernels (GCL and EquiMessage, csrc/oard_edge_b3.h: every fp32 value as three bf16 terms, six bf16 MFMAs per
 K block, fp32 accumulation) against the same bar as the fp32 kernel: the reference evaluated in float64, <= 1e-5 of the largest
-output, on every golden case in the throughput launch shapes and inside the B = 64 launch bench.py times.  The option is read when
-the weights are packed, so every case builds a fresh module inside the option's scope.  (OARD_GCL_B3=1 runs the WHOLE GPU suite on
-this kernel.)"""
+output, on every golden case in the throughput launch shapes and inside the B = 64 launch bench.py times.  The choice is a module
+attribute (`EGNNDynamics.edge_precision`) that travels with every library call as `oard_config.precision` - the library has no
+process-wide precision state.  (OARD_GCL_B3=1 OARD_EQUI_B3=1 OARD_TRAIN_B3=1 make it the default of every module whose attribute is
+None: the WHOLE GPU suite then runs on these kernels.)"""
+import threading
+
+import os
+
 import pytest
 import torch
 
@@ -18,10 +23,10 @@ def test_split_precision_forward_matches_reference_f64(name):
     dev = torch.device("cuda:0")
     c = Case(name)
     with torch.no_grad():
-        with debug_options(gcl_b3=0, equi_b3=0):
-            out32, _ = _dyn(c, dev)(*_args(c, dev))                   # the fp32 kernels
-        with debug_options(gcl_b3=1, equi_b3=1):
-            out, _ = _dyn(c, dev)(*_args(c, dev))
+        d32, d3 = _dyn(c, dev), _dyn(c, dev)
+        d32.edge_precision, d3.edge_precision = "f32", "bf16x3"
+        out32, _ = d32(*_args(c, dev))                                # the fp32 kernels
+        out, _ = d3(*_args(c, dev))
     v, h = c.split([o.cpu() for o in out])
     v32, h32 = c.split([o.cpu() for o in out32])
     rv, rh = c.split(c.ref64)
@@ -40,8 +45,9 @@ def test_split_precision_benched_launch(parts):
     dev = torch.device("cuda:0")
     c = Case("g2_prod_b2_n23")
     B, nf = 64, 23
-    with debug_options(parts=parts, gcl_b3=1, equi_b3=1):
+    with debug_options(parts=parts):
         dyn, _, _ = _prod_dynamics(dev, c.cfg)
+        dyn.edge_precision = "bf16x3"
         cm, nfs, ei, masks = make_topology(B, nf)
         xh = make_inputs(B, nf, masks, 99, "cpu")
         g = torch.Generator().manual_seed(1)
@@ -62,19 +68,14 @@ def test_split_precision_benched_launch(parts):
 def test_edge_precision_attribute_switches_kernels_per_module():
     """`EGNNDynamics.edge_precision`: "bf16x3" / "f32" select the kernels for that module's calls (and repack its weights when the
     choice changes); two modules with different choices can be used alternately."""
-    from oareactdiff_amd import _capi
     dev = torch.device("cuda:0")
     c = Case("g2_prod_b2_n23")
     a, b = _dyn(c, dev), _dyn(c, dev)
     a.edge_precision, b.edge_precision = "bf16x3", "f32"
-    try:
-        with torch.no_grad():
-            oa1, _ = a(*_args(c, dev)); ob1, _ = b(*_args(c, dev)); oa2, _ = a(*_args(c, dev)); ob2, _ = b(*_args(c, dev))
-            b.edge_precision = "bf16x3"
-            ob3, _ = b(*_args(c, dev))
-    finally:
-        _capi.lib().oard_debug_option(b"gcl_b3", 0)
-        _capi.lib().oard_debug_option(b"equi_b3", 0)
+    with torch.no_grad():
+        oa1, _ = a(*_args(c, dev)); ob1, _ = b(*_args(c, dev)); oa2, _ = a(*_args(c, dev)); ob2, _ = b(*_args(c, dev))
+        b.edge_precision = "bf16x3"
+        ob3, _ = b(*_args(c, dev))
     assert all(torch.equal(x, y) for x, y in zip(oa1, oa2)) and all(torch.equal(x, y) for x, y in zip(ob1, ob2))
     assert not all(torch.equal(x, y) for x, y in zip(oa1, ob1))          # different kernels
     assert all(torch.equal(x, y) for x, y in zip(oa1, ob3))              # same kernels, same weights -> same bits
@@ -89,5 +90,64 @@ def test_split_precision_training_forward_gradients(name):
     """The optional split-precision TRAINING-mode forward (tape written by k_gcl_edge_b3 / k_equi_edge_b3<TRAIN>; fp32 backward): the
     training step's loss and gradients against the reference's float64 autograd with the tolerances of tests/test_grad.py."""
     from test_grad import test_hip_training_step_gradients_match_reference_f64 as run_case
-    with debug_options(train_b3=1):
+    old = os.environ.get("OARD_TRAIN_B3")
+    os.environ["OARD_TRAIN_B3"] = "1"             # the default of `train_edge_precision = None`, resolved at every call
+    try:
         run_case(name)
+    finally:
+        if old is None:
+            del os.environ["OARD_TRAIN_B3"]
+        else:
+            os.environ["OARD_TRAIN_B3"] = old
+
+
+def test_default_none_never_inherits_another_modules_choice(monkeypatch):
+    """Round-3 advisor finding: a module left at `edge_precision = None` used to run whatever process-wide flags the last OTHER
+    module had set - on a bf16 weight stream it had never packed.  None now resolves to the environment's default at every call."""
+    monkeypatch.delenv("OARD_GCL_B3", raising=False)
+    monkeypatch.delenv("OARD_EQUI_B3", raising=False)
+    dev = torch.device("cuda:0")
+    c = Case("g2_prod_b2_n23")
+    ref32, b, a = _dyn(c, dev), _dyn(c, dev), _dyn(c, dev)
+    ref32.edge_precision, a.edge_precision = "f32", "bf16x3"
+    with torch.no_grad():
+        want, _ = ref32(*_args(c, dev))
+        ob1, _ = b(*_args(c, dev))                     # b packs its weights with no bf16 stream
+        a(*_args(c, dev))                              # a runs the split-precision kernels
+        ob2, _ = b(*_args(c, dev))                     # b must still be the fp32 module
+    assert all(torch.equal(x, y) for x, y in zip(want, ob1)) and all(torch.equal(x, y) for x, y in zip(want, ob2))
+
+
+def test_two_precisions_on_two_threads_and_streams_are_bitwise_reproducible():
+    """SURVEY 8(b) "thread-safe for distinct workspaces": an fp32 module and a split-precision module called alternately from two
+    host threads, each on its own stream, give exactly the bits of their single-threaded runs."""
+    dev = torch.device("cuda:0")
+    c = Case("g2_prod_b2_n23")
+    mods = [_dyn(c, dev), _dyn(c, dev)]
+    mods[0].edge_precision, mods[1].edge_precision = "f32", "bf16x3"
+    args = [_args(c, dev), _args(c, dev)]
+    with torch.no_grad():
+        want = [[o.clone() for o in m(*a)[0]] for m, a in zip(mods, args)]
+    torch.cuda.synchronize()
+    N_CALLS, errors, got = 40, [], [None, None]
+    start = threading.Barrier(2)
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st), torch.no_grad():
+                start.wait()
+                outs = [[o.clone() for o in mods[i](*args[i])[0]] for _ in range(N_CALLS)]
+            st.synchronize()
+            got[i] = outs
+        except Exception as e:                         # pragma: no cover
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for i in range(2):
+        for outs in got[i]:
+            assert all(torch.equal(x, y) for x, y in zip(outs, want[i]))
+    assert not all(torch.equal(x, y) for x, y in zip(want[0], want[1]))

@@ -138,8 +138,7 @@ def test_fused_training_lowers_a_fixed_objective():
     curves = {}
     for fused in (True, False):
         tr = _trainer(c, dev, fused, True)
-        tr.opt_config["lr"] = 2e-3
-        for g in tr.optimizer.param_groups:
+        for g in tr.optimizer.param_groups:          # the one place the learning rate lives, in both modes
             g["lr"] = 2e-3
         losses = []
         for step in range(60):
@@ -150,3 +149,56 @@ def test_fused_training_lowers_a_fixed_objective():
     print("fixed objective: fused", [round(x, 4) for x in f[::10]], "generic", [round(x, 4) for x in g[::10]])
     assert all(torch.isfinite(torch.tensor(f))) and f[-1] < 0.7 * f[0], (f[0], f[-1])
     assert all(torch.isfinite(torch.tensor(g))) and g[-1] < 0.7 * g[0], (g[0], g[-1])
+
+
+def test_fused_step_follows_optimizer_param_groups_and_resumes_from_state_dict():
+    """Round-3 advisor finding: `trainer.optimizer` is what a caller attaches an LR scheduler to (pl_trainer.py:149-151); the fused
+    step reads its hyper-parameters from `optimizer.param_groups[0]` at every step, and `state_dict()` / `load_state_dict()` carry
+    the fused AdamW moments, the step counter and the clipping history: a resumed trainer continues bit-identically."""
+    c = GradCase("g9_grad_h32")
+    dev = torch.device("cuda:0")
+    B = len(c.meta["sizes"])
+    batch = (c.reps(torch.float32, dev), torch.zeros(B, 1, device=dev))
+
+    def run(tr, steps, seed0):
+        out = []
+        for k in range(steps):
+            torch.manual_seed(seed0 + k)
+            out.append(tr.training_step(batch)["loss"])
+            tr_sched[id(tr)].step()
+        return out
+    tr_sched = {}
+    a = _trainer(c, dev, True, True)
+    tr_sched[id(a)] = torch.optim.lr_scheduler.StepLR(a.optimizer, step_size=2, gamma=0.5)
+    w0 = a.flat_param.clone()
+    run(a, 2, 0)
+    assert a.optimizer.param_groups[0]["lr"] == pytest.approx(0.5 * a.opt_config["lr"])
+    # a zero learning rate set through the param group freezes the weights: the fused kernel reads the group, not a private copy
+    frozen = _trainer(c, dev, True, True)
+    tr_sched[id(frozen)] = torch.optim.lr_scheduler.StepLR(frozen.optimizer, step_size=1000)
+    frozen.optimizer.param_groups[0]["lr"] = 0.0
+    run(frozen, 2, 0)
+    assert torch.equal(frozen.flat_param, w0) and not torch.equal(a.flat_param, w0)
+    # resume: module weights + trainer state into a fresh trainer, then both continue identically
+    msd = {k: v.clone() for k, v in a.dynamics.state_dict().items()}
+    tsd, ssd = a.state_dict(), tr_sched[id(a)].state_dict()
+    rest_a = run(a, 3, 100)
+    b = _trainer(c, dev, True, True)
+    b.dynamics.load_state_dict(msd, strict=True)
+    b.load_state_dict(tsd)
+    tr_sched[id(b)] = torch.optim.lr_scheduler.StepLR(b.optimizer, step_size=2, gamma=0.5)
+    tr_sched[id(b)].load_state_dict(ssd)
+    rest_b = run(b, 3, 100)
+    assert rest_a == rest_b and torch.equal(a.flat_param, b.flat_param)
+    assert torch.equal(a.exp_avg_sq, b.exp_avg_sq) and a.opt_step == b.opt_step == 5
+    assert a.gradnorm_queue.items == b.gradnorm_queue.items
+
+
+def test_fused_true_is_refused_where_the_fused_kernels_do_not_apply():
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.trainer import DDPMTrainer
+    c = GradCase("g9_grad_h32")
+    dev = torch.device("cuda:0")
+    dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=NODE_NFS, edge_nf=0, condition_nf=CNF, device=dev)
+    with pytest.raises(ValueError):
+        DDPMTrainer(dyn, timesteps=c.meta["T"], loss_type="vlb", fused=True)

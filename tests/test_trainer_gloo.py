@@ -163,3 +163,36 @@ def test_gradient_clipping_follows_the_reference_rule():
     assert abs(allowed - 1.5e-3) < 1e-12 and norm > allowed
     assert abs(float(torch.linalg.vector_norm(tr.flat_grad)) - allowed) <= 1e-6 * allowed
     assert tr.gradnorm_queue.items[0] == allowed                 # the clipped value enters the history (pl_trainer.py:409-412)
+
+
+def test_trainer_state_dict_resumes_the_generic_path():
+    """`DDPMTrainer.state_dict()` / `load_state_dict()` on the generic (autograd + torch.optim.AdamW) path: optimiser state, clipping
+    history and skipped-step counter survive a save / restore into a freshly built trainer; the continuation is bit-identical.
+    `fused=True` is refused off the HIP module (the fused kernels implement the float32 l2 objective only)."""
+    import pytest
+    from oareactdiff_amd.trainer import DDPMTrainer
+
+    def steps(tr, n):
+        out = []
+        for _ in range(n):
+            batch, t_int, draw = _batch(SIZES, 0, len(SIZES))
+            out.append(tr.training_step(batch, t_int=t_int, draw=draw)["loss"])
+        return out
+    a = DDPMTrainer(_oracle_dynamics(), timesteps=T, norm_values=(1.0, 4.0, 10.0), scales=(1.0, 2.0, 1.0))
+    assert not a.fused
+    steps(a, 2)
+    msd = {k: v.clone() for k, v in a.dynamics.state_dict().items()}
+    tsd = a.state_dict()
+    rest_a = steps(a, 2)
+    b = DDPMTrainer(_oracle_dynamics(), timesteps=T, norm_values=(1.0, 4.0, 10.0), scales=(1.0, 2.0, 1.0))
+    b.dynamics.load_state_dict(msd, strict=True)
+    b.load_state_dict(tsd)
+    assert b.gradnorm_queue.items == tsd["gradnorm_queue"] and len(b.gradnorm_queue) == 3
+    rest_b = steps(b, 2)
+    assert rest_a == rest_b
+    for p, q in zip(a.params, b.params):
+        assert torch.equal(p, q)
+    with pytest.raises(ValueError):
+        DDPMTrainer(_oracle_dynamics(), timesteps=T, fused=True)
+    with pytest.raises(ValueError):
+        b.load_state_dict(dict(tsd, names=["x"]))
