@@ -43,11 +43,12 @@ def cpu_model() -> str:
 
 
 def cpu_baseline(n_atoms: int):
-    """Times the CPU oracle (dense reference formulation, float32) on the host's cores, SURVEY.md section 8d: B in {1, 8}
-    reactions at 16 threads (and, opt-in, at every core of the host: measured non-scaling, see below) with >= 3 timed calls each
-    after one warm-up, then B = 64 (the benched batch) with ONE timed call if its projected duration fits the budget (no
-    extrapolation to T = 1000).  `value` = the best reaction-steps/s of all runs, `cores` = the threads that run used; every
-    run is listed with its thread count."""
+    """Times the CPU oracle (dense reference formulation, float32) on the host's cores, SURVEY.md section 8d.  Everything in the
+    result is MEASURED IN THIS RUN: B = 1 reaction at 16, 32, 64, ... torch threads (doubling up to the host's core count, stopping
+    at the first thread count that is slower than the one before - the eager formulation stops scaling early), then B = 8 at the
+    best of those; >= 3 timed calls each after one warm-up.  `value` = the best reaction-steps/s of all runs, `cores` = the threads
+    that run used; every run is listed with its thread count.  (The round-3 all-core measurement of this function on the MI355X
+    host - 256 threads: 84 s per B = 1 call - is on file in profiles/round3_bench_line_cpu_all_cores.json; it is not quoted here.)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import leftnet_oracle as oracle
     from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
@@ -55,7 +56,7 @@ def cpu_baseline(n_atoms: int):
     host_cores = os.cpu_count() or 1
     cfg = dict(PRODUCTION_LEFTNET_CONFIG)
     sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg)
-    budget = float(os.environ.get("OARD_CPU_BASELINE_SECONDS", "6"))
+    budget = float(os.environ.get("OARD_CPU_BASELINE_SECONDS", "4"))
     runs = []
 
     def case(B):
@@ -64,13 +65,12 @@ def cpu_baseline(n_atoms: int):
         return lambda: oracle.dynamics_forward(sd, cfg, xh, ei, torch.full((B, 1), 0.5), torch.zeros(B, 1), nfs, cm, 1,
                                                nodeframe="literal")
 
-    def timed(B, threads, call, min_calls, seconds, warm=True):
+    def timed(B, threads, call, min_calls, seconds, max_seconds):
         torch.set_num_threads(threads)
         with torch.no_grad():
-            if warm:
-                call()
+            call()                                             # warm-up
             calls, t0 = 0, time.perf_counter()
-            while calls < min_calls or (time.perf_counter() - t0 < seconds and calls < 40):
+            while (calls < min_calls and time.perf_counter() - t0 < max_seconds) or (time.perf_counter() - t0 < seconds and calls < 40):
                 call()
                 calls += 1
         dt = time.perf_counter() - t0
@@ -78,40 +78,28 @@ def cpu_baseline(n_atoms: int):
                      "reaction_steps_per_s": B * calls / dt})
         return runs[-1]
 
-    # The eager dense formulation stops scaling at ~16 threads and collapses with one thread per core of a large host: measured on the
-    # MI355X box (AMD EPYC 9575F, 256 logical cores; profiles/round3_bench_line_cpu_all_cores.json, round 3): B = 1 0.437 s per call at 16
-    # threads vs 84.2 s at 256; B = 8 5.07 s vs 146.3 s (0.012 / 0.055 instead of 2.29 / 1.58 reaction-steps/s).  The all-core run therefore
-    # is opt-in (OARD_CPU_BASELINE_ALL_CORES=1: ~15 minutes on that host); its measured result is carried in `documented_runs`.
-    thread_sets = sorted({max(1, min(host_cores, 16))} | ({host_cores} if os.environ.get("OARD_CPU_BASELINE_ALL_CORES") else set()))
-    for B in (1, 8):
-        call = case(B)
-        for th in thread_sets:
-            timed(B, th, call, 3, budget)
-    best8 = max((r for r in runs if r["batch"] == 8), key=lambda r: r["reaction_steps_per_s"])
-    projected = 64 * best8["s_per_call"] / 8
-    note64 = f"B=64 skipped: one call projected at {projected:.0f} s"
-    avail_gb = 0.0
-    try:
-        for line in open("/proc/meminfo"):
-            if line.startswith("MemAvailable"):
-                avail_gb = int(line.split()[1]) / 1e6
-    except OSError:
-        pass
-    if avail_gb < 24.0:                                        # the dense formulation peaks at ~15 GB of host memory at B = 64
-        note64 = f"B=64 skipped: {avail_gb:.0f} GB of host memory available, the dense formulation needs ~15 GB"
-    elif projected <= float(os.environ.get("OARD_CPU_BASELINE_B64_MAX_SECONDS", "60")):
-        timed(64, best8["threads"], case(64), 1, 0.0, warm=False)
-        note64 = "B=64: ONE timed call, no warm-up, at the better thread count of the B=8 runs"
+    call1 = case(1)
+    th, prev, stopped = min(16, host_cores), None, "the host's core count was reached"
+    while True:
+        r = timed(1, th, call1, 3, budget, 30.0)
+        if prev is not None and r["reaction_steps_per_s"] < prev["reaction_steps_per_s"]:
+            stopped = f"{th} threads were slower than {prev['threads']}"
+            break
+        prev = r
+        if th >= host_cores:
+            break
+        th = min(2 * th, host_cores)
+    best1 = max((r for r in runs if r["batch"] == 1), key=lambda r: r["reaction_steps_per_s"])
+    timed(8, best1["threads"], case(8), 3, budget, 45.0)
     best = max(runs, key=lambda r: r["reaction_steps_per_s"])
-    documented = [{"batch": 1, "threads": 256, "s_per_call": 84.23, "reaction_steps_per_s": 0.0119},
-                  {"batch": 8, "threads": 256, "s_per_call": 146.35, "reaction_steps_per_s": 0.0547},
-                  {"note": "all-core runs of this same function on the MI355X box host (AMD EPYC 9575F, 256 logical cores), round 3, "
-                           "profiles/round3_bench_line_cpu_all_cores.json; not re-measured in this run (OARD_CPU_BASELINE_ALL_CORES=1 does)"}]
+    swept = ", ".join(str(r["threads"]) for r in runs if r["batch"] == 1)
     return {"value": best["reaction_steps_per_s"], "unit": "reaction-steps/s", "cores": best["threads"], "kind": "port",
-            "host_cores": host_cores, "cpu_model": cpu_model(), "runs": runs, "documented_runs": documented,
-            "sample": f"oracle/leftnet_oracle.py (dense reference formulation), float32, {n_atoms}-atom triples; B in (1, 8) at "
-                      f"{' and '.join(str(t) for t in thread_sets)} torch threads ({host_cores}-core host), >= 3 calls / ~{budget:.0f} s "
-                      f"each after 1 warm-up; {note64}; value = best of all runs (B={best['batch']}, {best['threads']} threads)"}
+            "host_cores": host_cores, "cpu_model": cpu_model(), "runs": runs,
+            "sample": f"oracle/leftnet_oracle.py (dense reference formulation), float32, {n_atoms}-atom triples; B = 1 at {swept} torch "
+                      f"threads on the {host_cores}-core host (doubling; stopped because {stopped}), then B = 8 at {best1['threads']} "
+                      f"threads; >= 3 calls / ~{budget:.0f} s each after 1 warm-up, all measured in this run; value = best of all runs "
+                      f"(B={best['batch']}, {best['threads']} threads).  All-core record of round 3: "
+                      f"profiles/round3_bench_line_cpu_all_cores.json"}
 
 
 def source_stamp() -> str:
@@ -126,23 +114,25 @@ def source_stamp() -> str:
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel: str, batch: int, atoms: int, tag: str = None):
+PROFILE_TAG = os.environ.get("OARD_PROFILE_TAG", "round4")
+
+
+def pmc_traffic(kernel: str, prefix: str = None, tag: str = None):
     """HBM bytes per denoising step of all launches of `kernel`, from the committed PMC passes of this round
-    (profiles/<tag>_pmc_{fetch,write}.txt, collected by tools/profile.sh at the default workload): FETCH_SIZE
+    (profiles/<prefix>_pmc_{fetch,write}.txt, collected by tools/profile*.sh at the workload the prefix names): FETCH_SIZE
     (KiB; x2 - it under-reports wide streaming reads by 2x on gfx950, MI355X_MICROARCH.md HBM section) + WRITE_SIZE
-    (KiB).  Returns (bytes | None, note): None when the workload differs or when the profile was taken on other
-    kernel sources than the ones running now (profiles/<tag>_source_stamp.txt vs source_stamp())."""
+    (KiB).  Returns (bytes | None, note): None when the profile was taken on other kernel sources than the ones running now
+    (profiles/<tag>_source_stamp.txt vs source_stamp()) or is missing."""
     import re
-    tag = tag or os.environ.get("OARD_PROFILE_TAG", "round3")
-    if (batch, atoms) != (64, 23):
-        return None, "PMC passes exist for B=64 x 23 atoms only"
+    tag = tag or PROFILE_TAG
+    prefix = prefix or tag
     stamp_file = os.path.join(ROOT, "profiles", f"{tag}_source_stamp.txt")
     if not os.path.exists(stamp_file):
         return None, f"profiles/{tag}_source_stamp.txt missing: no PMC pass for this round yet"
     if open(stamp_file).read().strip() != source_stamp():
-        return None, f"kernel sources changed since profiles/{tag}_pmc_*.txt were collected: traffic not reported"
+        return None, f"kernel sources changed since profiles/{prefix}_pmc_*.txt were collected: traffic not reported"
     vals = {}
-    for key, fn in (("FETCH_SIZE", f"{tag}_pmc_fetch.txt"), ("WRITE_SIZE", f"{tag}_pmc_write.txt")):
+    for key, fn in (("FETCH_SIZE", f"{prefix}_pmc_fetch.txt"), ("WRITE_SIZE", f"{prefix}_pmc_write.txt")):
         path = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(path):
             return None, f"profiles/{fn} missing"
@@ -152,11 +142,11 @@ def pmc_traffic(kernel: str, batch: int, atoms: int, tag: str = None):
                 cur = line
             m = re.search(key + r"\s+per forward = ([0-9.e+]+)", line)
             if m and cur and kernel in cur:
-                vals[key] = float(m.group(1))
+                vals[key] = vals.get(key, 0.0) + float(m.group(1))
     if len(vals) != 2:
         return None, "kernel not found in the PMC summaries"
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
-        f"HBM bytes per step over all launches of this kernel: 2 x FETCH_SIZE + WRITE_SIZE, profiles/{tag}_pmc_*.txt (same sources: stamp {source_stamp()})"
+        f"HBM bytes per step over all launches of this kernel: 2 x FETCH_SIZE + WRITE_SIZE, profiles/{prefix}_pmc_*.txt (same sources: stamp {source_stamp()})"
 
 
 def make_training_batch(B: int, n_atoms: int, seed: int, dev):
@@ -249,6 +239,183 @@ def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
     return out, dt
 
 
+def new_dynamics(dev, precision="f32"):
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
+    cfg = dict(PRODUCTION_LEFTNET_CONFIG)
+    dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
+                       condition_nf=1, device=dev)
+    dyn.load_state_dict(synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg), strict=True)
+    dyn.nan_check = "async"                 # no host sync inside the step
+    if precision == "bf16x3":
+        dyn.edge_precision = "bf16x3"       # the split-precision edge kernels for this module's inference calls
+        dyn.train_edge_precision = "bf16x3" # ... and for its training-mode forward (--mode train; the backward stays fp32)
+    return dyn
+
+
+class Workload:
+    """Fixed-distribution inputs of one (B, atoms) shape, resident in HBM, cycled per step (fresh noise each step)."""
+
+    def __init__(self, B, nf, dev, seed, pos_scale=1.0, n_sets=4):
+        from oareactdiff_amd.synthetic import make_inputs, make_topology
+        self.B, self.nf, self.dev = B, nf, dev
+        cm, nfs, ei, masks = make_topology(B, nf)
+        self.cm, self.nfs, self.ei = cm.to(dev), nfs.to(dev), ei.to(dev)
+        self.inputs = [make_inputs(B, nf, masks, seed + k, dev, pos_scale) for k in range(n_sets)]
+        self.cond = torch.zeros(B, 1, device=dev)
+        self.ts = [torch.full((B, 1), (1000 - s) / 1000, device=dev) for s in range(8)]
+
+    def step(self, dyn, i):
+        with torch.no_grad():
+            dyn(self.inputs[i % len(self.inputs)], self.ei, self.ts[i % len(self.ts)], self.cond, self.nfs, self.cm)
+
+
+def timed_steps(step, steps, warmup, dev, dist=None):
+    """W untimed steps, then exactly K steps between (barrier +) device synchronisations; wall clock of THIS rank."""
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    return time.perf_counter() - t0
+
+
+def kernel_families(dyn, step, dev, calls=3):
+    """Per-family kernel time per step, HIP events on the launch stream (oard_timing_*), the batch as ONE sub-batch (whole-batch
+    launches, nothing overlapping): the figure a roofline fraction is about.  The timed steps run the default schedule (concurrent
+    sub-batches), which is faster than the sum of the isolated kernels."""
+    from oareactdiff_amd import _capi
+    L_ = _capi.lib()
+    L_.oard_debug_option(b"parts", 1)
+    dyn._topo_cache.clear()
+    step(0)
+    torch.cuda.synchronize(dev)
+    L_.oard_timing_reset()
+    L_.oard_timing_enable(1)
+    for i in range(calls):
+        step(i)
+    torch.cuda.synchronize(dev)
+    L_.oard_timing_enable(0)
+    L_.oard_debug_option(b"parts", int(os.environ.get("OARD_PARTS", "0")))
+    dyn._topo_cache.clear()
+    fam = {}
+    for f in ("gcl_edge", "equi_edge", "node", "init", "other"):
+        ms, n = _capi.timing_get(f)
+        fam[f] = {"avg_ms": ms / max(n, 1), "launches_per_step": n / calls, "ms_per_step": ms / calls}
+    return fam
+
+
+PEAK_BF16_MFMA = 2.5e15                       # MI355X_MICROARCH.md:42 (dense; the sparse figure is twice that)
+
+
+def roofline_of(fam, E, A, precision, traffic_prefix=None):
+    """`roofline` object of the dominant edge kernel.  fp32: algorithmic FLOPs against the fp32 MFMA peak.  bf16x3: both edge families
+    run on bf16 MFMAs - six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block of the fp32 product, i.e. 6 x the algorithmic FLOPs are
+    EXECUTED (plus padding) - against the dense bf16 MFMA peak, with the fp32-equivalent figure beside it."""
+    flops = fwd_flops(E, A)
+    dom = max(flops, key=lambda f: fam[f]["ms_per_step"])
+    oth = [f for f in flops if f != dom][0]
+    ach = flops[dom] / (fam[dom]["ms_per_step"] * 1e-3)
+    traffic, traffic_note = pmc_traffic("k_" + dom, traffic_prefix)
+    roof = {"bound": "mfma", "kernel": "k_" + dom, "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "traffic": traffic, "traffic_note": traffic_note,
+            "algorithmic_flops_per_step": flops[dom], "launches_per_step": fam[dom]["launches_per_step"],
+            "kernel_ms_per_step": fam[dom]["ms_per_step"], "avg_launch_ms": fam[dom]["avg_ms"],
+            "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},
+            "other_kernel": {"kernel": "k_" + oth, "achieved": flops[oth] / (fam[oth]["ms_per_step"] * 1e-3) / 1e12,
+                             "algorithmic_flops_per_step": flops[oth], "kernel_ms_per_step": fam[oth]["ms_per_step"]}}
+    if traffic is not None:
+        roof["hbm_gbps_while_running"] = traffic / (fam[dom]["ms_per_step"] * 1e-3) / 1e9
+        t2, _ = pmc_traffic("k_" + oth, traffic_prefix)
+        if t2 is not None:
+            roof["other_kernel"]["traffic"] = t2
+            roof["other_kernel"]["hbm_gbps_while_running"] = t2 / (fam[oth]["ms_per_step"] * 1e-3) / 1e9
+    if precision == "bf16x3":
+        roof.update({"achieved": 6 * ach / 1e12, "peak": PEAK_BF16_MFMA / 1e12, "frac": 6 * ach / PEAK_BF16_MFMA,
+                     "fp32_equivalent_tflops": ach / 1e12,
+                     "precision_note": "achieved = 6 x the algorithmic fp32 FLOPs per second (six bf16 products per fp32 product; "
+                                       "padding not counted) against the dense bf16 MFMA peak; fp32_equivalent_tflops = the "
+                                       "algorithmic figure the fp32 line reports"})
+        roof["other_kernel"]["fp32_equivalent_tflops"] = roof["other_kernel"]["achieved"]
+        roof["other_kernel"]["achieved"] *= 6
+    return roof
+
+
+def sampler_run(dyn, wl, T_run, dev):
+    """A genuine ancestral sampling run of T steps (T + 1 network calls + fused sampler kernel + RNG), timed end to end."""
+    from oareactdiff_amd.sampler import DiffusionSampler
+    B, nf = wl.B, wl.nf
+    frag = [torch.full((B,), nf, dtype=torch.long) for _ in range(3)]
+    h0 = [x[:, 3:].clone() for x in wl.inputs[0]]
+    warm = DiffusionSampler(dyn, "polynomial_2", 4, 1e-5, pos_only=True)
+    warm.sample(B, frag, conditions=wl.cond, h0=h0)                     # warm-up (topology, buffers)
+    smp = DiffusionSampler(dyn, "polynomial_2", T_run, 1e-5, pos_only=True)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    smp.sample(B, frag, conditions=wl.cond, h0=h0)
+    torch.cuda.synchronize(dev)
+    dts = time.perf_counter() - t1
+    per_call = dts / (T_run + 1)
+    return {"T": T_run, "network_calls": T_run + 1, "seconds": dts, "batch": B,
+            "ms_per_network_call_incl_sampler_step": per_call * 1e3,
+            "reactions_per_sec_measured" if T_run == 1000 else "reactions_per_sec_T1000_projected":
+                B / dts if T_run == 1000 else B / (1001 * per_call),
+            "note": "with untrained weights the trajectory leaves the 10 A cutoff after a few hundred steps, so the "
+                    "tail of this run is cheaper than the fixed-distribution steps of the headline value (SURVEY 8d)"}
+
+
+def second_line(dev, B, nf, steps, warmup, quick):
+    """The split-precision line (csrc/oard_edge_b3.h) measured by the SAME run as the headline: same B / atoms /
+    steps / warm-up, its own module (`edge_precision = "bf16x3"`), outside the headline's timed region.  fp32 stays the headline."""
+    dyn = new_dynamics(dev, "bf16x3")
+    wl = Workload(B, nf, dev, 1234)
+    step = lambda i: wl.step(dyn, i)                      # noqa: E731
+    dt = timed_steps(step, steps, warmup, dev)
+    assert int(dyn.last_status[0].item()) == 0, "NaN in the second line's timed region"
+    E, A = edge_counts(B, nf)
+    out = {"precision": "bf16x3", "dtype": "f32 via bf16x3 (the two edge stages: 3 bf16 terms per value, 6 bf16 MFMAs per K block, fp32 "
+                                           "accumulate; everything else f32)",
+           "value": B * steps / dt, "unit": "reaction-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+           "reactions_per_sec_T1000": B * steps / dt / 1001.0,
+           "roofline": roofline_of(kernel_families(dyn, step, dev), E, A, "bf16x3", PROFILE_TAG + "_bf16x3")}
+    if not quick:
+        out["sampler_loop"] = sampler_run(dyn, wl, 1000, dev)
+    return out
+
+
+def config5(dev, steps=6, warmup=2):
+    """BASELINE configs[4] - "Large synthetic fragments (128 atoms/object, dense radius graph) - LDS-tile / HBM-roofline stress": B = 4
+    reactions x 3 x 128 atoms (N = 1 536, E = 588 288 edge rows of 2 752 B, A = 195 072 inner edges), fp32, two position scales:
+    N(0, 1) (every intra-object pair inside the 10 A cutoff) and x 3 (the cutoff bites: ragged active set, node labelling).  Per
+    variant: ms per step (default schedule), per-family kernel time (one sub-batch), TFLOP/s of the two edge kernels against the
+    fp32 MFMA peak (the kernels run every inner row whether masked or not: same FLOPs in both variants), HBM GB/s from the
+    committed PMC passes of this workload (profiles/<round>_cfg5{n,x3}_pmc_*, tools/profile_cfg5.sh)."""
+    B, nf = 4, 128
+    E, A = edge_counts(B, nf)
+    out = {"workload": f"EGNNDynamics.forward (LEFTNet H=196 R=96 L=6), B={B} reactions x 3 objects x {nf} atoms (N={B * 3 * nf}, E={E}, "
+                       f"inner edges A={A}), fp32", "steps": steps, "warmup": warmup, "variants": {}}
+    for key, scale in (("n01", 1.0), ("x3", 3.0)):
+        dyn = new_dynamics(dev)
+        wl = Workload(B, nf, dev, 4242, pos_scale=scale, n_sets=2)
+        step = lambda i: wl.step(dyn, i)                  # noqa: E731
+        dt = timed_steps(step, steps, warmup, dev)
+        assert int(dyn.last_status[0].item()) == 0, "NaN in config 5"
+        fam = kernel_families(dyn, step, dev, calls=2)
+        roof = roofline_of(fam, E, A, "f32", PROFILE_TAG + "_cfg5" + ("n" if key == "n01" else "x3"))
+        out["variants"][key] = {"pos_scale": scale, "ms_per_step": dt / steps * 1e3, "reaction_steps_per_sec": B * steps / dt,
+                                "edge_rows_per_sec": E * steps / dt, "roofline": roof}
+        del dyn, wl
+        torch.cuda.empty_cache()
+    return out
+
+
 def dry_run(args, rank, world, dist, backend):
     """The multi-process skeleton of the timed region without a GPU (OARD_BENCH_DRY=1, tests/test_bench_multirank.py):
     per-rank stand-in steps, barrier on both sides, MAX of the wall clock over the ranks, ONE JSON line on rank 0."""
@@ -318,6 +485,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="reactions per GPU")
     ap.add_argument("--atoms", type=int, default=23, help="atoms per object")
+    ap.add_argument("--pos-scale", type=float, default=1.0, help="scale of the N(0,1) positions (3: the 10 A cutoff bites; BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("sample", "train"), default="sample",
                     help="sample: one denoising call per step (BASELINE configs 2/3); train: one training step (config 4)")
@@ -360,27 +528,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from oareactdiff_amd import _capi
-    from oareactdiff_amd.dynamics import EGNNDynamics
-    from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
-    from oareactdiff_amd.synthetic import make_inputs, make_topology
+    from oareactdiff_amd import _capi  # noqa: F401  (loads the library: fails loudly if it is missing)
 
-    cfg = dict(PRODUCTION_LEFTNET_CONFIG)
     B, nf = args.batch, args.atoms
-    dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
-                       condition_nf=1, device=dev)
-    dyn.load_state_dict(synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg), strict=True)
-    dyn.nan_check = "async"                 # no host sync inside the step
-    if args.precision == "bf16x3":
-        dyn.edge_precision = "bf16x3"       # the split-precision edge kernels for this module's inference calls
-        dyn.train_edge_precision = "bf16x3" # ... and for its training-mode forward (--mode train; the backward stays fp32)
-    cm, nfs, ei, masks = make_topology(B, nf)
-    cm, nfs, ei = cm.to(dev), nfs.to(dev), ei.to(dev)
-    # a few fixed-distribution input sets, resident in HBM, cycled per step (fresh noise each step)
-    inputs = [make_inputs(B, nf, masks, 1234 + 17 * rank + k, dev) for k in range(4)]
-    cond = torch.zeros(B, 1, device=dev)
-    T = 1000
-    ts = [torch.full((B, 1), (T - s) / T, device=dev) for s in range(8)]
+    dyn = new_dynamics(dev, args.precision)
+    wl = Workload(B, nf, dev, 1234 + 17 * rank, pos_scale=args.pos_scale)
 
     if args.mode == "train":
         leg, dt = train_leg(dyn, B, nf, dev, dist, world, args.steps, args.warmup, timing=(rank == 0))       # collective inside: all ranks
@@ -412,8 +564,7 @@ def main():
         return
 
     def eager_step(i):
-        with torch.no_grad():
-            dyn(inputs[i % len(inputs)], ei, ts[i % len(ts)], cond, nfs, cm)
+        wl.step(dyn, i)
 
     # Launch-bound batches (B <= 8: ~100 launches of a few microseconds each per call): the same call captured once per
     # input set as a hipGraph and replayed - same kernels, same arithmetic (tests: bit-identical), no host launch cost.
@@ -426,7 +577,7 @@ def main():
         with torch.cuda.stream(side):
             eager_step(0)
         torch.cuda.current_stream(dev).wait_stream(side)
-        for k in range(len(inputs)):
+        for k in range(len(wl.inputs)):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 eager_step(k)
@@ -438,19 +589,7 @@ def main():
         else:
             eager_step(i)
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = timed_steps(step, args.steps, args.warmup, dev, dist)      # W warm-up steps, barrier + sync, K steps, sync + barrier
     if dist is not None:
         tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -458,96 +597,36 @@ def main():
     if not os.environ.get("OARD_BENCH_ALLOW_NAN"):          # (kernel ablation experiments produce garbage on purpose)
         assert int(dyn.last_status[0].item()) == 0, "NaN in the timed region"
 
-    # per-kernel durations (HIP events on the launch stream), outside the timed region
+    # ---- everything below is outside the timed region, on rank 0 -------------------------------------------------------------------
     E, A = edge_counts(B, nf)
     roof = None
-    skip = set(filter(None, os.environ.get("OARD_BENCH_SKIP", "").split(",")))     # debugging: legs to leave out ("roofline", "sampler")
-    if rank == 0 and "roofline" not in skip:
-        # Kernels are timed in isolation on the WHOLE batch (one sub-batch, nothing overlapping): that is the
-        # figure a roofline fraction is about.  The timed region above runs the default schedule (4 concurrent
-        # sub-batches), which is faster than the sum of the isolated kernels.
-        L_ = _capi.lib()
-        L_.oard_debug_option(b"parts", 1)
-        dyn._topo_cache.clear()
-        eager_step(0)
-        torch.cuda.synchronize(dev)
-        L_.oard_timing_reset()
-        L_.oard_timing_enable(1)
-        for i in range(3):
-            eager_step(i)
-        torch.cuda.synchronize(dev)
-        L_.oard_timing_enable(0)
-        L_.oard_debug_option(b"parts", int(os.environ.get("OARD_PARTS", "0")))
-        dyn._topo_cache.clear()
-        fam = {}
-        for f in ("gcl_edge", "equi_edge", "node", "init", "other"):
-            ms, n = _capi.timing_get(f)
-            fam[f] = {"avg_ms": ms / max(n, 1), "launches_per_step": n / 3, "ms_per_step": ms / 3}
-        # algorithmic FLOPs per STEP of each hot kernel family (L launches of the Equi kernel; the GCL kernel runs
-        # once per layer on all edges, except that on inter-object edges the first layer has no S1 (constant
-        # initial state: exact structural shortcut) and the last layer no S3 (its result is never read)
-        flops = fwd_flops(E, A)
-        dom = max(flops, key=lambda f: fam[f]["ms_per_step"])
-        oth = [f for f in flops if f != dom][0]
-        ach = flops[dom] / (fam[dom]["ms_per_step"] * 1e-3)
-        traffic, traffic_note = pmc_traffic("k_" + dom, B, nf)
-        roof = {"bound": "mfma", "kernel": "k_" + dom, "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "traffic": traffic, "traffic_note": traffic_note,
-                "algorithmic_flops_per_step": flops[dom], "launches_per_step": fam[dom]["launches_per_step"],
-                "kernel_ms_per_step": fam[dom]["ms_per_step"], "avg_launch_ms": fam[dom]["avg_ms"],
-                "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},
-                "other_kernel": {"kernel": "k_" + oth, "achieved": flops[oth] / (fam[oth]["ms_per_step"] * 1e-3) / 1e12,
-                                 "algorithmic_flops_per_step": flops[oth], "kernel_ms_per_step": fam[oth]["ms_per_step"]}}
-        if args.precision == "bf16x3":
-            # both edge families run on bf16 MFMAs: six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block of the fp32 product, i.e. 6 x
-            # the algorithmic FLOPs are EXECUTED (plus padding); the roofline of these kernels is the dense bf16 MFMA peak
-            PEAK_BF16_MFMA = 2.5e15                       # MI355X_MICROARCH.md:42 (dense; the sparse figure is twice that)
-            roof.update({"achieved": 6 * ach / 1e12, "peak": PEAK_BF16_MFMA / 1e12, "frac": 6 * ach / PEAK_BF16_MFMA,
-                         "fp32_equivalent_tflops": ach / 1e12, "traffic": None,
-                         "traffic_note": "PMC passes of this line: profiles/round3_bf16x3_pmc_*.txt (tools/profile_b3.sh)",
-                         "precision_note": "achieved = 6 x the algorithmic fp32 FLOPs per second (six bf16 products per fp32 product; "
-                                           "padding not counted) against the dense bf16 MFMA peak; fp32_equivalent_tflops = the "
-                                           "algorithmic figure the fp32 line reports"})
-            roof["other_kernel"]["achieved"] *= 6
-            roof["other_kernel"]["fp32_equivalent_tflops"] = roof["other_kernel"]["achieved"] / 6
+    skip = set(filter(None, os.environ.get("OARD_BENCH_SKIP", "").split(",")))     # debugging: legs to leave out
+    std = (B, nf) == (64, 23)
+    if rank == 0 and "roofline" not in skip:               # per-kernel durations (HIP events on the launch stream)
+        prefix = (PROFILE_TAG if args.precision == "f32" else PROFILE_TAG + "_bf16x3") if std else "no-PMC-pass-for-this-shape"
+        roof = roofline_of(kernel_families(dyn, eager_step, dev), E, A, args.precision, prefix)
 
-    # the real sampling loop (row N1): a genuine ancestral sampling run of T steps (T+1 network calls + fused sampler
-    # kernel + RNG), timed end to end: the BASELINE metric's reactions/s, MEASURED (T = 1000 unless --quick)
-    sampler_leg = train = None
-    if rank == 0 and world == 1 and "sampler" not in skip and not os.environ.get("OARD_BENCH_ALLOW_NAN"):      # N > 1: the other ranks wait in a barrier meanwhile
-        from oareactdiff_amd.sampler import DiffusionSampler
-        frag = [torch.full((B,), nf, dtype=torch.long) for _ in range(3)]
-        h0 = [x[:, 3:].clone() for x in inputs[0]]
-        warm = DiffusionSampler(dyn, "polynomial_2", 4, 1e-5, pos_only=True)
-        warm.sample(B, frag, conditions=cond, h0=h0)                     # warm-up (topology, buffers)
-        T_run = 12 if args.quick else 1000
-        smp = DiffusionSampler(dyn, "polynomial_2", T_run, 1e-5, pos_only=True)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        smp.sample(B, frag, conditions=cond, h0=h0)
-        torch.cuda.synchronize(dev)
-        dts = time.perf_counter() - t1
-        per_call = dts / (T_run + 1)
-        sampler_leg = {"T": T_run, "network_calls": T_run + 1, "seconds": dts, "batch": B,
-                       "ms_per_network_call_incl_sampler_step": per_call * 1e3,
-                       "reactions_per_sec_measured" if T_run == 1000 else "reactions_per_sec_T1000_projected":
-                           B / dts if T_run == 1000 else B / (1001 * per_call),
-                       "note": "with untrained weights the trajectory leaves the 10 A cutoff after a few hundred steps, so the "
-                               "tail of this run is cheaper than the fixed-distribution steps of the headline value (SURVEY 8d)"}
-    if rank == 0 and not args.quick and world == 1 and args.precision == "f32":
-        dyn.nan_check = "async"
-        if os.environ.get("OARD_BENCH_EMPTY_CACHE", "1") != "0":
-            # the training step walks ~25 GB of tape / scratch per step; carved out of the caching allocator's left-overs of the legs
-            # above (next to their workspaces and topologies) it runs 5-8 % slower than `--mode train` does on fresh allocations
-            # (83 vs 77 ms measured), so the leg gets what that mode has: a fresh module and an allocator that starts empty
-            smp = warm = graphs = inputs = None
-            del dyn
+    # the real sampling loop (row N1): the BASELINE metric's reactions/s, MEASURED (T = 1000 unless --quick)
+    sampler_leg = train = second = cfg5 = None
+    extra = rank == 0 and world == 1 and not os.environ.get("OARD_BENCH_ALLOW_NAN")     # N > 1: the other ranks wait in a barrier meanwhile
+    if extra and "sampler" not in skip:
+        sampler_leg = sampler_run(dyn, wl, 12 if args.quick else 1000, dev)
+    full = extra and not args.quick and args.precision == "f32"
+    if full:
+        # the remaining legs get what their stand-alone modes have: fresh modules and an allocator that starts empty (the training
+        # step walks ~25 GB of tape / scratch; carved out of the other legs' left-overs it ran 5-8 % slower: 83 vs 77 ms measured)
+        graphs = wl = None
+        del dyn
+        torch.cuda.empty_cache()
+        if "train" not in skip:
+            train, _ = train_leg(new_dynamics(dev), B, nf, dev, None, 1, 10, 3)      # warm-up as in `--mode train`
             torch.cuda.empty_cache()
-            dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
-                               condition_nf=1, device=dev)
-            dyn.load_state_dict(synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg), strict=True)
-            dyn.nan_check = "async"
-        train, _ = train_leg(dyn, B, nf, dev, None, 1, 10, 3)      # warm-up as in `--mode train`
+        if "second_line" not in skip:
+            second = second_line(dev, B, nf, args.steps, args.warmup, args.quick)
+            torch.cuda.empty_cache()
+        if "config5" not in skip:
+            cfg5 = config5(dev)
+            torch.cuda.empty_cache()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -561,12 +640,14 @@ def main():
             "config": {"workload": f"EGNNDynamics.forward (LEFTNet H=196 R=96 L=6), B={B} reactions/GPU x 3 objects x "
                                    f"{nf} atoms, complete graph per reaction (N={B * 3 * nf}, E={E}), T=1000 sampler step shape",
                        "batch_per_gpu": B, "atoms_per_object": nf, "parallelism": f"replica x{world} (no collective)",
-                       "launch": "hipGraph replay (one captured call per input set)" if graphs else "eager"},
+                       "launch": "hipGraph replay (one captured call per input set)" if use_graph else "eager"},
             "batch_steps_per_sec_per_gpu": args.steps / dt,
             "reactions_per_sec_T1000": value / 1001.0,
             "roofline": roof,
             "sampler_loop": sampler_leg,
             "train_step": train,
+            "second_line": second,
+            "config5": cfg5,
         }
         if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(nf)
