@@ -12,6 +12,7 @@
 
 #include "oard_kernels.h"
 #include "oard_edge_v1.h"
+#include "oard_wgrad_t16.h"
 #include "oard_edge_b3.h"     // split-precision (3 x bf16, fp32 accumulate) variant of the GCL edge kernel: optional (debug option gcl_b3)
 #ifdef OARD_EXPERIMENTS
 #include "oard_edge_fp.h"     // barrier-free variant of the GCL kernel: measured slower (profiles/round2_gcl_phase_study.txt), experiment builds only
@@ -69,6 +70,7 @@ int g_parts = 0;            // sub-batches per topology (0 = auto: 4 for B >= 32
 int g_small_split = 128;     // EquiMessage latency kernel: launches of <= this many 16-edge tiles run one launch per dense stage
                             // (a workgroup = 16 edges x 8 output tiles); 0 = never
 int g_wgrad_shapes = 3;       // bit k: workgroup shape kWglShapes[k] of the LDS-panel kernel may be chosen (A/B: debug option wgrad_shapes)
+int g_wgrad_t16 = 256;       // workgroups per weight-gradient GEMM of the 16 x 16-tile kernel (oard_wgrad_t16.h; 0: never use it)
 int g_wgrad_lds = 256;       // workgroups per weight-gradient GEMM of the LDS-panel kernel (0: always the per-wave-tile kernel k_wgrad)
 int g_wgrad_wgs = 512;       // workgroups per weight-gradient GEMM (row chunks x task groups): one round of 2 x 4 waves per CU
                             // (measured per training step: 384 -> 38.1 ms, 512 -> 30.7, 768 -> 36.0, 1024 -> 33.2, 2048 -> 38.1)
@@ -1468,10 +1470,58 @@ int oard_lin3u_backward(const oard_config* c, const void* packed, int layer, con
     return OARD_OK;
 }
 
+// ---- plan of the 16 x 16-tile kernel (oard_wgrad_t16.h): a pure function of the shape ------------------------------------------------
+struct WgtPlan { int ok, transposed, MT, NT, nPT, nQT, TM, TN, n_chunks, grid; long long rpc; };
+// kernel instantiations: (largest wave tile TM x TN, SiLU on the Q operand, column sums: 0 none / 1 of P / 2 of Q)
+#define OARD_WGT_INSTANCES X(6, 7, false, 0) X(6, 7, false, 1) X(6, 7, false, 2) X(4, 7, true, 1) X(4, 7, false, 1) X(5, 7, true, 1)
+static bool wgt_instance(int TM, int TN, bool silu, int bias) {
+#define X(tm_, tn_, s_, b_) if (TM == tm_ && TN == tn_ && silu == s_ && bias == b_) return true;
+    OARD_WGT_INSTANCES
+#undef X
+    return false;
+}
+static WgtPlan wgt_plan(int ncY, int ncX, long long rows, int x_silu, int want_bias) {
+    WgtPlan best;
+    memset(&best, 0, sizeof(best));
+    if (g_wgrad_t16 <= 0 || rows < 16384 || (ncY & 15) || (ncX & 15)) return best;
+    const int tY = ncY / 16, tX = ncX / 16;
+    const int transposed = (!x_silu && tX > tY) ? 1 : 0;      // P (dealt 4 ways, up to 24 tiles per workgroup) = the wider operand; SiLU exists for Q only
+    const int MT = transposed ? tX : tY, NT = transposed ? tY : tX;
+    const int bias = want_bias ? (transposed ? 2 : 1) : 0;
+    double best_cost = 0;
+    for (int nPT = (int)cdiv(MT, 24); nPT <= (int)cdiv(MT, 24) + 1; ++nPT)
+        for (int nQT = (int)cdiv(NT, 14); nQT <= (int)cdiv(NT, 14) + 2; ++nQT) {
+            const int lp = (int)cdiv(MT, nPT), lq = (int)cdiv(NT, nQT);
+            const int TM = (int)cdiv(lp, 4), TN = (int)cdiv(lq, 2);
+            if (lp < 4 || lq < 2 || !wgt_instance(TM, TN, x_silu != 0, bias)) continue;
+            const int ntile = nPT * nQT;
+            long long nch = std::max<long long>(8, (long long)g_wgrad_t16 / ntile / 8 * 8);
+            nch = std::min(nch, std::max<long long>(1, cdiv(rows, 4 * WGT_R)));
+            const long long rpc = align_up((size_t)cdiv(rows, nch), WGT_R);
+            nch = cdiv(rows, rpc);
+            const long long grid = cdiv(nch, 8) * 8 * ntile;
+            // MFMAs per 4 rows of the busiest SIMD (waves w and w + 4: P part w x Q part 0, P part (w + 2) % 4 x Q part 1)
+            int simd = 0;
+            for (int w = 0; w < 4; ++w)
+                simd = std::max(simd, wgt_size(lp, 4, w) * wgt_size(lq, 2, 0) + wgt_size(lp, 4, (w + 2) & 3) * wgt_size(lq, 2, 1));
+            const double cost = (double)cdiv(grid, 256) * (double)rpc * simd;
+            if (!best.ok || cost < best_cost) {
+                best_cost = cost;
+                best = WgtPlan{1, transposed, MT, NT, nPT, nQT, TM, TN, (int)nch, (int)grid, rpc};
+            }
+        }
+    return best;
+}
+
 size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows) {
     if (ncY < 4 || ncX < 4 || rows < 0) return 0;
     const WgradPlan p = wgrad_plan(ncY, ncX, rows);
-    const size_t big = ((size_t)p.n_chunks * p.PP * p.QP + (size_t)p.n_chunks * std::max(p.PP, p.QP)) * sizeof(float);
+    size_t big = ((size_t)p.n_chunks * p.PP * p.QP + (size_t)p.n_chunks * std::max(p.PP, p.QP)) * sizeof(float);
+    for (int silu = 0; silu < 2; ++silu)
+        for (int bias = 0; bias < 2; ++bias) {
+            const WgtPlan t = wgt_plan(ncY, ncX, rows, silu, bias);
+            if (t.ok) big = std::max(big, ((size_t)t.n_chunks * t.MT * t.NT * 256 + (size_t)t.n_chunks * 16 * std::max(t.MT, t.NT)) * sizeof(float));
+        }
     return std::max(big, (size_t)1024 * 1024 * sizeof(float));        // the small-output path: <= 1024 chunks x <= 1024 outputs
 }
 
@@ -1485,11 +1535,40 @@ static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, i
         return OARD_EINVAL;
     if (((MO - 1) / o_len) * o_pad + (MO - 1) % o_len >= ncY || ((MI - 1) / i_len) * i_pad + (MI - 1) % i_len >= ncX)
         return OARD_EINVAL;
-    const WgradPlan p = wgrad_plan(ncY, ncX, rows);
-    if (x_silu && p.transposed) return OARD_EINVAL;          // SiLU-on-load exists for the narrow operand only (never needed otherwise)
     if (scratch_bytes < oard_wgrad_scratch_bytes(ncY, ncX, rows)) return OARD_ENOMEM;
     float* partial = (float*)scratch;
-    if (o_len >= MO && i_len >= MI && MO <= 64 && MI < 64 && MO * (MI + 1) <= 1024) {      // small, unsectioned outputs
+    const bool small_out = o_len >= MO && i_len >= MI && MO <= 64 && MI < 64 && MO * (MI + 1) <= 1024;
+    const WgtPlan t = small_out ? WgtPlan{} : wgt_plan(ncY, ncX, rows, x_silu, db != nullptr);
+    if (t.ok) {                                              // long contraction, 16-aligned operands: the 16 x 16-tile kernel
+        const int PP = t.MT * 16, QP = t.NT * 16;
+        float* bpart = partial + (size_t)t.n_chunks * PP * QP;
+        WgtArgs a;
+        a.P = t.transposed ? X : dY; a.Q = t.transposed ? dY : X;
+        a.ldP = t.transposed ? ldX : ldY; a.ldQ = t.transposed ? ldY : ldX;
+        a.MT = t.MT; a.NT = t.NT; a.nPT = t.nPT; a.nQT = t.nQT; a.r0 = 0; a.r1 = rows; a.rpc = t.rpc; a.n_chunks = t.n_chunks;
+        a.partial = partial; a.psum = (db && !t.transposed) ? bpart : nullptr; a.qsum = (db && t.transposed) ? bpart : nullptr;
+        const int bias = db ? (t.transposed ? 2 : 1) : 0;
+        bool launched = false;
+#define X(tm_, tn_, s_, b_) if (!launched && t.TM == tm_ && t.TN == tn_ && (x_silu != 0) == s_ && bias == b_) { \
+            LAUNCH_LDS(F_WGRAD, (k_wgrad_t16<tm_, tn_, s_, b_>), t.grid, 512, WGT_LDS_BYTES, st, a); launched = true; }
+        OARD_WGT_INSTANCES
+#undef X
+        if (!launched) return OARD_EINVAL;
+        {
+            ScopedLaunch sl_(F_WGRAD, st);
+            if (dW)
+                hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 32)), dim3(256), 0, st, partial, t.n_chunks, PP,
+                                   QP, t.transposed, o_len, o_pad, MO, i_len, i_pad, MI, dW, ldW, acc);
+            if (db)
+                hipLaunchKernelGGL(k_bgrad_reduce, dim3((unsigned)cdiv(MO, 4)), dim3(256), 0, st, bpart, t.n_chunks,
+                                   t.transposed ? QP : PP, o_len, o_pad, MO, db, acc);
+        }
+        HIP_TRY(hipGetLastError());
+        return OARD_OK;
+    }
+    const WgradPlan p = wgrad_plan(ncY, ncX, rows);
+    if (x_silu && p.transposed) return OARD_EINVAL;          // SiLU-on-load exists for the narrow operand only (never needed otherwise)
+    if (small_out) {      // small, unsectioned outputs
         const int n_chunks = (int)std::max<long long>(1, std::min<long long>(1024, cdiv(rows, 256)));
         const long long rpc = align_up((size_t)cdiv(std::max<long long>(rows, 1), n_chunks), 64);
         const int nch = (int)cdiv(std::max<long long>(rows, 1), rpc);
@@ -1778,6 +1857,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "auto_tiny") == 0) { g_auto_tiny = value; return OARD_OK; }
     if (strcmp(name, "npb") == 0) { g_npb = value; return OARD_OK; }
     if (strcmp(name, "wgrad_wgs") == 0) { g_wgrad_wgs = value; return OARD_OK; }
+    if (strcmp(name, "wgrad_t16") == 0) { g_wgrad_t16 = value; return OARD_OK; }
     if (strcmp(name, "wgrad_lds") == 0) { g_wgrad_lds = value; return OARD_OK; }
     if (strcmp(name, "wgrad_shapes") == 0) { g_wgrad_shapes = value & 3; return OARD_OK; }
     if (strcmp(name, "train_dual") == 0) { g_train_dual = value; return OARD_OK; }

@@ -55,11 +55,22 @@ def test_wgrad_small_outputs(rows):
     _case(rows, 8, 8, 8, 8, 48, 48, 48, 48, False, True, seed=rows + 1)
 
 
+@pytest.fixture(params=["t16", "lds"])
+def long_kernel(request):
+    """Which kernel serves the long contractions: "t16" = k_wgrad_t16 (round 4, the default: 16 x 16 tiles on both operands, rows
+    streamed by LDS-DMA into a three-buffer ring, SiLU applied in LDS); "lds" = round 3's k_wgrad_lds / k_wgrad (debug option
+    wgrad_t16 = 0), kept as the cross-check and for shapes the tile kernel has no instantiation for."""
+    from oareactdiff_amd import _capi
+    assert _capi.lib().oard_debug_option(b"wgrad_t16", 256 if request.param == "t16" else 0) == 0
+    yield request.param
+    _capi.lib().oard_debug_option(b"wgrad_t16", 256)
+
+
 @pytest.mark.parametrize("rows", [16384, 16385, 20011, 40000])
-def test_wgrad_lds_panel_kernel(rows):
-    """rows >= 16 384 with at least two 16-tile groups on the narrow side run k_wgrad_lds (row panels of 32 rows shared through
-    LDS by the eight (P block, Q group) tasks of a workgroup): ragged last groups / chunks, partial 64-column blocks, partial
-    tile groups (37 tiles = 4 full groups of 8 + 5), section padding, SiLU applied when the panel is staged, column sums."""
+def test_wgrad_long_contractions(rows, long_kernel):
+    """rows >= 16 384 on the five shapes of a layer: ragged last 16-row groups / chunks (rows beyond the chunk are zero-filled in LDS),
+    workgroup tiles of 22 + 21 and 13 + 12 + 12 tiles, section padding (three 196-wide thirds stored 208 apart), SiLU applied to the
+    staged panel, column sums on the P side and on the Q side, a leading dimension wider than the operand."""
     _case(rows, 688, 684, 684, 684, 208, 196, 196, 196, False, True, seed=rows)                    # edge_out_trans: dz3 x m
     _case(rows, 208, 196, 196, 196, 688, 684, 684, 684, False, False, seed=rows + 1)               # edge_mlp.0 (transposed product)
     _case(rows, 624, 196, 208, 588, 592, 588, 588, 588, True, True, seed=rows + 2, ld_extra=8)     # dir_proj.2: SiLU on load, thirds
@@ -67,19 +78,57 @@ def test_wgrad_lds_panel_kernel(rows):
     _case(rows, 208, 196, 196, 196, 208, 196, 196, 196, True, True, seed=rows + 4)                 # edge_mlp.1
 
 
-def test_wgrad_lds_and_per_wave_kernels_agree():
-    """A/B of the two kernels on one shape through the debug option (deterministic each, equal up to summation order)."""
+def test_wgrad_three_kernels_agree():
+    """A/B of the three kernels on one shape through the debug options (deterministic each, equal up to summation order)."""
     from oareactdiff_amd import _capi
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(3)
     rows = 30000
     dY, X = torch.randn(rows, 688, generator=g).to(dev), torch.randn(rows, 208, generator=g).to(dev)
     out = {}
-    for mode in (256, 0):
-        assert _capi.lib().oard_debug_option(b"wgrad_lds", mode) == 0
-        out[mode] = training._wgrad(dY, 688, 684, 684, 684, X, 208, False, 196, 196, 196, rows, True, _Owner(), torch.cuda.current_stream().cuda_stream)
-        again = training._wgrad(dY, 688, 684, 684, 684, X, 208, False, 196, 196, 196, rows, True, _Owner(), torch.cuda.current_stream().cuda_stream)
-        assert torch.equal(out[mode][0], again[0]) and torch.equal(out[mode][1], again[1])       # run-to-run deterministic
-    _capi.lib().oard_debug_option(b"wgrad_lds", 256)
-    assert float((out[256][0] - out[0][0]).abs().max()) <= 2e-6 * float(out[0][0].abs().max())
-    assert float((out[256][1] - out[0][1]).abs().max()) <= 2e-6 * float(out[0][1].abs().max())
+    try:
+        for name, t16, lds in (("t16", 256, 256), ("lds", 0, 256), ("wave", 0, 0)):
+            assert _capi.lib().oard_debug_option(b"wgrad_t16", t16) == 0 and _capi.lib().oard_debug_option(b"wgrad_lds", lds) == 0
+            out[name] = training._wgrad(dY, 688, 684, 684, 684, X, 208, False, 196, 196, 196, rows, True, _Owner(), torch.cuda.current_stream().cuda_stream)
+            again = training._wgrad(dY, 688, 684, 684, 684, X, 208, False, 196, 196, 196, rows, True, _Owner(), torch.cuda.current_stream().cuda_stream)
+            assert torch.equal(out[name][0], again[0]) and torch.equal(out[name][1], again[1])       # run-to-run deterministic
+    finally:
+        _capi.lib().oard_debug_option(b"wgrad_t16", 256)
+        _capi.lib().oard_debug_option(b"wgrad_lds", 256)
+    for name in ("t16", "lds"):
+        assert float((out[name][0] - out["wave"][0]).abs().max()) <= 2e-6 * float(out["wave"][0].abs().max())
+        assert float((out[name][1] - out["wave"][1]).abs().max()) <= 2e-6 * float(out["wave"][1].abs().max())
+    assert not torch.equal(out["t16"][0], out["lds"][0])                 # really different kernels (summation order)
+
+
+def test_wgrad_tile_kernel_speed_report():
+    """Not a gate: prints the time of the five long products of one layer at B = 64 under both kernels."""
+    from oareactdiff_amd import _capi
+    dev = torch.device("cuda:0")
+    E, A = 300288, 97152
+    shapes = [("edge_out_trans", E, 688, 684, 684, 684, 208, 196, 196, 196, False, True),
+              ("edge_mlp.1", E, 208, 196, 196, 196, 208, 196, 196, 196, True, True),
+              ("edge_mlp.0", E, 208, 196, 196, 196, 688, 684, 684, 684, False, False),
+              ("dir_proj.2", A, 624, 196, 208, 588, 592, 588, 588, 588, True, True),
+              ("dir_proj.0", A, 592, 588, 588, 588, 688, 684, 684, 684, False, True)]
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        for name, rows, ncY, ol, op, MO, ncX, il, ip, MI, silu, bias in shapes:
+            dY, X = torch.randn(rows, ncY, device=dev), torch.randn(rows, ncX, device=dev)
+            line = []
+            for kern, t16 in (("t16", 256), ("lds", 0)):
+                _capi.lib().oard_debug_option(b"wgrad_t16", t16)
+                own = _Owner()
+                for _ in range(2):
+                    training._wgrad(dY, ncY, ol, op, MO, X, ncX, silu, il, ip, MI, rows, bias, own, st)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(5):
+                    training._wgrad(dY, ncY, ol, op, MO, X, ncX, silu, il, ip, MI, rows, bias, own, st)
+                b.record()
+                torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 5
+                line.append(f"{kern} {ms:.3f} ms = {2.0 * rows * MO * MI / ms / 1e9:.1f} TF/s")
+            print(f"wgrad {name:15s} rows {rows}: " + " | ".join(line))
+    finally:
+        _capi.lib().oard_debug_option(b"wgrad_t16", 256)
