@@ -1472,28 +1472,27 @@ int oard_lin3u_backward(const oard_config* c, const void* packed, int layer, con
 
 // ---- plan of the 16 x 16-tile kernel (oard_wgrad_t16.h): a pure function of the shape ------------------------------------------------
 struct WgtPlan { int ok, transposed, MT, NT, nPT, nQT, TM, TN, n_chunks, grid; long long rpc; };
-// kernel instantiations: (largest wave tile TM x TN, SiLU on the Q operand, column sums: 0 none / 1 of P / 2 of Q)
-#define OARD_WGT_INSTANCES X(6, 7, false, 0) X(6, 7, false, 1) X(6, 7, false, 2) X(4, 7, true, 1) X(4, 7, false, 1) X(5, 7, true, 1)
-static bool wgt_instance(int TM, int TN, bool silu, int bias) {
-#define X(tm_, tn_, s_, b_) if (TM == tm_ && TN == tn_ && silu == s_ && bias == b_) return true;
+// kernel instantiations: (largest wave tile TM x TN, SiLU on the Q operand)
+#define OARD_WGT_INSTANCES X(6, 7, false) X(4, 7, true) X(4, 7, false) X(5, 7, true)
+static bool wgt_instance(int TM, int TN, bool silu) {
+#define X(tm_, tn_, s_) if (TM == tm_ && TN == tn_ && silu == s_) return true;
     OARD_WGT_INSTANCES
 #undef X
     return false;
 }
-static WgtPlan wgt_plan(int ncY, int ncX, long long rows, int x_silu, int want_bias) {
+static WgtPlan wgt_plan(int ncY, int ncX, long long rows, int x_silu) {
     WgtPlan best;
     memset(&best, 0, sizeof(best));
     if (g_wgrad_t16 <= 0 || rows < 16384 || (ncY & 15) || (ncX & 15)) return best;
     const int tY = ncY / 16, tX = ncX / 16;
-    const int transposed = (!x_silu && tX > tY) ? 1 : 0;      // P (dealt 4 ways, up to 24 tiles per workgroup) = the wider operand; SiLU exists for Q only
+    const int transposed = (!x_silu && tX > tY) ? 1 : 0;      // P (dealt 4 ways, up to 22 tiles per workgroup) = the wider operand; SiLU exists for Q only
     const int MT = transposed ? tX : tY, NT = transposed ? tY : tX;
-    const int bias = want_bias ? (transposed ? 2 : 1) : 0;
     double best_cost = 0;
-    for (int nPT = (int)cdiv(MT, 24); nPT <= (int)cdiv(MT, 24) + 1; ++nPT)
-        for (int nQT = (int)cdiv(NT, 14); nQT <= (int)cdiv(NT, 14) + 2; ++nQT) {
+    for (int nPT = (int)cdiv(MT, WGT_PT); nPT <= (int)cdiv(MT, WGT_PT) + 1; ++nPT)
+        for (int nQT = (int)cdiv(NT, WGT_QT); nQT <= (int)cdiv(NT, WGT_QT) + 2; ++nQT) {
             const int lp = (int)cdiv(MT, nPT), lq = (int)cdiv(NT, nQT);
             const int TM = (int)cdiv(lp, 4), TN = (int)cdiv(lq, 2);
-            if (lp < 4 || lq < 2 || !wgt_instance(TM, TN, x_silu != 0, bias)) continue;
+            if (lp < 4 || lq < 2 || !wgt_instance(TM, TN, x_silu != 0)) continue;
             const int ntile = nPT * nQT;
             long long nch = std::max<long long>(8, (long long)g_wgrad_t16 / ntile / 8 * 8);
             nch = std::min(nch, std::max<long long>(1, cdiv(rows, 4 * WGT_R)));
@@ -1512,16 +1511,20 @@ static WgtPlan wgt_plan(int ncY, int ncX, long long rows, int x_silu, int want_b
         }
     return best;
 }
+// a padded column of X that no logical input feature maps to (the ones column that turns the product's padded output into db), or -1
+static int wgt_ones_col(int ncX, int i_len, int i_pad, int MI) {
+    if (i_pad > i_len) return i_len;                               // the pad of the first section
+    return MI < ncX ? MI : -1;                                     // i_pad == i_len: unsectioned, the first column behind the features
+}
 
 size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows) {
     if (ncY < 4 || ncX < 4 || rows < 0) return 0;
     const WgradPlan p = wgrad_plan(ncY, ncX, rows);
     size_t big = ((size_t)p.n_chunks * p.PP * p.QP + (size_t)p.n_chunks * std::max(p.PP, p.QP)) * sizeof(float);
-    for (int silu = 0; silu < 2; ++silu)
-        for (int bias = 0; bias < 2; ++bias) {
-            const WgtPlan t = wgt_plan(ncY, ncX, rows, silu, bias);
-            if (t.ok) big = std::max(big, ((size_t)t.n_chunks * t.MT * t.NT * 256 + (size_t)t.n_chunks * 16 * std::max(t.MT, t.NT)) * sizeof(float));
-        }
+    for (int silu = 0; silu < 2; ++silu) {
+        const WgtPlan t = wgt_plan(ncY, ncX, rows, silu);
+        if (t.ok) big = std::max(big, (size_t)t.n_chunks * t.MT * t.NT * 256 * sizeof(float));
+    }
     return std::max(big, (size_t)1024 * 1024 * sizeof(float));        // the small-output path: <= 1024 chunks x <= 1024 outputs
 }
 
@@ -1538,19 +1541,19 @@ static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, i
     if (scratch_bytes < oard_wgrad_scratch_bytes(ncY, ncX, rows)) return OARD_ENOMEM;
     float* partial = (float*)scratch;
     const bool small_out = o_len >= MO && i_len >= MI && MO <= 64 && MI < 64 && MO * (MI + 1) <= 1024;
-    const WgtPlan t = small_out ? WgtPlan{} : wgt_plan(ncY, ncX, rows, x_silu, db != nullptr);
+    const int ones = db ? wgt_ones_col(ncX, i_len, i_pad, MI) : -1;
+    const WgtPlan t = (small_out || (db && ones < 0)) ? WgtPlan{} : wgt_plan(ncY, ncX, rows, x_silu);
     if (t.ok) {                                              // long contraction, 16-aligned operands: the 16 x 16-tile kernel
         const int PP = t.MT * 16, QP = t.NT * 16;
-        float* bpart = partial + (size_t)t.n_chunks * PP * QP;
         WgtArgs a;
         a.P = t.transposed ? X : dY; a.Q = t.transposed ? dY : X;
         a.ldP = t.transposed ? ldX : ldY; a.ldQ = t.transposed ? ldY : ldX;
         a.MT = t.MT; a.NT = t.NT; a.nPT = t.nPT; a.nQT = t.nQT; a.r0 = 0; a.r1 = rows; a.rpc = t.rpc; a.n_chunks = t.n_chunks;
-        a.partial = partial; a.psum = (db && !t.transposed) ? bpart : nullptr; a.qsum = (db && t.transposed) ? bpart : nullptr;
-        const int bias = db ? (t.transposed ? 2 : 1) : 0;
+        a.ones_side = db ? (t.transposed ? 1 : 2) : 0; a.ones_col = db ? ones : 0;
+        a.partial = partial;
         bool launched = false;
-#define X(tm_, tn_, s_, b_) if (!launched && t.TM == tm_ && t.TN == tn_ && (x_silu != 0) == s_ && bias == b_) { \
-            LAUNCH_LDS(F_WGRAD, (k_wgrad_t16<tm_, tn_, s_, b_>), t.grid, 512, WGT_LDS_BYTES, st, a); launched = true; }
+#define X(tm_, tn_, s_) if (!launched && t.TM == tm_ && t.TN == tn_ && (x_silu != 0) == s_) { \
+            LAUNCH_LDS(F_WGRAD, (k_wgrad_t16<tm_, tn_, s_>), t.grid, 512, WGT_LDS_BYTES, st, a); launched = true; }
         OARD_WGT_INSTANCES
 #undef X
         if (!launched) return OARD_EINVAL;
@@ -1559,9 +1562,10 @@ static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, i
             if (dW)
                 hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 32)), dim3(256), 0, st, partial, t.n_chunks, PP,
                                    QP, t.transposed, o_len, o_pad, MO, i_len, i_pad, MI, dW, ldW, acc);
-            if (db)
-                hipLaunchKernelGGL(k_bgrad_reduce, dim3((unsigned)cdiv(MO, 4)), dim3(256), 0, st, bpart, t.n_chunks,
-                                   t.transposed ? QP : PP, o_len, o_pad, MO, db, acc);
+            if (db)      // the product's padded column (row, when transposed) that the ones column of X produced
+                hipLaunchKernelGGL(k_wgt_bias_reduce, dim3((unsigned)cdiv(MO, 4)), dim3(256), 0, st, partial, t.n_chunks, (size_t)PP * QP,
+                                   t.transposed ? (size_t)ones * QP : (size_t)ones, t.transposed ? (size_t)1 : (size_t)QP, o_len, o_pad, MO,
+                                   db, acc);
         }
         HIP_TRY(hipGetLastError());
         return OARD_OK;

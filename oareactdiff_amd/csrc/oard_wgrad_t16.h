@@ -18,55 +18,76 @@
 //   * tiles are dealt to the waves so that the two waves of a SIMD (w and w + 4) get one large and one small tile set: for
 //     22 x 13 tiles every SIMD executes 71 or 72 tile-MFMAs per 4 rows (the even deal would give 78 / 65);
 //   * rows are streamed HBM -> LDS by LDS-DMA (global_load_lds, 16 bytes per lane, no VGPR round trip) in groups of 16 rows
-//     into a ring of three 40-KB buffers, two groups ahead; one barrier per group (~10 000 MFMA cycles per SIMD);
-//   * SiLU-on-load (X = SiLU(z), two of the five products per layer) is applied IN LDS, once per element, to the group that
-//     has landed but is not yet being read (the same barrier publishes it).
+//     into a ring of FOUR 37-KB buffers, three groups ahead.  One barrier per group (~10 000 MFMA cycles per SIMD), and it sits
+//     in the MIDDLE of a group's MFMA steps: it publishes data that is needed two steps later at the earliest, so the operands of
+//     a group's first step are read from LDS during the last step of the group before (no barrier, no LDS latency at a group's
+//     start), and a wave that waits at the barrier leaves its SIMD partner a full queue of MFMAs;
+//   * SiLU-on-load (X = SiLU(z), two of the five products per layer) is applied IN LDS, once per element, two groups ahead
+//     (after the barrier that saw the group land, published by the next one);
+//   * the bias gradient (column sums of dY) costs nothing: X always has a spare pad column (196 -> 208, 588 -> 592, 684 -> 688);
+//     it is overwritten by 1.0 in LDS, and the product's padded output column IS db.
 // Both operands of an MFMA step are plain ds_read_b32 (lane (g, i): row 4 s + g, feature 16 t + i of the panel; the panel's
-// row strides are = 16 mod 32 floats, so the two rows a 32-lane half reads sit in different banks): 13 reads per 42 MFMAs.
+// row strides are = 16 mod 32 floats, so the two rows a 32-lane half reads sit in different banks): 13 reads per 42 MFMAs,
+// requested one step ahead.
 // Deterministic: fixed chunking, per-chunk partials, the fixed-order reduce passes of oard_edge_bwd.h (k_wgrad_reduce /
 // k_bgrad_reduce).  Layout of the partials: [chunk][PP][QP], P-major (P = the operand with more tiles), psum [chunk][PP],
 // qsum [chunk][QP] - exactly k_wgrad's, so the reduce passes are shared.
 #pragma once
 #include "oard_edge_bwd.h"
 
+// timing-only ablations of an experiment build (results are garbage): -DOARD_WGT_ABL=1 no vmcnt wait at the group barrier, 2 no
+// barrier, 3 neither, 4 no LDS-DMA issue in the loop
+#ifndef OARD_WGT_ABL
+#define OARD_WGT_ABL 0
+#endif
+OARD_DEV void wgt_barrier() {
+    if (OARD_WGT_ABL != 1 && OARD_WGT_ABL != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (OARD_WGT_ABL != 2 && OARD_WGT_ABL != 3) __syncthreads();
+}
 #define WGT_R 16                           // rows per group
-#define WGT_SP 400                         // P panel row stride (floats): <= 24 tiles (384) + 16
-#define WGT_SQ 240                         // Q panel row stride: <= 14 tiles (224) + 16
-#define WGT_BUF (WGT_R * (WGT_SP + WGT_SQ))        // floats per ring buffer (40 KB)
-#define WGT_RING 3
+#define WGT_PT 22                          // P tiles per workgroup at most (4 waves x <= 6)
+#define WGT_QT 13                          // Q tiles per workgroup at most (2 waves x <= 7)
+#define WGT_SP (16 * WGT_PT + (WGT_PT % 2 ? 0 : 16))       // P panel row stride (floats), = 16 mod 32: the two rows a 32-lane half of a
+#define WGT_SQ (16 * WGT_QT + (WGT_QT % 2 ? 0 : 16))       // ds_read_b32 touches sit 16 banks apart (Q: 208, P: 368)
+#define WGT_BUF (WGT_R * (WGT_SP + WGT_SQ))        // floats per ring buffer (37 KB)
+#define WGT_RING 4
 #define WGT_LDS_BYTES ((size_t)WGT_RING * WGT_BUF * sizeof(float))
 
 struct WgtArgs {
-    const float* P; const float* Q;        // row-major operands; columns [0, 16 MT) / [0, 16 NT) are readable (pads are zero)
+    const float* P; const float* Q;        // row-major operands; columns [0, 16 MT) / [0, 16 NT) are readable
     int ldP, ldQ;
     int MT, NT;                            // 16-feature tiles of P / Q
-    int nPT, nQT;                          // workgroup tiles along P / Q (a workgroup: <= 4 TM x 2 TN tiles)
+    int nPT, nQT;                          // workgroup tiles along P / Q (a workgroup: <= WGT_PT x WGT_QT tiles)
     long long r0, r1, rpc;                 // rows [r0, r1), rows per chunk (multiple of WGT_R)
     int n_chunks;
+    int ones_side, ones_col;               // 1 / 2: column ones_col of P / Q reads as 1.0 (bias gradient through X's pad column); 0: none
     float* partial;                        // [n_chunks][16 MT][16 NT]
-    float* psum;                           // [n_chunks][16 MT] column sums of P (bias gradient when P = dY), or nullptr
-    float* qsum;                           // [n_chunks][16 NT] column sums of Q, or nullptr
 };
 
 // part k of `n` tiles cut into `parts` nearly equal pieces (the larger pieces first): [start, start + size)
-OARD_DEV int wgt_start(int n, int parts, int k) { return k * (n / parts) + (k < n % parts ? k : n % parts); }
+__host__ __device__ inline int wgt_start(int n, int parts, int k) { return k * (n / parts) + (k < n % parts ? k : n % parts); }
 __host__ __device__ inline int wgt_size(int n, int parts, int k) { return n / parts + (k < n % parts ? 1 : 0); }
 
-template <int TMV, int TNV, bool QSILU, int BIAS>
+template <int TMV, int TNV, bool QSILU>
 OARD_DEV void wgt_run(const WgtArgs& a, float* smem, int wave, int lane, int chunk, int p_tile0, int p_tiles, int q_tile0, int q_tiles,
-                      int pl0, int tm, int ql0, int tn, bool want_ps, bool want_qs) {
+                      int pl0, int tm, int ql0, int tn) {
     // p_tile0 / p_tiles: this WORKGROUP's P tiles (absolute first tile, count); pl0 / tm: this WAVE's first tile inside them and its
-    // tile count (tm <= TMV; with tm < TMV the surplus accumulators are never stored)
+    // tile count (tm <= TMV; with tm < TMV the surplus accumulators read whatever follows the wave's last tile - inside the LDS
+    // allocation - and are never stored)
     const int g = lane >> 4, i = lane & 15, tid = wave * 64 + lane;
     const long long rb = a.r0 + (long long)chunk * a.rpc;
     const long long re = rb + a.rpc < a.r1 ? rb + a.rpc : a.r1;
-    const int ngroups = (int)((re - rb + WGT_R - 1) / WGT_R);
+    const int ng = (int)((re - rb + WGT_R - 1) / WGT_R);
     const int wP4 = p_tiles * 4, wQ4 = q_tiles * 4;                 // float4 per panel row
-    const float* gP = a.P + (size_t)p_tile0 * 16 + 4 * lane;         // + row * ldP
-    const float* gQ = a.Q + (size_t)q_tile0 * 16 + 4 * lane;
+    const float* gP = a.P + (size_t)p_tile0 * 16;                    // wave-uniform; + row * ldP
+    const float* gQ = a.Q + (size_t)q_tile0 * 16;
+    const unsigned lane_off = (unsigned)lane * 16u;                  // LDS-DMA source = uniform row address (SGPR pair) + this 32-bit lane offset
+    auto ring = [&](int grp) -> float* { return smem + (size_t)(grp & (WGT_RING - 1)) * WGT_BUF; };
 
-    auto issue = [&](int grp) {                                      // rows `wave` and `wave + 8` of group grp -> ring buffer grp % 3
-        float* buf = smem + (size_t)(grp % WGT_RING) * WGT_BUF;
+    // this wave's share of group grp -> its ring buffer: rows `wave` and `wave + 8`, per row the first 64 float4 of the P part, the
+    // rest of it, the Q part (1-KiB LDS-DMA pieces, lanes beyond the part masked off)
+    auto issue = [&](int grp) {
+        float* buf = ring(grp);
 #pragma unroll
         for (int h = 0; h < WGT_R / 8; ++h) {
             const int r = wave + 8 * h;
@@ -76,28 +97,39 @@ OARD_DEV void wgt_run(const WgtArgs& a, float* smem, int wave, int lane, int chu
             if (row < re) {                                          // wave-uniform
                 const float* sp = gP + (size_t)row * a.ldP;
                 const float* sq = gQ + (size_t)row * a.ldQ;
-                if (lane < wP4) glds16(sp, dP);
-                if (lane + 64 < wP4) glds16(sp + 256, dP + 256);
-                if (lane < wQ4) glds16(sq, dQ);
-            } else {                                                 // beyond the chunk: the row counts as zero in both operands
-                if (lane < wP4) st_f4(dP + 4 * lane, f4zero());
-                if (lane + 64 < wP4) st_f4(dP + 256 + 4 * lane, f4zero());
-                if (lane < wQ4) st_f4(dQ + 4 * lane, f4zero());
+                if (lane < wP4) glds16u(sp, lane_off, dP);
+                if (lane + 64 < wP4) glds16u(sp + 256, lane_off, dP + 256);
+                if (lane < wQ4) glds16u(sq, lane_off, dQ);
+            } else {                                                 // beyond the chunk (last group only): the row counts as zero in both operands
+                for (int c = lane; c < 4 * wP4; c += 64) dP[c] = 0.f;
+                for (int c = lane; c < 4 * wQ4; c += 64) dQ[c] = 0.f;
             }
         }
     };
-    // SiLU in place on the Q panel of a landed group: float4 number tid, tid + 512 of its WGT_R x wQ4 grid
-    int so[2];
+    // In-LDS fix-ups of a landed group, once per element: SiLU on the Q panel (float4 number tid, tid + 512 of its WGT_R x wQ4
+    // grid) and the ones column (X's pad column := 1.0, so that the padded output column of the product is the bias gradient).
+    // The ones column of a SiLU operand is set by the thread that rewrites that float4 (no second writer).
+    const int op_local = a.ones_side == 1 ? a.ones_col - 16 * p_tile0 : -1, oq_local = a.ones_side == 2 ? a.ones_col - 16 * q_tile0 : -1;
+    const bool ones_p = op_local >= 0 && op_local < 16 * p_tiles, ones_q = oq_local >= 0 && oq_local < 16 * q_tiles;
+    int so[2], sone[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int idx = tid + 512 * k;
-        so[k] = idx < WGT_R * wQ4 ? (idx / wQ4) * WGT_SQ + 4 * (idx % wQ4) : -1;
+        const int idx = tid + 512 * k, c4 = idx % wQ4;
+        so[k] = (QSILU && idx < WGT_R * wQ4) ? (idx / wQ4) * WGT_SQ + 4 * c4 : -1;
+        sone[k] = (ones_q && c4 == (oq_local >> 2)) ? (oq_local & 3) : -1;
     }
-    auto transform = [&](int grp) {
-        float* q = smem + (size_t)(grp % WGT_RING) * WGT_BUF + WGT_R * WGT_SP;
+    auto fixup = [&](int grp) {
+        float* q = ring(grp) + WGT_R * WGT_SP;
+        if (QSILU) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            if (so[k] >= 0) st_f4(q + so[k], silu4(ld_f4(q + so[k])));
+            for (int k = 0; k < 2; ++k)
+                if (so[k] >= 0) {
+                    f4 v = silu4(ld_f4(q + so[k]));
+                    if (sone[k] == 0) v.x = 1.0f; else if (sone[k] == 1) v.y = 1.0f; else if (sone[k] == 2) v.z = 1.0f; else if (sone[k] == 3) v.w = 1.0f;
+                    st_f4(q + so[k], v);
+                }
+        } else if (ones_q && tid < WGT_R) q[tid * WGT_SQ + oq_local] = 1.0f;
+        if (ones_p && tid < WGT_R) ring(grp)[tid * WGT_SP + op_local] = 1.0f;
     };
 
     f4 acc[TMV][TNV];
@@ -105,49 +137,66 @@ OARD_DEV void wgt_run(const WgtArgs& a, float* smem, int wave, int lane, int chu
     for (int x = 0; x < TMV; ++x)
 #pragma unroll
         for (int y = 0; y < TNV; ++y) acc[x][y] = f4zero();
-    // column sums of the dY operand (the bias gradient; never the SiLU operand): thread tid owns column tid of the workgroup's P
-    // (BIAS 1) or Q (BIAS 2) panel and adds its 16 rows of every group in row order - one register, work spread over all waves
-    float bsum = 0.f;
-    const bool bias_on = BIAS == 1 ? (want_ps && tid < 4 * wP4) : (BIAS == 2 ? (want_qs && tid < 4 * wQ4) : false);
-    auto colsum = [&](int grp) {
-        const float* col = smem + (size_t)(grp % WGT_RING) * WGT_BUF + (BIAS == 1 ? tid : WGT_R * WGT_SP + tid);
-#pragma unroll
-        for (int r = 0; r < WGT_R; ++r) bsum += col[r * (BIAS == 1 ? WGT_SP : WGT_SQ)];
-    };
-    // per-lane read offset (floats) inside a buffer; tile x / y of this wave is a compile-time displacement from it.  A wave with
-    // fewer tiles than its variant has accumulators (tm < TMV) reads whatever follows its last tile - inside the LDS allocation,
-    // values never stored
+    // per-lane read offset (floats) inside a buffer; tile x / y of this wave is a compile-time displacement from it
     const int oa = g * WGT_SP + 16 * pl0 + i, ob = WGT_R * WGT_SP + g * WGT_SQ + 16 * ql0 + i;
+    // One MFMA step with the NEXT step's operand reads dealt out between its MFMAs.  The MFMAs are volatile asm statements: (1) the
+    // accumulator is updated in place ("+v" - with the builtin hipcc writes many results to fresh registers and copies, which cost
+    // 39 spilled registers here), (2) volatile asm and memory operations keep their program order, so the LDS reads below stay exactly
+    // where they are written - a wave never waits for LDS with an empty MFMA queue.  Hazards the compiler cannot see inside the asm:
+    // none in this loop (A / B come from LDS - s_waitcnt, which the compiler does insert for asm operands; an accumulator is touched
+    // once per 30+ MFMAs); the epilogue puts two s_nop 15 in front of its stores.
+    float av[2][TMV], bv[2][TNV];
+    auto rd = [&](int slot, const float* buf, int s, int k) {        // operand number k of step s: the TMV A tiles first, then the TNV B tiles
+        if (k < TMV) av[slot][k] = buf[oa + 4 * s * WGT_SP + 16 * k];
+        else bv[slot][k - TMV] = buf[ob + 4 * s * WGT_SQ + 16 * (k - TMV)];
+    };
+    auto load = [&](int slot, int grp, int s) {
+        const float* buf = ring(grp);
+#pragma unroll
+        for (int k = 0; k < TMV + TNV; ++k) rd(slot, buf, s, k);
+    };
+    // step on operand set `slot`; if `next`: set slot ^ 1 := operands of (ngrp, ns), one LDS read after every PER MFMAs
+    auto step = [&](int slot, bool next, int ngrp, int ns) {
+        constexpr int NR = TMV + TNV, NM = TMV * TNV, PER = NM / NR > 0 ? NM / NR : 1;
+        const float* nbuf = ring(ngrp);
+        int m = 0, k = 0;
+#pragma unroll
+        for (int y = 0; y < TNV; ++y)
+#pragma unroll
+            for (int x = 0; x < TMV; ++x) {
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[x][y]) : "v"(av[slot][x]), "v"(bv[slot][y]));
+                ++m;
+                if (m % PER == 0 && k < NR) { if (next) rd(slot ^ 1, nbuf, ns, k); ++k; }
+            }
+#pragma unroll
+        for (; k < NR; ++k) if (next) rd(slot ^ 1, nbuf, ns, k);
+    };
 
+    // ---- prologue: three groups in flight, the first two fixed up ------------------------------------------------------------------
     issue(0);
+    if (ng > 1) issue(1);
+    if (ng > 2) issue(2);
     phase_barrier();
-    if (QSILU) transform(0);
-    if (ngroups > 1) issue(1);
-    for (int grp = 0; grp < ngroups; ++grp) {
-        phase_barrier();                                             // group grp + 1 landed, transform(grp) visible, buffer (grp + 2) % 3 free
-        if (grp + 2 < ngroups) issue(grp + 2);
-        if (QSILU && grp + 1 < ngroups) transform(grp + 1);
-        if (BIAS != 0 && bias_on) colsum(grp);
-        const float* buf = smem + (size_t)(grp % WGT_RING) * WGT_BUF;
-        float av[2][TMV], bv[2][TNV];
-        auto load = [&](int slot, int s) {
-#pragma unroll
-            for (int x = 0; x < TMV; ++x) av[slot][x] = buf[oa + 4 * s * WGT_SP + 16 * x];
-#pragma unroll
-            for (int y = 0; y < TNV; ++y) bv[slot][y] = buf[ob + 4 * s * WGT_SQ + 16 * y];
-        };
-        load(0, 0);
-#pragma unroll
-        for (int s = 0; s < WGT_R / 4; ++s) {
-            const int cur = s & 1;
-            if (s + 1 < WGT_R / 4) load(cur ^ 1, s + 1);
-#pragma unroll
-            for (int y = 0; y < TNV; ++y)
-#pragma unroll
-                for (int x = 0; x < TMV; ++x)
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][x], bv[cur][y], acc[x][y], 0, 0, 0);
-        }
+    fixup(0);
+    if (ng > 1) fixup(1);
+    __syncthreads();
+    load(0, 0, 0);
+    // ---- one group per iteration: steps 0, 1 | barrier | steps 2, 3 -----------------------------------------------------------------
+    // barrier of group grp (every wave has waited for its own LDS-DMA pieces before it): group grp + 3's buffer - read last in group
+    // grp - 1 - is free, group grp + 2 has landed (fixed up behind the barrier, published by the next one), the fix-ups of group
+    // grp + 1 are visible (its first operands are read during step 3 below).  Waves 0..3 issue their share of group grp + 3 right behind
+    // the barrier, waves 4..7 one step later: the two waves of a SIMD never sit in their DMA issue at the same time.
+    for (int grp = 0; grp < ng; ++grp) {
+        step(0, true, grp, 1);
+        step(1, true, grp, 2);
+        wgt_barrier();
+        if (OARD_WGT_ABL != 4 && wave < 4 && grp + 3 < ng) issue(grp + 3);
+        if (grp + 2 < ng) fixup(grp + 2);
+        step(0, true, grp, 3);
+        if (OARD_WGT_ABL != 4 && wave >= 4 && grp + 3 < ng) issue(grp + 3);
+        step(1, grp + 1 < ng, grp + 1, 0);
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                // MFMA results -> stores (see above)
     // accumulator (x, y), component r of lane (g, i):  out[16 (P tile) + 4 g + r][16 (Q tile) + i]
     const int PP = a.MT * 16, QP = a.NT * 16;
     float* out = a.partial + (size_t)chunk * PP * QP;
@@ -162,12 +211,10 @@ OARD_DEV void wgt_run(const WgtArgs& a, float* smem, int wave, int lane, int chu
             for (int r = 0; r < 4; ++r) o[(size_t)r * QP] = acc[x][y][r];
         }
     }
-    if (BIAS == 1 && bias_on) a.psum[(size_t)chunk * PP + 16 * p_tile0 + tid] = bsum;
-    if (BIAS == 2 && bias_on) a.qsum[(size_t)chunk * QP + 16 * q_tile0 + tid] = bsum;
 }
 
-// BIAS: 0 = no column sums, 1 = of P (psum), 2 = of Q (qsum)
-template <int TM, int TN, bool QSILU, int BIAS>
+// TM x TN = the largest wave tile of the launch; a wave owns TM or TM - 1 (or fewer) P tiles and TN or TN - 1 (or fewer) Q tiles
+template <int TM, int TN, bool QSILU>
 __global__ __launch_bounds__(512, 2) void k_wgrad_t16(WgtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wgt_sm[];
     const int lane = threadIdx.x & 63;
@@ -186,14 +233,24 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_t16(WgtArgs a) {
     const int qw = wave >> 2, pw = wave < 4 ? wave : ((wave - 4 + 2) & 3);
     const int pl0 = wgt_start(p_tiles, 4, pw), tm = wgt_size(p_tiles, 4, pw);
     const int ql0 = wgt_start(q_tiles, 2, qw), tn = wgt_size(q_tiles, 2, qw);
-    const bool want_ps = BIAS == 1 && a.psum != nullptr && qt == 0, want_qs = BIAS == 2 && a.qsum != nullptr && pt == 0;     // workgroup-uniform
     if (tm <= 0 || tn <= 0) {                       // nothing to own (tiny operands): stay in the barrier protocol with one dummy tile
-        wgt_run<1, 1, QSILU, 0>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, 0, 0, 0, 0, false, false);
+        wgt_run<1, 1, QSILU>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, 0, 0, 0, 0);
         return;
     }
     const bool bigm = tm == TM, bign = tn == TN;
-    if (bigm && bign) wgt_run<TM, TN, QSILU, BIAS>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, pl0, tm, ql0, tn, want_ps, want_qs);
-    else if (bigm) wgt_run<TM, (TN > 1 ? TN - 1 : 1), QSILU, BIAS>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, pl0, tm, ql0, tn, want_ps, want_qs);
-    else if (bign) wgt_run<(TM > 1 ? TM - 1 : 1), TN, QSILU, BIAS>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, pl0, tm, ql0, tn, want_ps, want_qs);
-    else wgt_run<(TM > 1 ? TM - 1 : 1), (TN > 1 ? TN - 1 : 1), QSILU, BIAS>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, pl0, tm, ql0, tn, want_ps, want_qs);
+    if (bigm && bign) wgt_run<TM, TN, QSILU>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, pl0, tm, ql0, tn);
+    else if (bigm) wgt_run<TM, (TN > 1 ? TN - 1 : 1), QSILU>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, pl0, tm, ql0, tn);
+    else if (bign) wgt_run<(TM > 1 ? TM - 1 : 1), TN, QSILU>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, pl0, tm, ql0, tn);
+    else wgt_run<(TM > 1 ? TM - 1 : 1), (TN > 1 ? TN - 1 : 1), QSILU>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, pl0, tm, ql0, tn);
+}
+
+// db[o] (+)= sum over the chunks of partial[chunk][base + op(o) * stride]: the padded column / row of the product that the ones
+// column of X produced.  One wave per output, fixed order (chunk_sum_wave).
+__global__ __launch_bounds__(256) void k_wgt_bias_reduce(const float* __restrict__ partial, int n_chunks, size_t chunk_stride, size_t base,
+                                                         size_t stride, int o_len, int o_pad, int MO, float* __restrict__ out, int acc) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= MO) return;
+    const int op = (o / o_len) * o_pad + o % o_len;
+    const float s = chunk_sum_wave(partial + base + (size_t)op * stride, chunk_stride, n_chunks, threadIdx.x & 63);
+    if ((threadIdx.x & 63) == 0) out[o] = acc ? out[o] + s : s;
 }
