@@ -362,17 +362,17 @@ __global__ __launch_bounds__(64) void k_edge_node_sums(TopoDev tp, const float* 
 // group re-read the group's first tile: their accumulators belong to padding outputs that no reduce pass reads.  Rows beyond the
 // chunk are handled by a short masked epilogue.
 template <bool QSILU, int NT>
-__global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ P, int ldP, int ncP, const float* __restrict__ Q, int ldQ,
-                                                  int ncQ, long long r0, long long r1, long long rows_per_chunk, int nPB, int nQG,
-                                                  float* __restrict__ partial, float* __restrict__ psum, float* __restrict__ qsum) {
+OARD_DEV void wgrad_wave_body(const float* __restrict__ P, int ldP, int ncP, const float* __restrict__ Q, int ldQ,
+                              int ncQ, long long r0, long long r1, long long rows_per_chunk, int nPB, int nQG,
+                              float* __restrict__ partial, float* __restrict__ psum, float* __restrict__ qsum, const unsigned bid) {
     const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // grid.x = chunk * gy + task group (4 consecutive (P block, Q group) tasks per workgroup, Q group fastest): the workgroups
     // that stream the same row chunk are dispatched back to back.  Measured alternatives (profiles/round2_wgrad_notes.txt):
     // XCD-aware placement of a chunk's workgroups -15 %, 8-wave workgroups owning 4 P blocks x 2 Q groups -23 %.
     const int gy = (nPB * nQG + 3) / 4;
-    const int chunk = blockIdx.x / gy;
-    const int task = (blockIdx.x % gy) * 4 + wave;
+    const int chunk = bid / gy;
+    const int task = (bid % gy) * 4 + wave;
     const long long rb = r0 + (long long)chunk * rows_per_chunk;
     if (task >= nPB * nQG || rb >= r1) return;
     const int pb = task / nQG, qg = task - pb * nQG;
@@ -481,6 +481,41 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ P, i
             if (g == 0) qsum[(size_t)chunk * QP + 16 * (qg * NT + u) + i] = v;
         }
     }
+}
+
+template <bool QSILU, int NT>
+__global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ P, int ldP, int ncP, const float* __restrict__ Q, int ldQ,
+                                                  int ncQ, long long r0, long long r1, long long rows_per_chunk, int nPB, int nQG,
+                                                  float* __restrict__ partial, float* __restrict__ psum, float* __restrict__ qsum) {
+    wgrad_wave_body<QSILU, NT>(P, ldP, ncP, Q, ldQ, ncQ, r0, r1, rows_per_chunk, nPB, nQG, partial, psum, qsum, blockIdx.x);
+}
+
+// ---- grouped launches (round 4) ---------------------------------------------------------------------------------------------------------
+// The node-level Linear layers of a layer's reverse sweep (x_proj, node_mlp, xvec_proj, vec_proj, the node halves of edge_mlp.0,
+// pos_expansion: 12 products over N or 3 N rows) are 0.3 ... 1 GFLOP each: as 12 + 12 + 8 launches of k_wgrad / k_wgrad_reduce /
+// k_bgrad_reduce they were latency-bound (86 launches of 34 us per training step).  The stages now QUEUE them (oard_train_stages.h) and
+// a layer ends with ONE launch of each kind over a job table: same kernels, same chunking, same summation order - bit-identical
+// results.
+struct WgqJob {
+    const float* P; const float* Q; float* partial; float* bsum; float* dW; float* db;
+    long long rows, rpc;
+    int ldP, ncP, ldQ, ncQ, nPB, nQG, n_chunks, transposed;
+    int o_len, o_pad, MO, i_len, i_pad, MI, ldW, acc, PP, QP;
+    unsigned blk0, rblk0, rblk_w, rblk_b;      // first block in the GEMM launch; first block in the reduce launch, its dW / db block counts
+};
+OARD_DEV int wgq_find(const WgqJob* __restrict__ jobs, int n_jobs, unsigned bid, bool reduce) {
+    int cur = 0;
+    for (int j = 1; j < n_jobs; ++j)
+        if (bid >= (reduce ? jobs[j].rblk0 : jobs[j].blk0)) cur = j;
+    return cur;
+}
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_wgrad_q(const WgqJob* __restrict__ jobs, int n_jobs) {
+    const WgqJob& J = jobs[wgq_find(jobs, n_jobs, blockIdx.x, false)];
+    float* psum = (J.bsum != nullptr && !J.transposed) ? J.bsum : nullptr;
+    float* qsum = (J.bsum != nullptr && J.transposed) ? J.bsum : nullptr;
+    wgrad_wave_body<false, NT>(J.P, J.ldP, J.ncP, J.Q, J.ldQ, J.ncQ, 0LL, J.rows, J.rpc, J.nPB, J.nQG, J.partial, psum, qsum,
+                               blockIdx.x - J.blk0);
 }
 
 // =====================================================================================================
@@ -721,11 +756,10 @@ __global__ __launch_bounds__(256) void k_wgrad_small_reduce(const float* __restr
 // partials are [x feature][dY feature] (the kernel ran with P = X, Q = dY).
 // 256 threads = 32 consecutive outputs x 8 chunk slices: slice s adds chunks s, s + 8, ... in ascending order (eight loads in flight
 // per output instead of one thread walking all chunks), the eight slice sums are then added in slice order - a fixed order again.
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int PP, int QP, int transposed, int o_len, int o_pad,
-                               int MO, int i_len, int i_pad, int MI, float* __restrict__ out, int ldW, int acc) {
-    __shared__ float red[8][33];
+OARD_DEV void wgrad_reduce_body(float (*red)[33], const float* __restrict__ partial, int n_chunks, int PP, int QP, int transposed, int o_len, int o_pad,
+                                int MO, int i_len, int i_pad, int MI, float* __restrict__ out, int ldW, int acc, const unsigned bid) {
     const int oi = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const long long idx = (long long)blockIdx.x * 32 + oi;
+    const long long idx = (long long)bid * 32 + oi;
     const bool ok = idx < (long long)MO * MI;
     float s = 0.f;
     int o = 0, i = 0;
@@ -745,11 +779,30 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
         *dst = acc ? *dst + t : t;
     }
 }
-__global__ __launch_bounds__(256) void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int stride, int o_len, int o_pad,
-                                                      int MO, float* __restrict__ out, int acc) {  // one wave per output
-    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int PP, int QP, int transposed, int o_len, int o_pad,
+                               int MO, int i_len, int i_pad, int MI, float* __restrict__ out, int ldW, int acc) {
+    __shared__ float red[8][33];
+    wgrad_reduce_body(red, partial, n_chunks, PP, QP, transposed, o_len, o_pad, MO, i_len, i_pad, MI, out, ldW, acc, blockIdx.x);
+}
+OARD_DEV void bgrad_reduce_body(const float* __restrict__ bpartial, int n_chunks, int stride, int o_len, int o_pad,
+                                int MO, float* __restrict__ out, int acc, const unsigned bid) {  // one wave per output
+    const int o = bid * 4 + (threadIdx.x >> 6);
     if (o >= MO) return;
     const int op = (o / o_len) * o_pad + o % o_len;
     const float s = chunk_sum_wave(bpartial + op, (size_t)stride, n_chunks, threadIdx.x & 63);
     if ((threadIdx.x & 63) == 0) out[o] = acc ? out[o] + s : s;
+}
+__global__ __launch_bounds__(256) void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int stride, int o_len, int o_pad,
+                                                      int MO, float* __restrict__ out, int acc) {
+    bgrad_reduce_body(bpartial, n_chunks, stride, o_len, o_pad, MO, out, acc, blockIdx.x);
+}
+// the reduce passes of a job table in one launch: per job rblk_w blocks of the dW reduce, then rblk_b blocks of the bias reduce
+__global__ __launch_bounds__(256) void k_wgrad_reduce_q(const WgqJob* __restrict__ jobs, int n_jobs) {
+    __shared__ float red[8][33];
+    const WgqJob& J = jobs[wgq_find(jobs, n_jobs, blockIdx.x, true)];
+    const unsigned lb = blockIdx.x - J.rblk0;
+    if (lb < J.rblk_w)
+        wgrad_reduce_body(red, J.partial, J.n_chunks, J.PP, J.QP, J.transposed, J.o_len, J.o_pad, J.MO, J.i_len, J.i_pad, J.MI, J.dW, J.ldW, J.acc, lb);
+    else
+        bgrad_reduce_body(J.bsum, J.n_chunks, J.transposed ? J.QP : J.PP, J.o_len, J.o_pad, J.MO, J.db, J.acc, lb - J.rblk_w);
 }

@@ -1528,6 +1528,61 @@ size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows) {
     return std::max(big, (size_t)1024 * 1024 * sizeof(float));        // the small-output path: <= 1024 chunks x <= 1024 outputs
 }
 
+// ---- queue of short weight-gradient products (grouped launches, oard_edge_bwd.h: k_wgrad_q / k_wgrad_reduce_q) --------------------------
+// Active while a sweep entry point runs with a queue installed (oard_train_stages.h): wgrad_impl appends the per-wave-tile products
+// (k_wgrad<false, 7>) instead of launching them; wgq_flush launches the whole table.  Partials live in the queue's own scratch
+// region, one slice per job.  Job tables are cached on the device by content (a training step repeats the same tables).
+struct WgQueue {
+    std::vector<WgqJob> jobs;
+    char* region = nullptr; size_t region_bytes = 0, used = 0;
+    unsigned blocks = 0, rblocks = 0;
+    hipStream_t st = nullptr;
+};
+static thread_local WgQueue* t_wgq = nullptr;
+struct WgQueueScope {           // installs a queue for the duration of one sweep entry point (which flushes it before it returns)
+    WgQueue q;
+    WgQueueScope(char* region, size_t bytes, hipStream_t st) { q.region = region; q.region_bytes = bytes; q.st = st; t_wgq = &q; }
+    ~WgQueueScope() { t_wgq = nullptr; }
+};
+int g_wgrad_queue = 1;       // 0: every product is launched on its own (A/B, bit-identical)
+static int wgq_flush() {
+    WgQueue* q = t_wgq;
+    if (!q || q->jobs.empty()) return OARD_OK;
+    struct Cached { std::vector<WgqJob> host; WgqJob* dev = nullptr; };
+    static std::mutex mu;
+    static std::vector<Cached> cache[64];
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    const WgqJob* table = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<Cached>& cv = cache[devid & 63];
+        for (const Cached& c : cv)
+            if (c.host.size() == q->jobs.size() && memcmp(c.host.data(), q->jobs.data(), q->jobs.size() * sizeof(WgqJob)) == 0) { table = c.dev; break; }
+        if (!table) {
+            if (cv.size() >= 256) {          // tables of workspaces that are gone: start over (nothing in flight may read them any more)
+                HIP_TRY(hipDeviceSynchronize());
+                for (Cached& c : cv) (void)hipFree(c.dev);
+                cv.clear();
+            }
+            Cached c;
+            c.host = q->jobs;
+            HIP_TRY(hipMalloc(&c.dev, c.host.size() * sizeof(WgqJob)));
+            HIP_TRY(hipMemcpy(c.dev, c.host.data(), c.host.size() * sizeof(WgqJob), hipMemcpyHostToDevice));
+            table = c.dev;
+            cv.push_back(std::move(c));
+        }
+    }
+    {
+        ScopedLaunch sl_(F_WGRAD, q->st);
+        hipLaunchKernelGGL((k_wgrad_q<7>), dim3(q->blocks), dim3(256), 0, q->st, table, (int)q->jobs.size());
+        hipLaunchKernelGGL(k_wgrad_reduce_q, dim3(q->rblocks), dim3(256), 0, q->st, table, (int)q->jobs.size());
+    }
+    q->jobs.clear(); q->used = 0; q->blocks = q->rblocks = 0;
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
 // dW (row stride ldW: the destination may be a column slice of a wider nn.Linear weight; nullptr: bias only) and db; acc != 0:
 // the result is ADDED to the destination (parameters shared between layers, gradient accumulation into .grad)
 static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, int MO, const float* X, int ldX, int ncX,
@@ -1544,7 +1599,6 @@ static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, i
     const int ones = db ? wgt_ones_col(ncX, i_len, i_pad, MI) : -1;
     const WgtPlan t = (small_out || (db && ones < 0)) ? WgtPlan{} : wgt_plan(ncY, ncX, rows, x_silu);
     if (t.ok) {                                              // long contraction, 16-aligned operands: the 16 x 16-tile kernel
-        const int PP = t.MT * 16, QP = t.NT * 16;
         WgtArgs a;
         a.P = t.transposed ? X : dY; a.Q = t.transposed ? dY : X;
         a.ldP = t.transposed ? ldX : ldY; a.ldQ = t.transposed ? ldY : ldX;
@@ -1559,13 +1613,8 @@ static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, i
         if (!launched) return OARD_EINVAL;
         {
             ScopedLaunch sl_(F_WGRAD, st);
-            if (dW)
-                hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((long long)MO * MI, 32)), dim3(256), 0, st, partial, t.n_chunks, PP,
-                                   QP, t.transposed, o_len, o_pad, MO, i_len, i_pad, MI, dW, ldW, acc);
-            if (db)      // the product's padded column (row, when transposed) that the ones column of X produced
-                hipLaunchKernelGGL(k_wgt_bias_reduce, dim3((unsigned)cdiv(MO, 4)), dim3(256), 0, st, partial, t.n_chunks, (size_t)PP * QP,
-                                   t.transposed ? (size_t)ones * QP : (size_t)ones, t.transposed ? (size_t)1 : (size_t)QP, o_len, o_pad, MO,
-                                   db, acc);
+            hipLaunchKernelGGL(k_wgt_reduce, dim3((unsigned)(t.MT * t.NT)), dim3(256), 0, st, partial, t.n_chunks, t.MT, t.NT, t.transposed,
+                               o_len, o_pad, MO, i_len, i_pad, MI, dW, ldW, db, db ? ones : -1, acc);
         }
         HIP_TRY(hipGetLastError());
         return OARD_OK;
@@ -1599,6 +1648,25 @@ static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, i
 #undef WGL_SHAPE
 #undef WGL_LAUNCH
     } else {
+        WgQueue* q = t_wgq;
+        const size_t need = align_up(((size_t)p.n_chunks * p.PP * p.QP + (size_t)p.n_chunks * std::max(p.PP, p.QP)) * sizeof(float), 256);
+        if (q && g_wgrad_queue && q->st == st && !x_silu && p.NT == 7 && p.n_chunks * p.gy > 0 && need <= q->region_bytes) {
+            // queued: the layer ends with one grouped launch (wgq_flush)
+            if (q->used + need > q->region_bytes || q->jobs.size() >= 64) { int rcq = wgq_flush(); if (rcq != OARD_OK) return rcq; }
+            float* part = (float*)(q->region + q->used);
+            q->used += need;
+            WgqJob J;
+            memset(&J, 0, sizeof(J));
+            J.P = Pm; J.Q = Qm; J.partial = part; J.bsum = db ? part + (size_t)p.n_chunks * p.PP * p.QP : nullptr; J.dW = dW; J.db = db;
+            J.rows = rows; J.rpc = p.rpc; J.ldP = ldP; J.ncP = ncP; J.ldQ = ldQ; J.ncQ = ncQ; J.nPB = p.nPB; J.nQG = p.nQG;
+            J.n_chunks = p.n_chunks; J.transposed = p.transposed; J.o_len = o_len; J.o_pad = o_pad; J.MO = MO; J.i_len = i_len;
+            J.i_pad = i_pad; J.MI = MI; J.ldW = ldW; J.acc = acc; J.PP = p.PP; J.QP = p.QP;
+            J.blk0 = q->blocks; J.rblk0 = q->rblocks;
+            J.rblk_w = dW ? (unsigned)cdiv((long long)MO * MI, 32) : 0; J.rblk_b = db ? (unsigned)cdiv(MO, 4) : 0;
+            q->blocks += (unsigned)(p.n_chunks * p.gy); q->rblocks += J.rblk_w + J.rblk_b;
+            q->jobs.push_back(J);
+            return OARD_OK;
+        }
         ScopedLaunch sl_(F_WGRAD, st);
         const dim3 grid((unsigned)(p.n_chunks * p.gy)), block(256);
 #define WG_LAUNCH(SILU_, NT_) hipLaunchKernelGGL((k_wgrad<SILU_, NT_>), grid, block, 0, st, Pm, ldP, ncP, Qm, ldQ, ncQ, 0LL, (long long)rows, \
@@ -1646,6 +1714,7 @@ size_t oard_train_scratch_bytes(const oard_config* c, const oard_topology* topo)
     const TrainCtx x(c, &tp, packed, packed_bwd, tape, scratch, params, grads, (hipStream_t)stream);                           \
     const TrainTail tw = make_train_tail(c, tp, x.w.total);                                                                    \
     (void)tw;                                                                                                                  \
+    WgQueueScope wqs_((char*)scratch + x.w.wgq, x.w.wgq_bytes, x.stw);                                                          \
     int rc = OARD_EINVAL
 
 int oard_train_scratch_poison(const oard_config* c, const oard_topology* topo, void* scratch, size_t scratch_bytes, oard_stream_t stream) {
@@ -1660,6 +1729,7 @@ int oard_train_layer_backward(const oard_config* c, const oard_topology* topo, c
     TRAIN_ENTER();
     if (!ds || !dvec || !dew || layer < 0 || layer >= c->num_layers) return OARD_EINVAL;
     DISPATCH_DIMS(c, rc = tr_layer_bwd<D>(x, layer, ds, dvec, dew));
+    if (rc == OARD_OK) rc = wgq_flush();
     return rc;
 }
 
@@ -1670,6 +1740,7 @@ int oard_train_tail_backward(const oard_config* c, const oard_topology* topo, co
     if (!ds || !dvec) return OARD_EINVAL;
     if (g_poison) HIP_TRY(hipMemsetAsync(scratch, 0xFF, oard_train_scratch_bytes(c, topo), (hipStream_t)stream));   // first call of a sweep
     DISPATCH_DIMS(c, rc = tr_tail_bwd<D>(x, tw, topo, grad_out, ds, dvec));
+    if (rc == OARD_OK) rc = wgq_flush();
     x.join();                   // (a small stage; its operand buffers are reused by nothing until the next sweep, but tests read its gradients right away)
     return rc;
 }
@@ -1680,6 +1751,7 @@ int oard_train_init_backward(const oard_config* c, const oard_topology* topo, co
     TRAIN_ENTER();
     if (!xh || !ds0 || !dew || !params) return OARD_EINVAL;
     DISPATCH_DIMS(c, rc = tr_init_bwd<D>(x, tw, topo, xh, ds0, dew));
+    if (rc == OARD_OK) rc = wgq_flush();
     x.join();                   // end of the sweep: every gradient is complete in the caller's stream order
     return rc;
 }
@@ -1715,6 +1787,7 @@ int oard_train_stage_backward(const oard_config* c, const oard_topology* topo, c
             DISPATCH_DIMS(c, rc = tr_equi_edge_bwd<D>(x, layer, out0)); break; }
         default: return OARD_EINVAL;
     }
+    if (rc == OARD_OK) rc = wgq_flush();
     return rc;
 }
 
@@ -1862,6 +1935,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "npb") == 0) { g_npb = value; return OARD_OK; }
     if (strcmp(name, "wgrad_wgs") == 0) { g_wgrad_wgs = value; return OARD_OK; }
     if (strcmp(name, "wgrad_t16") == 0) { g_wgrad_t16 = value; return OARD_OK; }
+    if (strcmp(name, "wgrad_queue") == 0) { g_wgrad_queue = value; return OARD_OK; }
     if (strcmp(name, "wgrad_lds") == 0) { g_wgrad_lds = value; return OARD_OK; }
     if (strcmp(name, "wgrad_shapes") == 0) { g_wgrad_shapes = value & 3; return OARD_OK; }
     if (strcmp(name, "train_dual") == 0) { g_train_dual = value; return OARD_OK; }

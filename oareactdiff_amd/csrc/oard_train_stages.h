@@ -31,8 +31,8 @@ struct TrainWs {
     size_t dzq, dxln, lng, dsm, dzm, dxh, t1, t2, dhid, dzh;
     size_t lng2, dsn;          // node_pre adjoint: its own LayerNorm product buffer, cotangent of s entering the layer (copy read by the gradient stream)
     // column sums, weight-gradient partials (used by the gradient stream only)
-    size_t csum, cpart, wg;
-    size_t wg_bytes, total;
+    size_t csum, cpart, wg, wgq;
+    size_t wg_bytes, wgq_bytes, total;
     size_t layer_bytes;        // everything above lives twice: buffer set l & 1 for layer l (the gradient stream of layer l runs beside the cotangent chain of layer l - 1)
 };
 static TrainWs make_train_ws(const oard_config* c, const TopoDev& td) {
@@ -76,6 +76,17 @@ static TrainWs make_train_ws(const oard_config* c, const TopoDev& td) {
         for (const auto& sh : shapes) w.wg_bytes = std::max(w.wg_bytes, oard_wgrad_scratch_bytes(sh.y, sh.x, sh.r));
     }
     w.wg = take(w.wg_bytes);
+    {   // partials of the QUEUED (node-level, grouped-launch) products of one layer, each with its own slice; a product that does not
+        // fit is launched on its own instead (wgrad_impl), so this is a performance knob, not a correctness bound
+        const int HPi = d.HP, RPi = d.RP, PPi = d.PP;
+        const int64_t Ar = (int64_t)A, Nr = (int64_t)N;
+        const struct { int y, x; int64_t r; int n; } shapes[] = {{3 * HPi, HPi, Nr, 2}, {HPi, HPi, Nr, 9}, {2 * HPi, HPi, 3 * Nr, 1},
+                                                                 {3 * HPi, RPi, Ar, 1}, {HPi, PPi, Nr, 1}};
+        size_t sum = 0;
+        for (const auto& sh : shapes) sum += sh.n * align_up(oard_wgrad_scratch_bytes(sh.y, sh.x, sh.r), 256);
+        w.wgq_bytes = sum + sum / 4;
+    }
+    w.wgq = take(w.wgq_bytes);
     w.total = cur;
     return w;
 }
@@ -535,6 +546,7 @@ static int tr_layer_bwd(const TrainCtx& x0, int l, float* ds, float* dvec, float
     TR_TRY(tr_equi_edge_bwd<D>(x, l, dew));
     TR_TRY(tr_gcl_edge_bwd<D>(x, l, dagg, dew, dP, dQ));
     TR_TRY(tr_pre_bwd<D>(x, l, dxh, dP, dQ, ds));
+    TR_TRY(wgq_flush());                                      // the layer's queued node-level weight gradients: one grouped launch
     x.layer_done(l);
     return OARD_OK;
 }

@@ -78,37 +78,48 @@ OARD_DEV void wgt_run(const WgtArgs& a, float* smem, int wave, int lane, int chu
     const long long rb = a.r0 + (long long)chunk * a.rpc;
     const long long re = rb + a.rpc < a.r1 ? rb + a.rpc : a.r1;
     const int ng = (int)((re - rb + WGT_R - 1) / WGT_R);
-    const int wP4 = p_tiles * 4, wQ4 = q_tiles * 4;                 // float4 per panel row
-    const float* gP = a.P + (size_t)p_tile0 * 16;                    // wave-uniform; + row * ldP
-    const float* gQ = a.Q + (size_t)q_tile0 * 16;
-    const unsigned lane_off = (unsigned)lane * 16u;                  // LDS-DMA source = uniform row address (SGPR pair) + this 32-bit lane offset
+    const int wQ4 = q_tiles * 4;                                     // float4 per Q panel row
     auto ring = [&](int grp) -> float* { return smem + (size_t)(grp & (WGT_RING - 1)) * WGT_BUF; };
 
-    // this wave's share of group grp -> its ring buffer: rows `wave` and `wave + 8`, per row the first 64 float4 of the P part, the
-    // rest of it, the Q part (1-KiB LDS-DMA pieces, lanes beyond the part masked off)
+    // LDS-DMA: a ring buffer is NPP + NPQ = 36 pieces of 1 KiB (64 lanes x 16 bytes, contiguous in LDS; the panels' row strides make
+    // both panels whole numbers of pieces), piece j issued by wave j % 8.  A lane's 16 bytes lie in panel row o / rowbytes at byte
+    // o % rowbytes of the row; lanes that fall into the stride padding or beyond this workgroup's tiles fetch the row's first bytes
+    // again (never read).  Source = uniform group address (SGPR pair) + a per-lane 32-bit offset that is the same for every full
+    // group, so a piece costs no VALU work and no exec masking (measured: the 48 masked per-row pieces of the first version cost
+    // 6.5 % of the matrix pipe's time, ~50 idle cycles per piece and SIMD).  The last group of a chunk clamps the row to the last
+    // valid one; its surplus rows are zeroed by the fix-up pass.
+    constexpr int NPP = WGT_R * WGT_SP * 4 / 1024, NPQ = WGT_R * WGT_SQ * 4 / 1024, NPW = (NPP + NPQ + 7) / 8;
+    static_assert(NPP * 1024 == WGT_R * WGT_SP * 4 && NPQ * 1024 == WGT_R * WGT_SQ * 4, "panels must be whole LDS-DMA pieces");
+    auto piece_off = [&](int k, int maxrow) -> unsigned {             // per-lane source byte offset of this wave's k-th piece
+        const int j = wave + 8 * k;
+        const bool isP = j < NPP;
+        const int o = (isP ? j : j - NPP) * 1024 + lane * 16, rowbytes = isP ? WGT_SP * 4 : WGT_SQ * 4;
+        int row = o / rowbytes, colb = o - row * rowbytes;
+        if (colb >= 64 * (isP ? p_tiles : q_tiles)) colb = 0;
+        if (row > maxrow) row = maxrow;
+        return (unsigned)(row * (isP ? a.ldP : a.ldQ) * 4 + colb);
+    };
+    unsigned voff[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) voff[k] = piece_off(k, WGT_R - 1);
     auto issue = [&](int grp) {
         float* buf = ring(grp);
+        const long long row0 = rb + (long long)grp * WGT_R;
+        const int nvalid = (int)(re - row0 < WGT_R ? re - row0 : WGT_R);          // wave-uniform
+        const float* bP = a.P + (size_t)row0 * a.ldP + (size_t)p_tile0 * 16;
+        const float* bQ = a.Q + (size_t)row0 * a.ldQ + (size_t)q_tile0 * 16;
 #pragma unroll
-        for (int h = 0; h < WGT_R / 8; ++h) {
-            const int r = wave + 8 * h;
-            const long long row = rb + (long long)grp * WGT_R + r;
-            float* dP = buf + r * WGT_SP;
-            float* dQ = buf + WGT_R * WGT_SP + r * WGT_SQ;
-            if (row < re) {                                          // wave-uniform
-                const float* sp = gP + (size_t)row * a.ldP;
-                const float* sq = gQ + (size_t)row * a.ldQ;
-                if (lane < wP4) glds16u(sp, lane_off, dP);
-                if (lane + 64 < wP4) glds16u(sp + 256, lane_off, dP + 256);
-                if (lane < wQ4) glds16u(sq, lane_off, dQ);
-            } else {                                                 // beyond the chunk (last group only): the row counts as zero in both operands
-                for (int c = lane; c < 4 * wP4; c += 64) dP[c] = 0.f;
-                for (int c = lane; c < 4 * wQ4; c += 64) dQ[c] = 0.f;
-            }
+        for (int k = 0; k < NPW; ++k) {
+            const int j = wave + 8 * k;
+            if (j >= NPP + NPQ) break;
+            const unsigned vo = nvalid == WGT_R ? voff[k] : piece_off(k, nvalid - 1);
+            glds16u(j < NPP ? bP : bQ, vo, buf + j * 256);            // Q panel starts right behind the P panel: piece j at byte 1024 j
         }
     };
     // In-LDS fix-ups of a landed group, once per element: SiLU on the Q panel (float4 number tid, tid + 512 of its WGT_R x wQ4
-    // grid) and the ones column (X's pad column := 1.0, so that the padded output column of the product is the bias gradient).
-    // The ones column of a SiLU operand is set by the thread that rewrites that float4 (no second writer).
+    // grid), the ones column (X's pad column := 1.0, so that the padded output column of the product is the bias gradient) and, in
+    // the last group of a chunk, zeros in the rows beyond the chunk.  Every element has ONE writer: the ones column of a SiLU
+    // operand is set by the thread that rewrites that float4, and surplus rows are left to the zero fill.
     const int op_local = a.ones_side == 1 ? a.ones_col - 16 * p_tile0 : -1, oq_local = a.ones_side == 2 ? a.ones_col - 16 * q_tile0 : -1;
     const bool ones_p = op_local >= 0 && op_local < 16 * p_tiles, ones_q = oq_local >= 0 && oq_local < 16 * q_tiles;
     int so[2], sone[2];
@@ -119,17 +130,24 @@ OARD_DEV void wgt_run(const WgtArgs& a, float* smem, int wave, int lane, int chu
         sone[k] = (ones_q && c4 == (oq_local >> 2)) ? (oq_local & 3) : -1;
     }
     auto fixup = [&](int grp) {
-        float* q = ring(grp) + WGT_R * WGT_SP;
+        float* pp = ring(grp);
+        float* q = pp + WGT_R * WGT_SP;
+        const long long left = re - (rb + (long long)grp * WGT_R);
+        const int nvalid = (int)(left < WGT_R ? left : WGT_R);       // workgroup-uniform; < WGT_R in the last group only
         if (QSILU) {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
-                if (so[k] >= 0) {
+                if (so[k] >= 0 && so[k] < nvalid * WGT_SQ) {
                     f4 v = silu4(ld_f4(q + so[k]));
                     if (sone[k] == 0) v.x = 1.0f; else if (sone[k] == 1) v.y = 1.0f; else if (sone[k] == 2) v.z = 1.0f; else if (sone[k] == 3) v.w = 1.0f;
                     st_f4(q + so[k], v);
                 }
-        } else if (ones_q && tid < WGT_R) q[tid * WGT_SQ + oq_local] = 1.0f;
-        if (ones_p && tid < WGT_R) ring(grp)[tid * WGT_SP + op_local] = 1.0f;
+        } else if (ones_q && tid < nvalid) q[tid * WGT_SQ + oq_local] = 1.0f;
+        if (ones_p && tid < nvalid) pp[tid * WGT_SP + op_local] = 1.0f;
+        if (nvalid < WGT_R) {
+            for (int c = nvalid * WGT_SP + tid; c < WGT_R * WGT_SP; c += 512) pp[c] = 0.f;
+            for (int c = nvalid * WGT_SQ + tid; c < WGT_R * WGT_SQ; c += 512) q[c] = 0.f;
+        }
     };
 
     f4 acc[TMV][TNV];
@@ -197,18 +215,16 @@ OARD_DEV void wgt_run(const WgtArgs& a, float* smem, int wave, int lane, int chu
         step(1, grp + 1 < ng, grp + 1, 0);
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                // MFMA results -> stores (see above)
-    // accumulator (x, y), component r of lane (g, i):  out[16 (P tile) + 4 g + r][16 (Q tile) + i]
-    const int PP = a.MT * 16, QP = a.NT * 16;
-    float* out = a.partial + (size_t)chunk * PP * QP;
+    // partials are kept TILE-MAJOR: tile (P tile, Q tile) of a chunk = the accumulator's register image, one float4 per lane (lane
+    // (g, i): rows 4 g .. 4 g + 3 of the tile, column i), 1 KiB, one coalesced store; k_wgt_reduce undoes the layout
+    float* out = a.partial + (size_t)chunk * a.MT * a.NT * 256 + lane * 4;
 #pragma unroll
     for (int x = 0; x < TMV; ++x) {
         if (x >= tm) break;
 #pragma unroll
         for (int y = 0; y < TNV; ++y) {
             if (y >= tn) break;
-            float* o = out + (size_t)(16 * (p_tile0 + pl0 + x) + 4 * g) * QP + 16 * (q_tile0 + ql0 + y) + i;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[(size_t)r * QP] = acc[x][y][r];
+            st_f4(out + ((size_t)(p_tile0 + pl0 + x) * a.NT + (q_tile0 + ql0 + y)) * 256, acc[x][y]);
         }
     }
 }
@@ -244,13 +260,41 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_t16(WgtArgs a) {
     else wgt_run<(TM > 1 ? TM - 1 : 1), (TN > 1 ? TN - 1 : 1), QSILU>(a, wgt_sm, wave, lane, chunk, p_tile0, p_tiles, q_tile0, q_tiles, pl0, tm, ql0, tn);
 }
 
-// db[o] (+)= sum over the chunks of partial[chunk][base + op(o) * stride]: the padded column / row of the product that the ones
-// column of X produced.  One wave per output, fixed order (chunk_sum_wave).
-__global__ __launch_bounds__(256) void k_wgt_bias_reduce(const float* __restrict__ partial, int n_chunks, size_t chunk_stride, size_t base,
-                                                         size_t stride, int o_len, int o_pad, int MO, float* __restrict__ out, int acc) {
-    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (o >= MO) return;
-    const int op = (o / o_len) * o_pad + o % o_len;
-    const float s = chunk_sum_wave(partial + base + (size_t)op * stride, chunk_stride, n_chunks, threadIdx.x & 63);
-    if ((threadIdx.x & 63) == 0) out[o] = acc ? out[o] + s : s;
+// Second pass: dW (logical nn.Linear shape, row stride ldW) and db from the tile-major partials, chunks in ascending order.  One
+// workgroup per 16 x 16 tile: 4 chunk slices x 64 lanes, a lane sums its float4 (rows 4 g .. 4 g + 3 of the tile, column i) over
+// the chunks sl, sl + 4, ... (coalesced 1-KiB reads), the four slice sums are added in slice order - a fixed order.  Padded index
+// -> logical index by sections (undoes 196 -> 208 between the thirds of split projections); pads are dropped.  `transposed`: the
+// product was formed with P = X, Q = dY.  db = the padded column (row, when transposed) `ones_col` of the product.
+OARD_DEV int wgt_logical(int padded, int len, int pad, int n) {
+    const int sec = padded / pad, w = padded - sec * pad, l = sec * len + w;
+    return (w < len && l < n) ? l : -1;
+}
+__global__ __launch_bounds__(256) void k_wgt_reduce(const float* __restrict__ partial, int n_chunks, int MT, int NT, int transposed, int o_len, int o_pad,
+                                                    int MO, int i_len, int i_pad, int MI, float* __restrict__ dW, int ldW, float* __restrict__ db,
+                                                    int ones_col, int acc) {
+    __shared__ f4 red[4][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6, tile = blockIdx.x;
+    const size_t cs = (size_t)MT * NT * 256;
+    const float* p = partial + (size_t)tile * 256 + lane * 4;
+    f4 v = f4zero();
+    for (int ch = sl; ch < n_chunks; ch += 4) v += ld_f4(p + (size_t)ch * cs);
+    red[sl][lane] = v;
+    __syncthreads();
+    if (sl != 0) return;
+    v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    const int tp = tile / NT, tq = tile - tp * NT, g = lane >> 4, j = lane & 15;
+    const int qq = 16 * tq + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int pp = 16 * tp + 4 * g + r;
+        const int o = transposed ? wgt_logical(qq, o_len, o_pad, MO) : wgt_logical(pp, o_len, o_pad, MO);
+        if (o < 0) continue;
+        const int xp = transposed ? pp : qq;                        // padded X column of this element
+        if (db != nullptr && xp == ones_col) db[o] = acc ? db[o] + v[r] : v[r];
+        const int i = wgt_logical(xp, i_len, i_pad, MI);
+        if (dW != nullptr && i >= 0) {
+            float* d = dW + (size_t)o * ldW + i;
+            *d = acc ? *d + v[r] : v[r];
+        }
+    }
 }
