@@ -166,6 +166,33 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X
     }
     part[(size_t)blockIdx.x * ncols + c] = s;
 }
+// long matrices (thousands of rows, ncols a multiple of 4, 16-byte aligned rows): float4 loads, the block's 256 threads as RL row
+// lanes x nc4 column quads (RL = 256 / nc4), a thread adds rows rb + rl, rb + rl + RL, ... of its quad in ascending order, the RL lane
+// sums are then added in lane order - a fixed order.  CSL_ROWS rows per block -> part[q][c] as k_colsum_part.  (The one-thread-per-
+// column kernel above spent 1.66 ms per training step, most of it on the six [E][196] sums of the att_mlp weight gradient.)
+#define CSL_ROWS 512
+__global__ __launch_bounds__(256) void k_colsum_long(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
+                                                     const float* __restrict__ wrow, int x_silu, float* __restrict__ part) {
+    __shared__ f4 red[256];
+    const int nc4 = ncols >> 2, RL = 256 / nc4, rl = threadIdx.x / nc4, c4 = threadIdx.x - rl * nc4;
+    const long long rb = r0 + (long long)blockIdx.x * CSL_ROWS, re = rb + CSL_ROWS < r1 ? rb + CSL_ROWS : r1;
+    f4 s = f4zero();
+    if (rl < RL) {
+        const float* p = X + 4 * c4;
+#pragma unroll 4
+        for (long long r = rb + rl; r < re; r += RL) {
+            f4 v = ld_f4(p + (size_t)r * ld);
+            if (x_silu) v = silu4(v);
+            s += wrow != nullptr ? v * wrow[r] : v;
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < RL; ++k) s += red[k * nc4 + c4];
+        st_f4(part + (size_t)blockIdx.x * ncols + 4 * c4, s);
+    }
+}
 // narrow matrices (ncols <= 16, e.g. the [items][12] operand of the frame-scalar MLP's last layer): one thread per ROW slice instead
 // of one per column - thread t of chunk q adds rows q CSN_ROWS + t, + 256, ... for all columns in registers, then the 256 thread
 // sums are combined by a fixed tree in LDS.  part[q][c] as above.

@@ -201,6 +201,12 @@ static void colsum(const TrainCtx& x, const float* X, int ld, long long r0, long
         hipLaunchKernelGGL(k_colsum_fin, dim3((unsigned)cdiv(ncols, 4)), dim3(256), 0, x.stw, (const float*)part, nchn, ncols, out, accumulate, scale);
         return;
     }
+    if (r1 - r0 >= 8 * CSL_ROWS && (ncols & 3) == 0 && ncols >= 8 && ncols <= 1024 && (ld & 3) == 0 && (((uintptr_t)X) & 15) == 0) {
+        const int nchl = (int)cdiv(r1 - r0, CSL_ROWS);                // long and wide enough: float4 loads, several row lanes per block
+        hipLaunchKernelGGL(k_colsum_long, dim3((unsigned)nchl), dim3(256), 0, x.stw, X, ld, r0, r1, ncols, wrow, x_silu, part);
+        hipLaunchKernelGGL(k_colsum_fin, dim3((unsigned)cdiv(ncols, 4)), dim3(256), 0, x.stw, (const float*)part, nchl, ncols, out, accumulate, scale);
+        return;
+    }
     const int nch = (int)std::max<long long>(1, cdiv(std::max<long long>(r1 - r0, 0), CS_ROWS));
     if (r1 > r0)
         hipLaunchKernelGGL(k_colsum_part, dim3((unsigned)nch, (unsigned)cdiv(ncols, 256)), dim3(256), 0, x.stw, X, ld, r0, r1, ncols, wrow,
