@@ -54,7 +54,8 @@ typedef struct oard_config {
     int32_t condition_time;  /* bool                                                */
     int32_t pos_dim;         /* must be 3                                           */
     float   cutoff;
-    int32_t reflect_equiv;   /* must be 1 (production setting)                      */
+    int32_t reflect_equiv;   /* LEFTNet reflect_equiv (leftnet.py:268-272, 331, 794-796): 1 = production setting; 0 = the Equi
+                                message carries x (x) coord_cross and the edge scalarisation keeps its sign              */
     int32_t precision;       /* OARD_PREC_* bits: arithmetic of the two MFMA edge stages (0 = fp32 everywhere).  A property of
                                 the call, not of the process: oard_pack_weights builds the bf16 streams for the bits set, and
                                 oard_forward / oard_forward_train must be given the blob packed with the same bits. */

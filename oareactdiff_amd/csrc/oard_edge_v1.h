@@ -688,6 +688,7 @@ __global__ __launch_bounds__(256) void k_equi_agg_v1(TopoDev tp, const float* __
             const int m = tp.act_src[a];
             const float* g = geo + a * GEO_STRIDE;
             const float ux = g[2], uy = g[3], uz = g[4];
+            const float xc = lo.xcross ? 1.0f : 0.0f, cx = xc * g[5], cy = xc * g[6], cz = xc * g[7];  // reflect_equiv = False: + x (x) coord_cross
 #pragma unroll
             for (int t = 0; t < D::HT; ++t) {
                 const f4 q0 = ld_blk(qbuf, a, 3 * D::HP, t, id.lane);
@@ -696,11 +697,12 @@ __global__ __launch_bounds__(256) void k_equi_agg_v1(TopoDev tp, const float* __
                 const f4 xs0 = ld_blk(xq, m, 3 * D::HP, t, id.lane) + ld_blk(xq, n, 3 * D::HP, t, id.lane);
                 const f4 xs1 = ld_blk(xq, m, 3 * D::HP, D::HT + t, id.lane) + ld_blk(xq, n, 3 * D::HP, D::HT + t, id.lane);
                 const f4 xs2 = ld_blk(xq, m, 3 * D::HP, 2 * D::HT + t, id.lane) + ld_blk(xq, n, 3 * D::HP, 2 * D::HT + t, id.lane);
-                dx[t] += xs0 * q0;
+                const f4 xm = xs0 * q0;
+                dx[t] += xm;
                 const f4 a2 = xs1 * q1 * inv_sqrt3, a3 = xs2 * q2;
-                vx[0][t] += (ld_blk(vec_in, (size_t)m * 3 + 0, D::HP, t, id.lane) * a2 + a3 * ux) * inv_sqrt_h;
-                vx[1][t] += (ld_blk(vec_in, (size_t)m * 3 + 1, D::HP, t, id.lane) * a2 + a3 * uy) * inv_sqrt_h;
-                vx[2][t] += (ld_blk(vec_in, (size_t)m * 3 + 2, D::HP, t, id.lane) * a2 + a3 * uz) * inv_sqrt_h;
+                vx[0][t] += (ld_blk(vec_in, (size_t)m * 3 + 0, D::HP, t, id.lane) * a2 + a3 * ux + xm * cx) * inv_sqrt_h;
+                vx[1][t] += (ld_blk(vec_in, (size_t)m * 3 + 1, D::HP, t, id.lane) * a2 + a3 * uy + xm * cy) * inv_sqrt_h;
+                vx[2][t] += (ld_blk(vec_in, (size_t)m * 3 + 2, D::HP, t, id.lane) * a2 + a3 * uz + xm * cz) * inv_sqrt_h;
             }
         }
 #pragma unroll

@@ -112,7 +112,7 @@ bool config_ok(const oard_config* c) {
     if (c->num_layers < 1 || c->num_layers > OARD_MAX_LAYERS) return false;
     if (c->in_hidden < 1 || c->in_hidden > 16) return false;
     if (c->n_obj < 1 || c->n_obj > OARD_MAX_OBJECTS) return false;
-    if (c->pos_dim != 3 || c->reflect_equiv != 1) return false;
+    if (c->pos_dim != 3 || (c->reflect_equiv != 0 && c->reflect_equiv != 1)) return false;
     if (c->precision & ~(OARD_PREC_GCL_BF16X3 | OARD_PREC_EQUI_BF16X3 | OARD_PREC_TRAIN_BF16X3)) return false;
     const int emb = c->in_hidden - (c->condition_time ? 1 : 0) - (c->condition_nf > 0 ? c->condition_nf : 0);
     if (emb < 1) return false;
@@ -190,6 +190,8 @@ PackOff make_layout(const oard_config* c) {
         }
     }
     po.total = cur;
+    po.signed_scal = c->reflect_equiv ? 0 : 1;
+    for (int l = 0; l < c->num_layers; ++l) po.layer[l].xcross = c->reflect_equiv ? 0 : 1;
     return po;
 }
 
@@ -619,14 +621,13 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                                            (float*)(ws + w.d1s));
                 if (rc != OARD_OK) return rc;
             }
+#define EQUI_NODE_V1(ROWS_, XC_) LAUNCH(F_NODE, (k_equi_node_v1<D, NW, ROWS_, XC_>), gN16, NW * 64, st, tp, wb, lo, (const float*)vmsg, \
+                       (const float*)xq, (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext, \
+                       train ? (float*)(tape + to.s_a[l]) : nullptr, train ? (float*)(tape + to.vec_a[l]) : nullptr)
             if (nv1 && rows) {
-                LAUNCH(F_NODE, (k_equi_node_v1<D, NW, true>), gN16, NW * 64, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
-                       (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext,
-                       train ? (float*)(tape + to.s_a[l]) : nullptr, train ? (float*)(tape + to.vec_a[l]) : nullptr);
+                if (lo.xcross) EQUI_NODE_V1(true, true); else EQUI_NODE_V1(true, false);
             } else if (nv1) {
-                LAUNCH(F_NODE, (k_equi_node_v1<D, NW, false>), gN16, NW * 64, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
-                       (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext,
-                       train ? (float*)(tape + to.s_a[l]) : nullptr, train ? (float*)(tape + to.vec_a[l]) : nullptr);
+                if (lo.xcross) EQUI_NODE_V1(false, true); else EQUI_NODE_V1(false, false);
             } else {
                 LAUNCH(F_NODE, (k_equi_agg_v1<D>), gN, 256, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
                        (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext, v2buf, scal, vdot);
@@ -716,18 +717,19 @@ static int scalarize_backward_impl(const oard_config* c, const TopoDev& tp, cons
                                    const float* ne1, int ld, const float* dew, float* dne1, float* part, hipStream_t st) {
     const PackOff po = make_layout(c);
     constexpr int NW = D::HT < 4 ? D::HT : 4;      // one wave per SIMD: the kernel keeps ~150 accumulators / constants per lane
-    LAUNCH(F_INIT, (k_scalarize_bwd<D, NW>), tp.N, NW * 64, st, tp, wb + po.lin3, ne1, ld, (const float*)(tape + to.geo), dew, dne1, part);
+    LAUNCH(F_INIT, (k_scalarize_bwd<D, NW>), tp.N, NW * 64, st, tp, wb + po.lin3, ne1, ld, (const float*)(tape + to.geo), dew, dne1, part,
+           po.signed_scal);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
 
 template <class D>
-static int equi_msg_backward_impl(const TopoDev& tp, const char* tape, const TapeOff& to, int layer, const float* xq, const float* cr,
+static int equi_msg_backward_impl(const oard_config* c, const TopoDev& tp, const char* tape, const TapeOff& to, int layer, const float* xq, const float* cr,
                                   const float* gs, const float* gv, float* dcd, float* dcr, float* dxq, float* dvec, hipStream_t st) {
     const Strided3 xq3{xq, 3 * D::H, D::H}, vec3{(const float*)(tape + to.vec_in[layer]), 3 * D::HP, D::HP}, cr3{cr, 3 * D::H, D::H},
         gv3{gv, 3 * D::H, D::H};
     LAUNCH(F_NODE, (k_equi_msg_bwd<D>), tp.N, 256, st, tp, (const float*)(tape + to.geo), xq3, vec3, (const float*)(tape + to.cd[layer]), cr3,
-           gs, D::H, gv3, dcd, dcr, dxq, dvec, D::H);
+           gs, D::H, gv3, dcd, dcr, dxq, dvec, D::H, c->reflect_equiv ? 0 : 1);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
@@ -1445,7 +1447,7 @@ int oard_equi_msg_backward(const oard_config* c, const oard_topology* topo, cons
     const TopoDev& tp = topo->parts[0].d;
     const TapeOff to = make_tape(c, tp);
     int rc = OARD_EINVAL;
-    DISPATCH_DIMS(c, rc = equi_msg_backward_impl<D>(tp, (const char*)tape, to, layer, xq, cr, gx, gv, dcd, dcr, dxq, dvec, (hipStream_t)stream));
+    DISPATCH_DIMS(c, rc = equi_msg_backward_impl<D>(c, tp, (const char*)tape, to, layer, xq, cr, gx, gv, dcd, dcr, dxq, dvec, (hipStream_t)stream));
     return rc;
 }
 

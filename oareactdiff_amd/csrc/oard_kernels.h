@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void k_scalarize(TopoDev tp, const float* __re
             const f4 S0 = n0 * ux + n1 * uy + n2 * uz;
             f4 S1 = n0 * cx + n1 * cy + n2 * cz;
             const f4 S2 = n0 * vx + n1 * vy + n2 * vz;
-            S1 = (f4){fabsf(S1.x), fabsf(S1.y), fabsf(S1.z), fabsf(S1.w)};      // reflect_equiv, :794-796
+            if (!po.signed_scal) S1 = (f4){fabsf(S1.x), fabsf(S1.y), fabsf(S1.z), fabsf(S1.w)};      // reflect_equiv, :794-796
             f4 o = (f4){b2, b2, b2, b2};
             for (int k = 0; k < D::H4; ++k) {
                 const float wa = w0[3 * k], wbb = w0[3 * k + 1], wc = w0[3 * k + 2], bb = b0[k], ww = w2[k];
@@ -904,6 +904,7 @@ __global__ __launch_bounds__(256) void k_equi_edge(TopoDev tp, const float* __re
     const float* erow = ew + a * D::WP + 4 * id.g;
     const float* g = geo + a * GEO_STRIDE;
     const float ux = g[2], uy = g[3], uz = g[4];
+    const float xc = lo.xcross ? 1.0f : 0.0f, cx = xc * g[5], cy = xc * g[6], cz = xc * g[7];      // reflect_equiv = False: + x (x) coord_cross
     const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt_h = 1.0f / sqrtf((float)D::H);
 
     f4 d1[D::D1T];
@@ -936,11 +937,11 @@ __global__ __launch_bounds__(256) void k_equi_edge(TopoDev tp, const float* __re
         if (id.valid) {
             st_blk(xmsg, a, D::HP, tt, id.lane, q[0]);
             st_blk(vmsg, a * 3 + 0, D::HP, tt, id.lane,
-                   (ld_blk(vec, (size_t)src * 3 + 0, D::HP, tt, id.lane) * a2 + a3 * ux) * inv_sqrt_h);
+                   (ld_blk(vec, (size_t)src * 3 + 0, D::HP, tt, id.lane) * a2 + a3 * ux + q[0] * cx) * inv_sqrt_h);
             st_blk(vmsg, a * 3 + 1, D::HP, tt, id.lane,
-                   (ld_blk(vec, (size_t)src * 3 + 1, D::HP, tt, id.lane) * a2 + a3 * uy) * inv_sqrt_h);
+                   (ld_blk(vec, (size_t)src * 3 + 1, D::HP, tt, id.lane) * a2 + a3 * uy + q[0] * cy) * inv_sqrt_h);
             st_blk(vmsg, a * 3 + 2, D::HP, tt, id.lane,
-                   (ld_blk(vec, (size_t)src * 3 + 2, D::HP, tt, id.lane) * a2 + a3 * uz) * inv_sqrt_h);
+                   (ld_blk(vec, (size_t)src * 3 + 2, D::HP, tt, id.lane) * a2 + a3 * uz + q[0] * cz) * inv_sqrt_h);
         }
     }
 }

@@ -42,6 +42,7 @@ struct LayerOff {
     // LDS weight streams of the two hot edge kernels, chunks in consumption order (oard_edge_v1.h)
     size_t gcl_stream, equi_stream;
     size_t gcl_b3, equi_b3;     // split-precision streams of the two edge kernels (oard_edge_b3.h); built only when those kernels are enabled
+    int xcross;                 // reflect_equiv = False: the Equi message carries x (x) coord_cross as well (leftnet.py:268-272)
 };
 struct PackOff {
     size_t emb, emb_b, nbemb, nbemb_b, s2v, s2v_b, rl0, rl0_b, rl2, rl2_b;
@@ -54,6 +55,7 @@ struct PackOff {
     size_t enc[OARD_MAX_OBJECTS], dec[OARD_MAX_OBJECTS];  // raw MLP blocks
     LayerOff layer[OARD_MAX_LAYERS];
     size_t total;
+    int signed_scal;  // reflect_equiv = False: no |.| on the second frame component of the edge scalarisation (leftnet.py:794-796)
 };
 
 // ---- topology tables (device pointers) -----------------------------------------------------------

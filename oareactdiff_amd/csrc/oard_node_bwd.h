@@ -30,7 +30,8 @@ struct ScalarizeBwd {
 template <class D, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bwd(TopoDev tp, const float* __restrict__ l3, const float* __restrict__ ne1,
                                                               int ld, const float* __restrict__ geo, const float* __restrict__ gdew,
-                                                              float* __restrict__ dne1, float* __restrict__ part) {
+                                                              float* __restrict__ dne1, float* __restrict__ part, int signed_scal) {
+    // signed_scal: reflect_equiv = False - no |.| on the second frame component (leftnet.py:794-796)
     using SB = ScalarizeBwd<D>;
     constexpr int H4 = SB::H4, HQ = SB::HQ, HT = D::HT;
     __shared__ float red[WAVES][4 * HQ * 4 * 5 + 4];
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bw
                 const float S0 = n0 * ux + n1 * uy + n2 * uz;
                 const float S1r = n0 * cx + n1 * cy + n2 * cz;
                 const float S2 = n0 * vx + n1 * vy + n2 * vz;
-                const float S1 = fabsf(S1r);
+                const float S1 = signed_scal ? S1r : fabsf(S1r);
                 const float bval = g == 0 ? S0 : (g == 1 ? S1 : (g == 2 ? S2 : 1.0f));
                 const float dout = chok ? gdew[a * D::WP + side * D::H + ch] * env : 0.f;
                 float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bw
                     }
                 }
                 p0 = col_reduce(p0); p1 = col_reduce(p1); p2 = col_reduce(p2);
-                const float dS0 = p0 + dout, dS1 = S1r < 0.f ? -p1 : (S1r > 0.f ? p1 : 0.f), dS2 = p2;
+                const float dS0 = p0 + dout, dS1 = signed_scal ? p1 : (S1r < 0.f ? -p1 : (S1r > 0.f ? p1 : 0.f)), dS2 = p2;
                 d0 += dS0 * ux + dS1 * cx + dS2 * vx;
                 d1 += dS0 * uy + dS1 * cy + dS2 * vy;
                 d2 += dS0 * uz + dS1 * cz + dS2 * vz;
@@ -173,7 +174,8 @@ template <class D>
 __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* __restrict__ geo, Strided3 xq, Strided3 vec,
                                                       const float* __restrict__ cd, Strided3 cr, const float* __restrict__ gX,
                                                       int gx_row, Strided3 gV, float* __restrict__ dcd, float* __restrict__ dcr,
-                                                      float* __restrict__ dxq, float* __restrict__ dvec, int o_comp) {
+                                                      float* __restrict__ dxq, float* __restrict__ dvec, int o_comp, int xcross) {
+    // xcross: reflect_equiv = False (the message's x (x) coord_cross term, leftnet.py:268-272)
     // outputs d xq / d vec: [N][3][o_comp] (o_comp = H: dense; o_comp = HP: padded, the pads are written as zeros)
     const int n = blockIdx.x, ch = threadIdx.x;
     if (ch >= D::H) {
@@ -233,7 +235,9 @@ __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* _
             const float a2 = xs[1] * q[1] * inv_sqrt3;
             const float ga2 = (gv[0] * w[0] + gv[1] * w[1] + gv[2] * w[2]) * inv_sqrt_h;
             const float ga3 = (gv[0] * u[0] + gv[1] * u[1] + gv[2] * u[2]) * inv_sqrt_h;
-            const float dm[3] = {gx, ga2 * inv_sqrt3, ga3};
+            // reflect_equiv = False: the vector message holds x (x) coord_cross as well - its cotangent joins the scalar message's
+            const float gxc = xcross ? gx + (gv[0] * ge[5] + gv[1] * ge[6] + gv[2] * ge[7]) * inv_sqrt_h : gx;
+            const float dm[3] = {gxc, ga2 * inv_sqrt3, ga3};
 #pragma unroll
             for (int k = 0; k < 3; ++k) ax[k] += dm[k] * q[k];             // d xs -> d xq of BOTH end points; this is n's share
             if (role == 0) {

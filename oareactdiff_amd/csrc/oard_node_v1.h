@@ -407,7 +407,9 @@ OARD_DEV float lin3u1(const float* l3s, const float* __restrict__ p, float x) {
 //   messages from q, aggregation, s = (s + dx)/sqrt2, vec += dvec, vec_proj, frame scalar MLP,
 //   xvec_proj, s += (a + b + vdot)/sqrt2, vec += c * vec2.        vec_in != vec_out.
 // =====================================================================================================
-template <class D, int WAVES, bool ROWS = false>
+// XC: reflect_equiv = False - the message carries x (x) coord_cross as well (leftnet.py:268-272); its own instantiation, so
+// that the production kernel's register budget is untouched
+template <class D, int WAVES, bool ROWS = false, bool XC = false>
 __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const float* __restrict__ wb, LayerOff lo,
                                                              const float* __restrict__ qbuf, const float* __restrict__ xq,
                                                              const float* __restrict__ geo, const float* __restrict__ x1,
@@ -451,6 +453,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                 const int m = tp.act_src[a];
                 const float* gp = geo + a * GEO_STRIDE;
                 const float gx = gp[2], gy = gp[3], gz = gp[4];
+                const float cx = XC ? gp[5] : 0.f, cy = XC ? gp[6] : 0.f, cz = XC ? gp[7] : 0.f;
                 const f4 q0 = ld_blk(qbuf, a, 3 * D::HP, t, nb.lane), q1 = ld_blk(qbuf, a, 3 * D::HP, HT + t, nb.lane),
                          q2 = ld_blk(qbuf, a, 3 * D::HP, 2 * HT + t, nb.lane);
                 const f4 y0 = ld_blk(xq, m, 3 * D::HP, t, nb.lane), y1 = ld_blk(xq, m, 3 * D::HP, HT + t, nb.lane),
@@ -458,12 +461,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                 const f4 w0 = ld_blk(vec_in, (size_t)m * 3 + 0, D::HP, t, nb.lane), w1 = ld_blk(vec_in, (size_t)m * 3 + 1, D::HP, t, nb.lane),
                          w2 = ld_blk(vec_in, (size_t)m * 3 + 2, D::HP, t, nb.lane);
                 if (kk < cnt2) {
-                    dx += (y0 + zn0) * q0;
+                    const f4 xm = (y0 + zn0) * q0;
+                    dx += xm;
                     const f4 a2 = (y1 + zn1) * q1 * inv_sqrt3;
                     const f4 a3 = (y2 + zn2) * q2;
-                    v0 += (w0 * a2 + a3 * gx) * inv_sqrt_h;
-                    v1 += (w1 * a2 + a3 * gy) * inv_sqrt_h;
-                    v2 += (w2 * a2 + a3 * gz) * inv_sqrt_h;
+                    v0 += (XC ? w0 * a2 + a3 * gx + xm * cx : w0 * a2 + a3 * gx) * inv_sqrt_h;
+                    v1 += (XC ? w1 * a2 + a3 * gy + xm * cy : w1 * a2 + a3 * gy) * inv_sqrt_h;
+                    v2 += (XC ? w2 * a2 + a3 * gz + xm * cz : w2 * a2 + a3 * gz) * inv_sqrt_h;
                 }
             }
             dx = rows_total4(dx, rl, nb.lane); v0 = rows_total4(v0, rl, nb.lane);
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         for (int i = 0; i < 2; ++i) mnext[i] = tp.act_src[(size_t)min((long long)a0 + min(i, max(cnt - 1, 0)), a_hi)];
         for (int k = 0; !ROWS && k < mx; k += 2) {
             f4 q0[2], q1[2], q2[2], y0[2], y1[2], y2[2], w0[2], w1[2], w2[2];
-            float gx[2], gy[2], gz[2];
+            float gx[2], gy[2], gz[2], cx[2], cy[2], cz[2];
             const int mc[2] = {mnext[0], mnext[1]};
 #pragma unroll
             for (int i = 0; i < 2; ++i)          // source nodes of the NEXT step: their latency hides behind this step's gathers
@@ -486,6 +490,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                 const int m = mc[i];
                 const float* g = geo + a * GEO_STRIDE;
                 gx[i] = g[2]; gy[i] = g[3]; gz[i] = g[4];
+                cx[i] = XC ? g[5] : 0.f; cy[i] = XC ? g[6] : 0.f; cz[i] = XC ? g[7] : 0.f;
                 q0[i] = ld_blk(qbuf, a, 3 * D::HP, t, nb.lane); q1[i] = ld_blk(qbuf, a, 3 * D::HP, HT + t, nb.lane);
                 q2[i] = ld_blk(qbuf, a, 3 * D::HP, 2 * HT + t, nb.lane);
                 y0[i] = ld_blk(xq, m, 3 * D::HP, t, nb.lane); y1[i] = ld_blk(xq, m, 3 * D::HP, HT + t, nb.lane);
@@ -497,12 +502,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 if (k + i < cnt) {
-                    dx += (y0[i] + xn0) * q0[i];
+                    const f4 xm = (y0[i] + xn0) * q0[i];
+                    dx += xm;
                     const f4 a2 = (y1[i] + xn1) * q1[i] * inv_sqrt3;
                     const f4 a3 = (y2[i] + xn2) * q2[i];
-                    v0 += (w0[i] * a2 + a3 * gx[i]) * inv_sqrt_h;
-                    v1 += (w1[i] * a2 + a3 * gy[i]) * inv_sqrt_h;
-                    v2 += (w2[i] * a2 + a3 * gz[i]) * inv_sqrt_h;
+                    v0 += (XC ? w0[i] * a2 + a3 * gx[i] + xm * cx[i] : w0[i] * a2 + a3 * gx[i]) * inv_sqrt_h;
+                    v1 += (XC ? w1[i] * a2 + a3 * gy[i] + xm * cy[i] : w1[i] * a2 + a3 * gy[i]) * inv_sqrt_h;
+                    v2 += (XC ? w2[i] * a2 + a3 * gz[i] + xm * cz[i] : w2[i] * a2 + a3 * gz[i]) * inv_sqrt_h;
                 }
         }
         const f4 sa = (ld_blk(s, n, D::HP, t, nb.lane) + dx) * inv_sqrt2;

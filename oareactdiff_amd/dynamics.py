@@ -65,7 +65,7 @@ class EGNNDynamics(nn.Module):
         if model_config["act_fn"] not in ("swish", "silu"):
             raise NotImplementedError("only the swish/silu activation is implemented")
         for key, want in (("legacy", True), ("update", True), ("pos_grad", False), ("single_layer_output", True),
-                          ("object_aware", True), ("reflect_equiv", True), ("for_conf", False), ("ff", False)):
+                          ("object_aware", True), ("for_conf", False), ("ff", False)):       # reflect_equiv: both settings
             if model_config.get(key, want) != want:
                 raise NotImplementedError(f"model_config[{key!r}] must be {want} for the MI355X backend")
         if "in_edge_nf" in model_config:
@@ -176,7 +176,7 @@ class EGNNDynamics(nn.Module):
         cfg.condition_time = 1 if self.condition_time else 0
         cfg.pos_dim = self.pos_dim
         cfg.cutoff = float(self.model_config.get("cutoff", 10.0))
-        cfg.reflect_equiv = 1
+        cfg.reflect_equiv = 1 if self.model_config.get("reflect_equiv", True) else 0       # leftnet.py:268-272, 331, 794-796
         cfg.precision = self._precision_bits()
         return cfg
 

@@ -205,6 +205,12 @@ CASES = [
     dict(name="g6_h32_r32", model_config=dict(pos_require_grad=False, cutoff=20.0, num_layers=6,
                                                 hidden_channels=32, num_radial=32, in_hidden_channels=8),
          node_nfs=[9, 9, 9], condition_nf=1, fragments_nodes=[[4, 6], [5, 6], [4, 2]], t_1d=False),
+    # G10: reflect_equiv = False (leftnet.py:268-272, 794-796; the setting tests/model/test_equiv.py:172-185 exercises): the Equi message
+    # carries x (x) coord_cross, the edge scalarisation keeps its sign.  Test dims with a biting cutoff, and production dims.
+    dict(name="g10_noreflect_h32", model_config=dict(TEST_CFG, num_layers=3, reflect_equiv=False), node_nfs=[9, 9, 9],
+         condition_nf=1, fragments_nodes=[[5, 7, 3]] * 3, t_1d=False, pos_scale=3.0, onehot=True),
+    dict(name="g10p_noreflect_prod", model_config=dict(PROD, num_layers=2, reflect_equiv=False), node_nfs=[9, 9, 9],
+         condition_nf=1, fragments_nodes=[[9, 6]] * 3, t_1d=False, onehot=True),
 ]
 
 if __name__ == "__main__":

@@ -49,7 +49,12 @@ def hash_name(s):
     return h
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("--")]       # optional case names: generate only those
+
+
 def run(name, sizes, t_fixed, norm_values, cfg, pos_scale=1.0, T=100, pos_only=False):
+    if ONLY and name not in ONLY:
+        return
     node_nfs, cnf = [9, 9, 9], 1
     sd = synthetic_state_dict(state_spec(cfg, node_nfs, cnf), cfg, seed=42)
     B = len(sizes)
@@ -188,3 +193,6 @@ if __name__ == "__main__":
         pos_scale=3.0)
     run("g9_grad_h32", [4, 6, 1, 3], [5, 50, 99, 1], (1.0, 4.0, 10.0),
         dict(PRODUCTION_LEFTNET_CONFIG, num_layers=2, hidden_channels=32, num_radial=8))
+    # reflect_equiv = False: the adjoints of the message's x (x) coord_cross term and of the signed edge scalarisation
+    run("g9_grad_h32_noreflect", [4, 6, 1, 3], [5, 50, 99, 1], (1.0, 4.0, 10.0),
+        dict(PRODUCTION_LEFTNET_CONFIG, num_layers=2, hidden_channels=32, num_radial=8, reflect_equiv=False))

@@ -10,7 +10,8 @@ from oareactdiff_amd.spec import state_spec, synthetic_state_dict
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL_CASES = ["g1_wrapper_small", "g2_prod_b2_n23", "g2s_prod_b1_n5", "g3_cutoff_ragged",
-             "g3p_prod_cutoff", "g6_h32_r32"]
+             "g3p_prod_cutoff", "g6_h32_r32",
+             "g10_noreflect_h32", "g10p_noreflect_prod"]      # reflect_equiv = False (leftnet.py:268-272, 794-796)
 
 
 def rel(a, b):

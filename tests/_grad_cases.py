@@ -10,7 +10,7 @@ from oareactdiff_amd.loss import DiffusionLoss
 from oareactdiff_amd.spec import state_spec, synthetic_state_dict
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GRAD_CASES = ["g9_grad_h32", "g9_grad_prod_l2", "g9_grad_prod_cutoff", "g9_grad_prod_n23"]
+GRAD_CASES = ["g9_grad_h32", "g9_grad_prod_l2", "g9_grad_prod_cutoff", "g9_grad_prod_n23", "g9_grad_h32_noreflect"]
 #: g9_grad_prod_n23: two 23-atom reactions, production dims, all 6 layers, pos_only loss (oracle/make_goldens_grad.py --n23)
 NODE_NFS, CNF = [9, 9, 9], 1
 

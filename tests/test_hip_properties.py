@@ -176,3 +176,33 @@ def test_nan_guard_replaces_velocities_on_the_device():
         mean = torch.zeros(B, 3).index_add_(0, masks[k], vel) / torch.bincount(masks[k], minlength=B).clamp(min=1).unsqueeze(1)
         assert float(mean.abs().max()) <= 1e-6                    # CoM-free per (sample, object)
         assert 0.5 < float(vel.std()) < 1.5                       # N(0, 1) draws, not the network's output
+
+
+@pytest.mark.parametrize("name,reflects", [("g10_noreflect_h32", False), ("g3_cutoff_ragged", True)])
+def test_reflection_of_the_input(name, reflects):
+    """The reference's tests/model/test_equiv.py:172-185 (`test_no_reflection_equiv`): with reflect_equiv = False a mirrored input does
+    NOT give the unmirrored positions back (the message's x (x) coord_cross term and the signed scalarisation see the handedness),
+    relative difference > 1e-5.  With reflect_equiv = True (production) the network is reflection-equivariant: mirroring z commutes
+    with it (the test the reference keeps commented out, :157-170) - here within float32 noise of the mirrored output."""
+    from _cases import Case, rel
+    from test_hip_parity import _args, _dyn
+    dev = torch.device("cuda:0")
+    c = Case(name)
+    assert bool(c.cfg.get("reflect_equiv", True)) == reflects
+    dyn = _dyn(c, dev)
+    a = list(_args(c, dev))
+    mirror = torch.tensor([1.0, 1.0, -1.0], device=dev)
+    b = list(a)
+    b[0] = [torch.cat([x[:, :3] * mirror, x[:, 3:]], dim=1) for x in a[0]]
+    with torch.no_grad():
+        out, _ = dyn(*a)
+        out_m, _ = dyn(*b)
+    vel = torch.cat([o[:, :3] for o in out if o.numel()])
+    vel_m = torch.cat([o[:, :3] for o in out_m if o.numel()])
+    h, h_m = torch.cat([o[:, 3:].reshape(-1) for o in out if o.numel()]), torch.cat([o[:, 3:].reshape(-1) for o in out_m if o.numel()])
+    d_equiv = rel((vel_m * mirror).cpu(), vel.cpu())              # 0 for a reflection-equivariant network
+    print(f"{name}: |mirror(vel(mirror x)) - vel(x)| / |vel| = {d_equiv:.2e}, features {rel(h_m.cpu(), h.cpu()):.2e}")
+    if reflects:
+        assert d_equiv <= 2e-5 and rel(h_m.cpu(), h.cpu()) <= 2e-5
+    else:
+        assert d_equiv > 1e-5
