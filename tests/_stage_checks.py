@@ -64,6 +64,7 @@ def run(name, log=print):
     rbf_t, pp0_t, x1_t = tape.get(_capi.TAPE_RBF)[:A, :R], tape.get(_capi.TAPE_PP0)[:, 0], tape.get(_capi.TAPE_X1)
     g = refs.Geometry(*gargs, geo, rbf_t, pp0_t, x1_t)
     g64 = refs.Geometry(*gargs, geo.double(), rbf_t.double(), pp0_t.double(), x1_t.double())
+    g.reflect_equiv = g64.reflect_equiv = bool(c.cfg.get("reflect_equiv", True))
     stream = torch.cuda.current_stream(dev).cuda_stream
     L = _capi.lib()
     packed_f, packed_b = dyn._get_packed(cfg, stream), dyn._get_packed_bwd(cfg, stream)

@@ -44,6 +44,8 @@ class Geometry:
         self.rbf = rbf                                 # [A,R] radial basis, masked (leftnet.py:781-782)
         self.pos_prjt = torch.stack((pp0, torch.zeros_like(pp0), torch.zeros_like(pp0)), dim=1)   # [N,3], exact frame
         self.x1 = x1                                   # [N,3]
+        self.cross = geo[:, 5:8]                       # coord_cross, masked (leftnet.py:698-702, 770)
+        self.reflect_equiv = True                      # model_config["reflect_equiv"]; False: signed scalarisation, x (x) coord_cross
 
 
 def _lin3_rows(S: Tensor, w0: Tensor, b0: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
@@ -89,7 +91,8 @@ def stage_scalarize(P: Dict[str, Tensor], NE1: Tensor, g: Geometry, H: int, chun
             out = []
             for node in (g.src[sl], g.tgt[sl]):
                 S = torch.einsum("axh,axk->akh", NE1_[node], fr)                                            # :792-793
-                S = torch.cat((S[:, :1], S[:, 1:2].abs(), S[:, 2:]), dim=1)                                 # :794-796
+                if g.reflect_equiv:
+                    S = torch.cat((S[:, :1], S[:, 1:2].abs(), S[:, 2:]), dim=1)                             # :794-796
                 out.append(_lin3_rows(S, l0w_, l0b_, l2w_, l2b_) * g.env[sl, None])
             return torch.cat(out, dim=1)
         parts.append(checkpoint(piece, NE1, l0w, l0b, l2w, l2b, use_reentrant=False) if A > chunk
@@ -135,7 +138,10 @@ def stage_equi_message(P: Dict[str, Tensor], l: int, s: Tensor, xq: Tensor, cd: 
     cr = F.linear(g.rbf, P[f"model.message_layers.{l}.rbf_proj.weight"])             # [A,3H]
     msg = (xq[g.src] + xq[g.tgt]) * (cd.reshape(cd.shape[0], 3 * H) * cr)
     x_m, a2, a3 = torch.split(msg, H, dim=-1)
-    vmsg = (vec_in[g.src] * (a2 * INV_SQRT3)[:, None, :] + a3[:, None, :] * g.u[:, :, None]) * (1.0 / math.sqrt(H))
+    vmsg = vec_in[g.src] * (a2 * INV_SQRT3)[:, None, :] + a3[:, None, :] * g.u[:, :, None]
+    if not g.reflect_equiv:
+        vmsg = vmsg + x_m[:, None, :] * g.cross[:, :, None]                          # :268-272
+    vmsg = vmsg * (1.0 / math.sqrt(H))
     return (s + _seg_sum(x_m, g.tgt, N)) * INV_SQRT2, vec_in + _seg_sum(vmsg, g.tgt, N)
 
 
