@@ -72,6 +72,17 @@ struct GclBwdArgs {
 // state), so G == 0, z3 was never stored, dz3 is not produced, and the old-state gradient is just W1c^T dz1.
 // (Three LDS slabs with the barrier inside the phase - k_gcl_edge_v1's RING = 3 - were measured here: 13.03 against 12.83 ms per
 // step; this kernel waits for memory, not at the barrier.  Not kept.)
+// timing-only ablations of an experiment build (results are garbage): -DOARD_GB_ABL=1 no vmcnt wait at the phase barriers of
+// k_gcl_edge_bwd, 2 no global stores, 3 no edge-row loads, 4 neither loads nor stores
+#ifndef OARD_GB_ABL
+#define OARD_GB_ABL 0
+#endif
+OARD_DEV void gb_barrier() {
+    if (OARD_GB_ABL == 1) __syncthreads(); else phase_barrier();
+}
+__device__ int g_gb_never = 0;            // always 0: "stores" of the no-store ablations stay in the code (nothing is dead) but never execute
+OARD_DEV void gb_st(float* p, f4 v) { if ((OARD_GB_ABL != 2 && OARD_GB_ABL != 4) || g_gb_never) st_f4(p, v); }
+OARD_DEV f4 gb_ld(const float* p) { return (OARD_GB_ABL == 3 || OARD_GB_ABL == 4) ? (f4){0.25f, -0.5f, 0.125f, 1.0f} : ld_f4(p); }
 template <class D, int WAVES, int GP, bool HAS_S3>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, const float* __restrict__ stream,
                                                                 long long r0, long long r1, GclBwdArgs a) {
@@ -107,8 +118,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
     f4 gn[GP], zn[GP];
 #pragma unroll
     for (int gg = 0; gg < GP; ++gg) {
-        gn[gg] = (HAS_S3 && gg < WB) ? ld_f4(grow + 16 * gg) : f4zero();
-        zn[gg] = (HAS_S3 && gg < WB) ? ld_f4(z3row + 16 * gg) : f4zero();
+        gn[gg] = (HAS_S3 && gg < WB) ? gb_ld(grow + 16 * gg) : f4zero();
+        zn[gg] = (HAS_S3 && gg < WB) ? gb_ld(z3row + 16 * gg) : f4zero();
     }
     int p = HAS_S3 ? 0 : S::NP3;
     pf_begin(p);
@@ -118,10 +129,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
     f4 xs[GP];
     f4 dmx = f4zero();                                   // ROWS4: second accumulator of the 4-row tile (unreduced k-slice sums)
     for (int p3 = 0; HAS_S3 && p3 < S::NP3; ++p3, ++p) {
-        phase_barrier();
+        gb_barrier();
         if (p3 > 0) {
 #pragma unroll
-            for (int gg = 0; gg < GP; ++gg) st_f4(dz3row + 16 * ((p3 - 1) * GP + gg), xs[gg]);
+            for (int gg = 0; gg < GP; ++gg) gb_st(dz3row + 16 * ((p3 - 1) * GP + gg), xs[gg]);
         }
         f4 x[GP];
 #pragma unroll
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int b = (p3 + 1) * GP + gg;
-                if (b < WB) { gn[gg] = ld_f4(grow + 16 * b); zn[gg] = ld_f4(z3row + 16 * b); }
+                if (b < WB) { gn[gg] = gb_ld(grow + 16 * b); zn[gg] = gb_ld(z3row + 16 * b); }
             }
         }
 #pragma unroll
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
             const int b = (S::NP3 - 1) * GP + gg;
-            if (b < WB) st_f4(dz3row + 16 * b, xs[gg]);
+            if (b < WB) gb_st(dz3row + 16 * b, xs[gg]);
         }
         if (ROWS4) {                                     // k-slice sums of the 4-row tile -> block layout (real rows in lanes g = 0)
             const f4 v = reduce_g(dm[HT - 1] + dmx);
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
             dz2[t] = ld_blk(a.z2, e, D::HP, t, lane);              // z2 for now
             const f4 m0 = silu4(dz2[t]);
             part += dm[t].x * m0.x + dm[t].y * m0.y + dm[t].z * m0.z + dm[t].w * m0.w;
-            st_blk(a.mout, e, D::HP, t, lane, m0 * gate);
+            if ((OARD_GB_ABL != 2 && OARD_GB_ABL != 4) || g_gb_never) st_blk(a.mout, e, D::HP, t, lane, m0 * gate);
         }
         const float dav = col_reduce(part) * dsilu1(att);
         if (g == 0) a.da[e] = dav;
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
         for (int t = 0; t < HT; ++t) {
             const f4 z = dz2[t];
             dz2[t] = (dm[t] * gate + ld_vec(a.watt, t, lane) * dav) * dsilu4(z);
-            st_blk(a.dz2, e, D::HP, t, lane, dz2[t]);
+            if ((OARD_GB_ABL != 2 && OARD_GB_ABL != 4) || g_gb_never) st_blk(a.dz2, e, D::HP, t, lane, dz2[t]);
         }
     }
 
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
     for (int gg = 0; gg < GP; ++gg) z1n[gg] = gg < HT ? ld_blk(a.z1, e, D::HP, gg, lane) : f4zero();
 #pragma unroll
     for (int p2 = 0; p2 < S::NP2; ++p2, ++p) {
-        phase_barrier();
+        gb_barrier();
         pf_begin(p + 1);
         f4 zc[GP];
 #pragma unroll
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
             }
         } else {                                       // prefetch the incoming-gradient tiles of T1's first phase
 #pragma unroll
-            for (int gg = 0; gg < GP; ++gg) on[gg] = (HAS_S3 && gg < WB) ? ld_f4(grow + 16 * gg) : f4zero();
+            for (int gg = 0; gg < GP; ++gg) on[gg] = (HAS_S3 && gg < WB) ? gb_ld(grow + 16 * gg) : f4zero();
         }
 #pragma unroll
         for (int gg = 0; gg < GP; ++gg) {
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
                 } else {
                     dz1[t] = chain_tile<HT, TAIL1>(SL(p), gg * G, dz2, f4zero(), dz2_tail, hook) * dsilu4(zc[gg]);
                 }
-                st_blk(a.dz1, e, D::HP, t, lane, dz1[t]);
+                if ((OARD_GB_ABL != 2 && OARD_GB_ABL != 4) || g_gb_never) st_blk(a.dz1, e, D::HP, t, lane, dz1[t]);
             }
         }
         pf.flush();
@@ -224,10 +235,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
     f4 pend[GP];
     const float dz1_tail = TAIL1 ? tail_compact(dz1[HT - 1], lane) : 0.f;
     for (int p1 = 0; p1 < S::NP1; ++p1, ++p) {
-        phase_barrier();
+        gb_barrier();
         if (p1 > 0) {
 #pragma unroll
-            for (int gg = 0; gg < GP; ++gg) st_f4(grow + 16 * ((p1 - 1) * GP + gg), pend[gg]);
+            for (int gg = 0; gg < GP; ++gg) gb_st(grow + 16 * ((p1 - 1) * GP + gg), pend[gg]);
         }
         f4 o[GP];
 #pragma unroll
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int t = (p1 + 1) * GP + gg;
-                if (t < WB) on[gg] = ld_f4(grow + 16 * t);
+                if (t < WB) on[gg] = gb_ld(grow + 16 * t);
             }
         }
 #pragma unroll
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
 #pragma unroll
     for (int gg = 0; gg < GP; ++gg) {
         const int t = (S::NP1 - 1) * GP + gg;
-        if (t < WB) st_f4(grow + 16 * t, pend[gg]);
+        if (t < WB) gb_st(grow + 16 * t, pend[gg]);
     }
 }
 

@@ -717,8 +717,10 @@ static int scalarize_backward_impl(const oard_config* c, const TopoDev& tp, cons
                                    const float* ne1, int ld, const float* dew, float* dne1, float* part, hipStream_t st) {
     const PackOff po = make_layout(c);
     constexpr int NW = D::HT < 4 ? D::HT : 4;      // one wave per SIMD: the kernel keeps ~150 accumulators / constants per lane
-    LAUNCH(F_INIT, (k_scalarize_bwd<D, NW>), tp.N, NW * 64, st, tp, wb + po.lin3, ne1, ld, (const float*)(tape + to.geo), dew, dne1, part,
-           po.signed_scal);
+    if (po.signed_scal)
+        LAUNCH(F_INIT, (k_scalarize_bwd<D, NW, true>), tp.N, NW * 64, st, tp, wb + po.lin3, ne1, ld, (const float*)(tape + to.geo), dew, dne1, part);
+    else
+        LAUNCH(F_INIT, (k_scalarize_bwd<D, NW, false>), tp.N, NW * 64, st, tp, wb + po.lin3, ne1, ld, (const float*)(tape + to.geo), dew, dne1, part);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
@@ -1475,7 +1477,7 @@ int oard_lin3u_backward(const oard_config* c, const void* packed, int layer, con
 // ---- plan of the 16 x 16-tile kernel (oard_wgrad_t16.h): a pure function of the shape ------------------------------------------------
 struct WgtPlan { int ok, transposed, MT, NT, nPT, nQT, TM, TN, n_chunks, grid; long long rpc; };
 // kernel instantiations: (largest wave tile TM x TN, SiLU on the Q operand)
-#define OARD_WGT_INSTANCES X(6, 7, false) X(4, 7, true) X(4, 7, false) X(5, 7, true)
+#define OARD_WGT_INSTANCES X(6, 7, false) X(4, 7, true) X(4, 7, false) X(5, 7, true) X(5, 3, false)
 static bool wgt_instance(int TM, int TN, bool silu) {
 #define X(tm_, tn_, s_) if (TM == tm_ && TN == tn_ && silu == s_) return true;
     OARD_WGT_INSTANCES

@@ -27,11 +27,13 @@ struct ScalarizeBwd {
 #ifndef OARD_SCAL_BWD_MINW
 #define OARD_SCAL_BWD_MINW 2
 #endif
-template <class D, int WAVES>
+// SIGNED: reflect_equiv = False - no |.| on the second frame component (leftnet.py:794-796).  A template parameter: as a run-time flag
+// it cost the production instantiation 69 spilled registers.
+template <class D, int WAVES, bool SIGNED = false>
 __global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bwd(TopoDev tp, const float* __restrict__ l3, const float* __restrict__ ne1,
                                                               int ld, const float* __restrict__ geo, const float* __restrict__ gdew,
-                                                              float* __restrict__ dne1, float* __restrict__ part, int signed_scal) {
-    // signed_scal: reflect_equiv = False - no |.| on the second frame component (leftnet.py:794-796)
+                                                              float* __restrict__ dne1, float* __restrict__ part) {
+    constexpr bool signed_scal = SIGNED;
     using SB = ScalarizeBwd<D>;
     constexpr int H4 = SB::H4, HQ = SB::HQ, HT = D::HT;
     __shared__ float red[WAVES][4 * HQ * 4 * 5 + 4];

@@ -1,0 +1,51 @@
+"""Register budgets of the hot kernels, checked at build time (no GPU): a spill in a production instantiation is a silent
+performance regression that no parity test sees (round 4: a run-time `reflect_equiv` flag cost k_scalarize_bwd 69 spilled registers and
+the training step 2.7 ms until it became a template parameter).  Compiles the production widths only and reads hipcc's
+-Rpass-analysis=kernel-resource-usage remarks."""
+import os
+import re
+import subprocess
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oareactdiff_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+#: demangled-name regex -> max scratch bytes per lane (the one known exception: the large-batch k_equi_node_v1)
+BUDGETS = {
+    r"^void k_gcl_edge_v1<Dims<196, 96>, 8, 2, .*, 2, 3>": 0,
+    r"^void k_equi_edge_v1<Dims<196, 96>, 8, ": 0,
+    r"^void k_gcl_edge_bwd<": 0,
+    r"^void k_equi_edge_bwd<": 0,
+    r"^void k_wgrad_t16<": 0,
+    r"^void k_wgrad_q<": 0,
+    r"^void k_scalarize_bwd<Dims<196, 96>, 4, false>": 0,
+    r"^void k_gcl_edge_b3<": 0,
+    r"^void k_equi_edge_b3<Dims<196, 96>, false>": 0,
+    r"^void k_equi_edge_b3<Dims<196, 96>, true>": 20,        # the optional split-precision TRAINING-mode forward (tape stores)
+    r"^void k_gcl_node_v1<Dims<196, 96>, 13, ": 0,
+    r"^void k_equi_node_v1<Dims<196, 96>, 13, (true|false), false>": 36,
+}
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_production_kernels_stay_inside_their_register_budgets(tmp_path):
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only", "-Wno-unused-result",
+                        "-DOARD_DIMS_LIST=X(196,96)", "-Rpass-analysis=kernel-resource-usage", "oard_hip.hip", "-o",
+                        os.path.join(tmp_path, "res.o")], cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = r.stderr.split("Function Name: ")[1:]
+    names = subprocess.run(["c++filt"], input="\n".join(b.split("\n")[0].split()[0] for b in blocks), capture_output=True,
+                           text=True).stdout.splitlines()
+    seen = {k: 0 for k in BUDGETS}
+    bad = []
+    for dem, b in zip(names, blocks):
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        vgpr = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        for pat, limit in BUDGETS.items():
+            if re.search(pat, dem):
+                seen[pat] += 1
+                if scratch > limit:
+                    bad.append(f"{dem[:140]}: {scratch} bytes of scratch per lane (budget {limit}), {vgpr} VGPRs")
+    assert not bad, "\n".join(bad)
+    assert all(v > 0 for v in seen.values()), [k for k, v in seen.items() if v == 0]

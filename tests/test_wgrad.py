@@ -76,6 +76,7 @@ def test_wgrad_long_contractions(rows, long_kernel):
     _case(rows, 624, 196, 208, 588, 592, 588, 588, 588, True, True, seed=rows + 2, ld_extra=8)     # dir_proj.2: SiLU on load, thirds
     _case(rows, 592, 588, 588, 588, 688, 684, 684, 684, False, True, seed=rows + 3)                # dir_proj.0 (transposed, bias on the Q side)
     _case(rows, 208, 196, 196, 196, 208, 196, 196, 196, True, True, seed=rows + 4)                 # edge_mlp.1
+    _case(rows, 624, 196, 208, 588, 96, 96, 96, 96, False, False, seed=rows + 5)                   # rbf_proj: 96-column X, no bias
 
 
 def test_wgrad_three_kernels_agree():
