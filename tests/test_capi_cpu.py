@@ -92,9 +92,14 @@ def test_no_cpu_fallback_and_config_errors():
     with pytest.raises(AssertionError):                         # _base.py:44-46
         EGNNDynamics(model_config=dict(c.cfg), fragment_names=["a"], node_nfs=c.node_nfs, edge_nf=0,
                      device=torch.device("cpu"))
-    with pytest.raises(NotImplementedError):
-        EGNNDynamics(model_config=dict(c.cfg, reflect_equiv=False), fragment_names=["a", "b", "c"],
+    with pytest.raises(NotImplementedError):                    # a LEFTNet switch outside the production setting
+        EGNNDynamics(model_config=dict(c.cfg, legacy=False), fragment_names=["a", "b", "c"],
                      node_nfs=c.node_nfs, edge_nf=0, condition_nf=c.cnf, device=torch.device("cpu"))
+    # reflect_equiv: both settings are implemented since round 4 and travel to the library in oard_config
+    for flag in (True, False):
+        dd = EGNNDynamics(model_config=dict(c.cfg, reflect_equiv=flag), fragment_names=["a", "b", "c"],
+                          node_nfs=c.node_nfs, edge_nf=0, condition_nf=c.cnf, device=torch.device("cpu"))
+        assert dd._config().reflect_equiv == int(flag)
 
 
 def test_checkpoint_adapter_round_trip():
