@@ -131,7 +131,7 @@ def lib() -> C.CDLL:
     L.oard_timing_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]; L.oard_timing_get.restype = C.c_int
     for env, opt in (("OARD_GCL_VARIANT", b"gcl_variant"), ("OARD_EQUI_VARIANT", b"equi_variant"),
                      ("OARD_NODE_VARIANT", b"node_variant"), ("OARD_GCL_SKIP", b"gcl_skip"), ("OARD_PARTS", b"parts"), ("OARD_SEQUENTIAL", b"sequential"), ("OARD_POISON", b"poison"), ("OARD_AUTO_SMALL", b"auto_small"), ("OARD_AUTO_TINY", b"auto_tiny"), ("OARD_NPB", b"npb"),
-                     ("OARD_WGRAD_WGS", b"wgrad_wgs"), ("OARD_WGRAD_LDS", b"wgrad_lds"), ("OARD_WGRAD_T16", b"wgrad_t16"), ("OARD_WGRAD_QUEUE", b"wgrad_queue"), ("OARD_WGRAD_SHAPES", b"wgrad_shapes"), ("OARD_TRAIN_DUAL", b"train_dual"), ("OARD_SMALL_SPLIT", b"small_split"),
+                     ("OARD_WGRAD_WGS", b"wgrad_wgs"), ("OARD_WGRAD_LDS", b"wgrad_lds"), ("OARD_WGRAD_T16", b"wgrad_t16"), ("OARD_WGRAD_QUEUE", b"wgrad_queue"), ("OARD_GATE_FOLD", b"gate_fold"), ("OARD_WGRAD_SHAPES", b"wgrad_shapes"), ("OARD_TRAIN_DUAL", b"train_dual"), ("OARD_SMALL_SPLIT", b"small_split"),
                      ("OARD_SKIP_FAMILIES", b"skip_families")):
         if os.environ.get(env) not in (None, ""):
             check(L.oard_debug_option(opt, int(os.environ[env])), f"oard_debug_option({opt.decode()})")

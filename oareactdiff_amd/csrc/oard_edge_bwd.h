@@ -33,6 +33,29 @@ OARD_DEV f4 dsilu4(f4 v) {
     return (f4){ra.x, ra.y, rb.x, rb.y};
 }
 
+// SiLU'(v) and SiLU(v) from one sigmoid
+OARD_DEV f4 dsilu4_silu(f4 v, f4& sil) {
+    const f2 a = {v.x, v.y}, b = {v.z, v.w};
+    const f2 ta = a * -1.44269504088896340736f, tb = b * -1.44269504088896340736f;
+    const f2 da = (f2){__builtin_amdgcn_exp2f(ta.x), __builtin_amdgcn_exp2f(ta.y)} + 1.0f;
+    const f2 db = (f2){__builtin_amdgcn_exp2f(tb.x), __builtin_amdgcn_exp2f(tb.y)} + 1.0f;
+    const f2 sa = {__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y)}, sb = {__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y)};
+    const f2 ra = sa * (a * (1.0f - sa) + 1.0f), rb = sb * (b * (1.0f - sb) + 1.0f);
+    const f2 ya = a * sa, yb = b * sb;
+    sil = (f4){ya.x, ya.y, yb.x, yb.y};
+    return (f4){ra.x, ra.y, rb.x, rb.y};
+}
+// sum over the 16 lanes of a DPP row (the 16 columns of one k-slice g); every lane of the row gets the total.  Four v_add_f32 with a
+// DPP operand: quad xor 1, quad xor 2, mirror inside the half row, mirror of the row
+#define OARD_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false))
+OARD_DEV float row16_sum(float x) {
+    x += OARD_DPP(x, 0xB1);       // quad_perm [1, 0, 3, 2]
+    x += OARD_DPP(x, 0x4E);       // quad_perm [2, 3, 0, 1]
+    x += OARD_DPP(x, 0x141);      // row_half_mirror
+    x += OARD_DPP(x, 0x140);      // row_mirror
+    return x;
+}
+
 // =====================================================================================================
 // GCLMessage edge part, backward.  Stream (chunks, all groups HT wide, no bias chunks):
 //   T3 = WB groups x HT [W3^T, K-outer over the blocks of dz3];  T2 = HT groups x HT [W2^T tile t];
@@ -66,6 +89,9 @@ struct GclBwdArgs {
     float* dz2;                        // [E+1][HP] out
     float* da;                         // [E+1]     out
     float* dz1;                        // [E+1][HP] out
+    float* gate_part;                  // [waves of the launch][HP] out, or nullptr: per-wave sums over its 16 edges of da * SiLU(z2) (the
+                                       // att_mlp weight gradient; feature H holds the sum of da = its bias gradient) - a fixed-order
+                                       // k_colsum_fin over the rows finishes them.  Round 4: replaces a [E][H] column-sum pass per layer
 };
 
 // HAS_S3 = false: inter-object rows of the last layer - the forward skipped S3 there (nothing reads their new
@@ -184,11 +210,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_gcl_edge_bwd(TopoDev tp, cons
         }
         const float dav = col_reduce(part) * dsilu1(att);
         if (g == 0) a.da[e] = dav;
+        const float dav_w = c < r1 ? dav : 0.f;                      // padding columns (spare row) do not count
+        float* gp = a.gate_part != nullptr ? a.gate_part + ((size_t)blockIdx.x * WAVES + wave) * D::HP + 4 * g : nullptr;
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
             const f4 z = dz2[t];
-            dz2[t] = (dm[t] * gate + ld_vec(a.watt, t, lane) * dav) * dsilu4(z);
+            f4 m0;
+            const f4 ds = dsilu4_silu(z, m0);
+            dz2[t] = (dm[t] * gate + ld_vec(a.watt, t, lane) * dav) * ds;
             if ((OARD_GB_ABL != 2 && OARD_GB_ABL != 4) || g_gb_never) st_blk(a.dz2, e, D::HP, t, lane, dz2[t]);
+            if (gp != nullptr) {                                     // wave-uniform
+                f4 w = m0 * dav_w;
+                if (16 * t + 4 * g == D::H) w.x = dav_w;             // the first pad feature carries sum(da): att_mlp's bias gradient
+                w = (f4){row16_sum(w.x), row16_sum(w.y), row16_sum(w.z), row16_sum(w.w)};
+                if ((lane & 15) == 0) st_f4(gp + 16 * t, w);
+            }
         }
     }
 

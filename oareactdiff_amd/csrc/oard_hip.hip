@@ -685,20 +685,28 @@ static BwdOff make_bwd_layout(const oard_config* c) {
 template <class D>
 static int gcl_backward_impl(const oard_config* c, const TopoDev& tp, const float* pb, const BwdLayerOff& bl, int layer,
                              const char* tape, const TapeOff& to, const float* dagg, float* dew, float* dz3, float* mout,
-                             float* dz2, float* da, float* dz1, hipStream_t st) {
+                             float* dz2, float* da, float* dz1, hipStream_t st, float* gate_part = nullptr, long long* gate_rows = nullptr) {
     GclBwdArgs a;
+    a.gate_part = gate_part;
     a.z1 = (const float*)(tape + to.z1[layer]); a.z2 = (const float*)(tape + to.z2[layer]);
     a.att = (const float*)(tape + to.att[layer]); a.z3 = (const float*)(tape + to.z3[layer]);
     a.dagg = dagg; a.watt = pb + bl.watt; a.dew = dew; a.dz3 = dz3; a.mout = mout; a.dz2 = dz2; a.da = da; a.dz1 = dz1;
     const float* stream = pb + bl.gcl;
     const bool last = layer == c->num_layers - 1;
     const long long r_full = last ? tp.A : tp.E;       // rows whose forward ran S3
-    if (r_full > 0)
+    long long rows = 0;                                 // per-wave rows of gate_part written so far
+    if (r_full > 0) {
         LAUNCH_LDS(F_GCL_BWD, (k_gcl_edge_bwd<D, 8, 2, true>), cdiv(r_full, 128), 512, (GclBwdStream<D, 2>::LDS_BYTES), st,
                    tp, stream, 0LL, r_full, a);
-    if (last && tp.E > tp.A)
+        rows += cdiv(r_full, 128) * 8;
+    }
+    if (last && tp.E > tp.A) {
+        if (a.gate_part) a.gate_part += (size_t)rows * D::HP;
         LAUNCH_LDS(F_GCL_BWD, (k_gcl_edge_bwd<D, 8, 2, false>), cdiv(tp.E - tp.A, 128), 512, (GclBwdStream<D, 2>::LDS_BYTES), st,
                    tp, stream, tp.A, tp.E, a);
+        rows += cdiv(tp.E - tp.A, 128) * 8;
+    }
+    if (gate_rows) *gate_rows = rows;
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
@@ -1548,6 +1556,7 @@ struct WgQueueScope {           // installs a queue for the duration of one swee
     WgQueueScope(char* region, size_t bytes, hipStream_t st) { q.region = region; q.region_bytes = bytes; q.st = st; t_wgq = &q; }
     ~WgQueueScope() { t_wgq = nullptr; }
 };
+int g_gate_fold = 1;         // 0: att_mlp gradient sums by column-sum passes over [E][H] instead of inside k_gcl_edge_bwd (A/B)
 int g_wgrad_queue = 1;       // 0: every product is launched on its own (A/B, bit-identical)
 static int wgq_flush() {
     WgQueue* q = t_wgq;
@@ -1940,6 +1949,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "wgrad_wgs") == 0) { g_wgrad_wgs = value; return OARD_OK; }
     if (strcmp(name, "wgrad_t16") == 0) { g_wgrad_t16 = value; return OARD_OK; }
     if (strcmp(name, "wgrad_queue") == 0) { g_wgrad_queue = value; return OARD_OK; }
+    if (strcmp(name, "gate_fold") == 0) { g_gate_fold = value; return OARD_OK; }
     if (strcmp(name, "wgrad_lds") == 0) { g_wgrad_lds = value; return OARD_OK; }
     if (strcmp(name, "wgrad_shapes") == 0) { g_wgrad_shapes = value & 3; return OARD_OK; }
     if (strcmp(name, "train_dual") == 0) { g_train_dual = value; return OARD_OK; }

@@ -29,6 +29,7 @@ struct TrainWs {
     size_t gx, gs_a, gvec_a, dxq, dvec_in, dcd, dcr, dzd1, dz3, mout, dz2, dz1, da, dPQ, dagg;
     // GCL node / pre adjoint
     size_t dzq, dxln, lng, dsm, dzm, dxh, t1, t2, dhid, dzh;
+    size_t gatep;              // per-wave partial sums of the att_mlp gradients, written by k_gcl_edge_bwd ([E / 16 + 32][HP])
     size_t lng2, dsn;          // node_pre adjoint: its own LayerNorm product buffer, cotangent of s entering the layer (copy read by the gradient stream)
     // column sums, weight-gradient partials (used by the gradient stream only)
     size_t csum, cpart, wg, wgq;
@@ -56,6 +57,7 @@ static TrainWs make_train_ws(const oard_config* c, const TopoDev& td) {
     w.dzq = take(N * HP * F); w.dxln = take(N * HP * F); w.lng = take(N * HP * F); w.dsm = take(N * HP * F); w.dzm = take(N * HP * F);
     w.dxh = take(N * HP * F); w.t1 = take(N * HP * F); w.t2 = take(N * HP * F); w.dhid = take(N * d.PP * F); w.dzh = take(N * d.PP * F);
     w.lng2 = take(N * HP * F); w.dsn = take(N * HP * F);
+    w.gatep = take((E / 16 + 32) * HP * F);
     w.layer_bytes = cur;
     cur = 2 * w.layer_bytes;
     w.csum = take(4096 * F);
@@ -471,7 +473,9 @@ static int tr_gcl_edge_bwd(const TrainCtx& x, int l, const float* dagg, float* d
     }
     const int g = x.pi.gcl0 + 14 * l;
     float *dz3 = x.f(x.w.dz3), *mout = x.f(x.w.mout), *dz2 = x.f(x.w.dz2), *dz1 = x.f(x.w.dz1), *da = x.f(x.w.da);
-    TR_TRY(gcl_backward_impl<D>(x.c, tp, x.pb, x.bo.layer[l], l, x.tape, x.to, dagg, dew, dz3, mout, dz2, da, dz1, x.st));
+    long long gate_rows = 0;
+    float* gatep = (g_gate_fold && HP > H) ? x.f(x.w.gatep) : nullptr;
+    TR_TRY(gcl_backward_impl<D>(x.c, tp, x.pb, x.bo.layer[l], l, x.tape, x.to, dagg, dew, dz3, mout, dz2, da, dz1, x.st, gatep, &gate_rows));
     LAUNCH(F_GCL_BWD, k_edge_node_sums, N, 64, x.st, tp, (const float*)dz1, HP, dP, dQ);
     x.fork();
     const long long rows3 = l == NL - 1 ? A : E;          // rows whose forward evaluated edge_out_trans
@@ -485,8 +489,14 @@ static int tr_gcl_edge_bwd(const TrainCtx& x, int l, const float* dagg, float* d
         ScopedLaunch sl_(F_WGRAD, x.stw);
         hipLaunchKernelGGL(k_outer_acc, EW_GRID((long long)H * W), 0, x.stw, w1c, 2 * H + W, (const float*)x.f(x.w.csum), H, x.wb + x.po.c0row, W, 1);
     }
-    colsum(x, x.t(x.to.z2[l]), HP, 0, E, H, x.g(g + 10), 1, da, 1);      // att_mlp weight: sum_e da_e SiLU(z2_e)
-    colsum(x, da, 1, 0, E, 1, x.g(g + 11));                               // att_mlp bias
+    // att_mlp weight: sum_e da_e SiLU(z2_e), bias: sum_e da_e - k_gcl_edge_bwd left per-wave sums over its 16 edges (feature H = the bias)
+    if (gatep) {
+        colsum(x, gatep, HP, 0, gate_rows, H, x.g(g + 10));
+        colsum(x, gatep + H, HP, 0, gate_rows, 1, x.g(g + 11));
+    } else {
+        colsum(x, x.t(x.to.z2[l]), HP, 0, E, H, x.g(g + 10), 1, da, 1);
+        colsum(x, da, 1, 0, E, 1, x.g(g + 11));
+    }
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }
