@@ -720,11 +720,14 @@ static int equi_backward_impl(const TopoDev& tp, const float* stream, const floa
     return OARD_OK;
 }
 
+#ifndef OARD_SCAL_BWD_WAVES
+#define OARD_SCAL_BWD_WAVES 2
+#endif
 template <class D>
 static int scalarize_backward_impl(const oard_config* c, const TopoDev& tp, const float* wb, const char* tape, const TapeOff& to,
                                    const float* ne1, int ld, const float* dew, float* dne1, float* part, hipStream_t st) {
     const PackOff po = make_layout(c);
-    constexpr int NW = D::HT < 4 ? D::HT : 4;      // one wave per SIMD: the kernel keeps ~150 accumulators / constants per lane
+    constexpr int NW = OARD_SCAL_BWD_WAVES;        // 2 HT units of (channel tile, side) per node, dealt to the waves
     if (po.signed_scal)
         LAUNCH(F_INIT, (k_scalarize_bwd<D, NW, true>), tp.N, NW * 64, st, tp, wb + po.lin3, ne1, ld, (const float*)(tape + to.geo), dew, dne1, part);
     else

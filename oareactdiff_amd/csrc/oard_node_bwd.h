@@ -24,11 +24,33 @@ struct ScalarizeBwd {
 
 // ne1: [N][3][ld] (ld >= H), gdew: gradient of the initial edge state, rows = inner edges, row stride WP, columns [0, 2H)
 // dne1: [N][3][ld] out;  part: [N][NPART] out (summed over the node's edges and channels; the caller adds the nodes up)
+//
+// Round 4 (second version).  The first version spent 33 instructions per hidden-unit evaluation (the compiler packed the four rows of
+// an MFMA result into v_pk_* operands through register moves), waited for three dependent loads per item and dealt 13 channel tiles
+// to 4 waves (4 + 3 + 3 + 3).  Now: (a) the rows of a lane are processed as the register PAIRS the MFMA result already consists of
+// (sc_eval<f2>: 16 packed instructions + 4 transcendentals per two evaluations), (b) a unit of work is (channel tile, side) - 2 HT
+// units, 13 per wave at 2 waves per node - and the per-lane partial sums of d NE1 are only reduced over the k-groups once per unit,
+// (c) the geometry row and the gradient element of the NEXT item are loaded before the current item is evaluated.
 #ifndef OARD_SCAL_BWD_MINW
 #define OARD_SCAL_BWD_MINW 2
 #endif
-// SIGNED: reflect_equiv = False - no |.| on the second frame component (leftnet.py:794-796).  A template parameter: as a run-time flag
-// it cost the production instantiation 69 spilled registers.
+template <class T> OARD_DEV T sc_exp2(T v);
+template <> OARD_DEV float sc_exp2<float>(float v) { return __builtin_amdgcn_exp2f(v); }
+template <> OARD_DEV f2 sc_exp2<f2>(f2 v) { return (f2){__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
+template <class T> OARD_DEV T sc_rcp(T v);
+template <> OARD_DEV float sc_rcp<float>(float v) { return __builtin_amdgcn_rcpf(v); }
+template <> OARD_DEV f2 sc_rcp<f2>(f2 v) { return (f2){__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; }
+// one (T = float) or two (T = f2) hidden rows of one item: z = pre-activation, w2 / w0 = the rows' constants
+template <class T>
+OARD_DEV void sc_eval(T z, float dout, float S0, float S1, float S2, T w2, const T (&w0)[3], T& aw2, T& ab0, T (&aw0)[3], T (&p)[3]) {
+    const T sg = sc_rcp<T>(sc_exp2<T>(z * -1.44269504088896340736f) + 1.0f);
+    aw2 += (z * sg) * dout;
+    const T dz = (w2 * dout) * (sg * (z * (1.0f - sg) + 1.0f));
+    ab0 += dz;
+    aw0[0] += dz * S0; aw0[1] += dz * S1; aw0[2] += dz * S2;
+    p[0] += dz * w0[0]; p[1] += dz * w0[1]; p[2] += dz * w0[2];
+}
+
 template <class D, int WAVES, bool SIGNED = false>
 __global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bwd(TopoDev tp, const float* __restrict__ l3, const float* __restrict__ ne1,
                                                               int ld, const float* __restrict__ geo, const float* __restrict__ gdew,
@@ -37,7 +59,9 @@ __global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bw
     using SB = ScalarizeBwd<D>;
     constexpr int H4 = SB::H4, HQ = SB::HQ, HT = D::HT;
     __shared__ float red[WAVES][4 * HQ * 4 * 5 + 4];
-    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+    __shared__ float dpart[2 * HT][3][16];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform for the compiler: scalar address arithmetic
     const int n = blockIdx.x;
     const float* w0 = l3;
     const float* b0 = l3 + H4 * 3;
@@ -49,79 +73,112 @@ __global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bw
         const int row = 16 * q + j;
         aw[q] = row < H4 ? (g < 3 ? w0[row * 3 + g] : b0[row]) : 0.f;
     }
-    // constants of this lane's rows 16q + 4g + r
-    float w2r[HQ][4], w0r[HQ][4][3];
+    // constants and accumulators of this lane's rows 16q + 4g + r, as pairs (r = 0, 1), (r = 2, 3)
+    f2 w2r[HQ][2], w0r[HQ][2][3], aw0[HQ][2][3], ab0[HQ][2], aw2[HQ][2];
+    float ab2 = 0.f;
 #pragma unroll
     for (int q = 0; q < HQ; ++q)
 #pragma unroll
-        for (int r = 0; r < SB::rows(q); ++r) {
+        for (int r = 0; r < 4; ++r) {
             const int row = 16 * q + 4 * g + r;
-            const bool ok = row < H4;
-            w2r[q][r] = ok ? w2[row] : 0.f;
+            const bool ok = r < SB::rows(q) && row < H4;
+            w2r[q][r >> 1][r & 1] = ok ? w2[row] : 0.f;
+            ab0[q][r >> 1][r & 1] = 0.f; aw2[q][r >> 1][r & 1] = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) w0r[q][r][c] = ok ? w0[row * 3 + c] : 0.f;
+            for (int c = 0; c < 3; ++c) { w0r[q][r >> 1][c][r & 1] = ok ? w0[row * 3 + c] : 0.f; aw0[q][r >> 1][c][r & 1] = 0.f; }
         }
-    float aw0[HQ][4][3], ab0[HQ][4], aw2[HQ][4], ab2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < HQ; ++q)
-#pragma unroll
-        for (int r = 0; r < SB::rows(q); ++r) { ab0[q][r] = 0.f; aw2[q][r] = 0.f; aw0[q][r][0] = 0.f; aw0[q][r][1] = 0.f; aw0[q][r][2] = 0.f; }
 
     const int q_grp = tp.node_sample[n] * tp.n_obj + tp.node_obj[n];
     const int g0 = tp.grp_ptr[q_grp], ng = tp.grp_ptr[q_grp + 1] - g0, self = n - g0;
     const int a_n = tp.act_ptr[n];
-    for (int t = wave; t < HT; t += WAVES) {
+    const int ni = ng - 1;                                    // items of a unit: the other members of the group
+    for (int u = wave; u < 2 * HT; u += WAVES) {
+        const int t = u >> 1, side = u & 1;
         const int ch = 16 * t + j;
         const bool chok = ch < D::H;
         const float n0 = chok ? ne1[((size_t)n * 3 + 0) * ld + ch] : 0.f;
         const float n1 = chok ? ne1[((size_t)n * 3 + 1) * ld + ch] : 0.f;
         const float n2 = chok ? ne1[((size_t)n * 3 + 2) * ld + ch] : 0.f;
+        // side 1: edge (m -> n), n is the target;  side 0: edge (n -> m), n is the source.  Item i is group member kk = i + (i >= self);
+        // its row is a_n + i (side 1) or act_ptr[member] + (position of n in the member's list) (side 0).
+        // zv is 0 in every lane but opaque to the compiler: rows count as per-lane values, so the geometry rows come by VECTOR loads
+        // (every lane the same address: one transaction), which return in order - the wait for item i + 1 is a vmcnt at the end of
+        // item i, where a scalar load would be waited for with lgkmcnt(0) wherever the next scalar load result is needed - and the
+        // loop body has no branch for hipcc to sink the loads behind.
+        const int zv = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);
+        auto member = [&](int i) { const int ii = (i < ni ? i : ni - 1) + zv; return g0 + ii + (ii >= self ? 1 : 0); };
+        auto row_of = [&](int i, int act) {
+            const int ii = (i < ni ? i : ni - 1) + zv, kk = ii + (ii >= self ? 1 : 0);
+            return side == 1 ? a_n + ii : act + self - (self > kk ? 1 : 0);
+        };
+        const int chc = side * D::H + (chok ? ch : 0);          // lanes beyond H read a valid element and discard it
         float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-        for (int kk = 0; kk < ng; ++kk) {
-            if (kk == self) continue;
+        if (ni > 0) {
+            int a_nx = row_of(0, tp.act_ptr[member(0)]);
+            // env u[3] c[3] v[3] of the row, and nothing else: a loaded register that is never read gets reused by the compiler, which
+            // then has to wait for the load to land first (write-after-write)
+            const float* gp = geo + (size_t)a_nx * GEO_STRIDE + 1;
+            float gc[10];
 #pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                // side 1: edge (m -> n), n is the target;  side 0: edge (n -> m), n is the source
-                const size_t a = side == 1 ? (size_t)a_n + kk - (kk > self ? 1 : 0)
-                                           : (size_t)tp.act_ptr[g0 + kk] + self - (self > kk ? 1 : 0);
-                const float* ge = geo + a * GEO_STRIDE;
-                const float env = ge[1];
-                const float ux = ge[2], uy = ge[3], uz = ge[4], cx = ge[5], cy = ge[6], cz = ge[7], vx = ge[8], vy = ge[9], vz = ge[10];
+            for (int k = 0; k < 10; ++k) gc[k] = gp[k];
+            float go = gdew[(size_t)a_nx * D::WP + chc];
+            a_nx = row_of(1, tp.act_ptr[member(1)]);
+            for (int i = 0; i < ni; ++i) {
+                // operands of item i + 1 and the list pointer of item i + 2 travel while item i is evaluated (the last iterations re-read
+                // the last item)
+                gp = geo + (size_t)a_nx * GEO_STRIDE + 1;
+                float gn[10];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) gn[k] = gp[k];
+                const float gon = gdew[(size_t)a_nx * D::WP + chc];
+                const int act_nx = tp.act_ptr[member(i + 2)];
+                __builtin_amdgcn_sched_barrier(0);              // the loads stay up here (hipcc otherwise sinks them to the end of the body)
+                const float env = gc[0];
+                const float ux = gc[1], uy = gc[2], uz = gc[3], cx = gc[4], cy = gc[5], cz = gc[6], vx = gc[7], vy = gc[8], vz = gc[9];
                 const float S0 = n0 * ux + n1 * uy + n2 * uz;
                 const float S1r = n0 * cx + n1 * cy + n2 * cz;
                 const float S2 = n0 * vx + n1 * vy + n2 * vz;
                 const float S1 = signed_scal ? S1r : fabsf(S1r);
                 const float bval = g == 0 ? S0 : (g == 1 ? S1 : (g == 2 ? S2 : 1.0f));
-                const float dout = chok ? gdew[a * D::WP + side * D::H + ch] * env : 0.f;
-                float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+                const float dout = chok ? go * env : 0.f;
+                f2 pp[3] = {(f2){0.f, 0.f}, (f2){0.f, 0.f}, (f2){0.f, 0.f}};
+                float ps[3] = {0.f, 0.f, 0.f};
+                f4 zq[HQ];
+#pragma unroll
+                for (int q = 0; q < HQ; ++q) zq[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[q], bval, f4zero(), 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < HQ; ++q) {
-                    const f4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[q], bval, f4zero(), 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < SB::rows(q); ++r) {
-                        const float zz = z[r];
-                        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-zz));
-                        const float h = zz * sg;
-                        aw2[q][r] += dout * h;
-                        const float dz = dout * w2r[q][r] * (sg * (1.0f + zz * (1.0f - sg)));
-                        ab0[q][r] += dz;
-                        aw0[q][r][0] += dz * S0; aw0[q][r][1] += dz * S1; aw0[q][r][2] += dz * S2;
-                        p0 += dz * w0r[q][r][0]; p1 += dz * w0r[q][r][1]; p2 += dz * w0r[q][r][2];
+                    const f4 z = zq[q];
+                    const int rows = SB::rows(q);
+                    if (rows >= 2) sc_eval<f2>((f2){z.x, z.y}, dout, S0, S1, S2, w2r[q][0], w0r[q][0], aw2[q][0], ab0[q][0], aw0[q][0], pp);
+                    if (rows == 4) sc_eval<f2>((f2){z.z, z.w}, dout, S0, S1, S2, w2r[q][1], w0r[q][1], aw2[q][1], ab0[q][1], aw0[q][1], pp);
+                    if (rows == 1 || rows == 3) {              // an odd last row: scalar
+                        const int pi = rows >> 1;
+                        float w0s[3] = {w0r[q][pi][0].x, w0r[q][pi][1].x, w0r[q][pi][2].x};
+                        float a0s[3] = {aw0[q][pi][0].x, aw0[q][pi][1].x, aw0[q][pi][2].x};
+                        float a2s = aw2[q][pi].x, b0s = ab0[q][pi].x;
+                        sc_eval<float>(rows == 1 ? z.x : z.z, dout, S0, S1, S2, w2r[q][pi].x, w0s, a2s, b0s, a0s, ps);
+                        aw0[q][pi][0].x = a0s[0]; aw0[q][pi][1].x = a0s[1]; aw0[q][pi][2].x = a0s[2];
+                        aw2[q][pi].x = a2s; ab0[q][pi].x = b0s;
                     }
                 }
-                p0 = col_reduce(p0); p1 = col_reduce(p1); p2 = col_reduce(p2);
-                const float dS0 = p0 + dout, dS1 = signed_scal ? p1 : (S1r < 0.f ? -p1 : (S1r > 0.f ? p1 : 0.f)), dS2 = p2;
-                d0 += dS0 * ux + dS1 * cx + dS2 * vx;
-                d1 += dS0 * uy + dS1 * cy + dS2 * vy;
-                d2 += dS0 * uz + dS1 * cz + dS2 * vz;
+                // this lane's share (its hidden rows) of d S; the k-groups are added up once per unit
+                const float p0 = pp[0].x + pp[0].y + ps[0], p1 = pp[1].x + pp[1].y + ps[1], p2 = pp[2].x + pp[2].y + ps[2];
+                const float dS0 = p0 + (g == 0 ? dout : 0.f);
+                const float dS1 = signed_scal ? p1 : (S1r < 0.f ? -p1 : (S1r > 0.f ? p1 : 0.f));
+                d0 += dS0 * ux + dS1 * cx + p2 * vx;
+                d1 += dS0 * uy + dS1 * cy + p2 * vy;
+                d2 += dS0 * uz + dS1 * cz + p2 * vz;
                 if (g == 0) ab2 += dout;
+                __builtin_amdgcn_sched_barrier(0);
+                a_nx = row_of(i + 2, act_nx);
+#pragma unroll
+                for (int k = 0; k < 10; ++k) gc[k] = gn[k];
+                go = gon;
             }
         }
-        if (g == 0 && chok) {
-            dne1[((size_t)n * 3 + 0) * ld + ch] = d0;
-            dne1[((size_t)n * 3 + 1) * ld + ch] = d1;
-            dne1[((size_t)n * 3 + 2) * ld + ch] = d2;
-        }
+        d0 = col_reduce(d0); d1 = col_reduce(d1); d2 = col_reduce(d2);
+        if (g == 0) { dpart[u][0][j] = d0; dpart[u][1][j] = d1; dpart[u][2][j] = d2; }
     }
     // reduce the weight-gradient partials over the 16 channel lanes, then over the waves
     auto red16 = [](float v) {
@@ -132,8 +189,8 @@ __global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bw
     for (int q = 0; q < HQ; ++q)
 #pragma unroll
         for (int r = 0; r < SB::rows(q); ++r) {
-            const float s0 = red16(aw0[q][r][0]), s1 = red16(aw0[q][r][1]), s2 = red16(aw0[q][r][2]);
-            const float sb = red16(ab0[q][r]), sw = red16(aw2[q][r]);
+            const float s0 = red16(aw0[q][r >> 1][0][r & 1]), s1 = red16(aw0[q][r >> 1][1][r & 1]), s2 = red16(aw0[q][r >> 1][2][r & 1]);
+            const float sb = red16(ab0[q][r >> 1][r & 1]), sw = red16(aw2[q][r >> 1][r & 1]);
             if (j == 0) {
                 float* dst = &red[wave][((q * 4 + g) * 4 + r) * 5];        // row 16q + 4g + r
                 dst[0] = s0; dst[1] = s1; dst[2] = s2; dst[3] = sb; dst[4] = sw;
@@ -142,6 +199,11 @@ __global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bw
     ab2 = red16(ab2);
     if (lane == 0) red[wave][4 * HQ * 4 * 5] = ab2;
     __syncthreads();
+    // d NE1[n]: side 0 + side 1 of every channel tile
+    for (int i = threadIdx.x; i < HT * 3 * 16; i += WAVES * 64) {
+        const int t = i / 48, c = (i % 48) >> 4, jj = i & 15, ch = 16 * t + jj;
+        if (ch < D::H) dne1[((size_t)n * 3 + c) * ld + ch] = dpart[2 * t][c][jj] + dpart[2 * t + 1][c][jj];
+    }
     float* out = part + (size_t)n * SB::NPART;
     for (int i = threadIdx.x; i < SB::NPART; i += WAVES * 64) {
         float s = 0.f;

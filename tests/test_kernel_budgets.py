@@ -19,7 +19,7 @@ BUDGETS = {
     r"^void k_equi_edge_bwd<": 0,
     r"^void k_wgrad_t16<": 0,
     r"^void k_wgrad_q<": 0,
-    r"^void k_scalarize_bwd<Dims<196, 96>, 4, false>": 0,
+    r"^void k_scalarize_bwd<Dims<196, 96>, \d+, (true|false)>": 0,
     r"^void k_gcl_edge_b3<": 0,
     r"^void k_equi_edge_b3<Dims<196, 96>, false>": 0,
     r"^void k_equi_edge_b3<Dims<196, 96>, true>": 20,        # the optional split-precision TRAINING-mode forward (tape stores)
