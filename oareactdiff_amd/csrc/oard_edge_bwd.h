@@ -371,24 +371,44 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_bwd(TopoDev tp, const 
 
 // =====================================================================================================
 // dP[n] = sum of dz1 over the edges whose SOURCE is n, dQ[n] = over the edges whose TARGET is n (the node terms
-// P[src] + Q[tgt] of edge_mlp.0 were hoisted to the nodes in the forward).  One 64-thread block per node, one
-// float4 of the row per thread, fixed summation order.
+// P[src] + Q[tgt] of edge_mlp.0 were hoisted to the nodes in the forward).  One 256-thread block per node: wave w takes
+// the list entries k = w (mod 4) of both lists, one float4 of the row per lane, four rows in flight per wave; the four
+// partial sums are added in wave order (fixed summation order).  Round 4: was one wave per node walking both lists
+// (index load -> row load, 2 (ns - 1) dependent round trips): 118 -> see profiles us per layer at B = 64.
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_edge_node_sums(TopoDev tp, const float* __restrict__ dz1, int HP,
-                                                       float* __restrict__ dP, float* __restrict__ dQ) {
-    const int n = blockIdx.x, f = threadIdx.x * 4;
-    if (f >= HP) return;
+__global__ __launch_bounds__(256) void k_edge_node_sums(TopoDev tp, const float* __restrict__ dz1, int HP,
+                                                        float* __restrict__ dP, float* __restrict__ dQ) {
+    __shared__ f4 part[3][2][64];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, f = lane * 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool on = f < HP;
     const int smp = tp.node_sample[n], s0 = tp.sample_ptr[smp], ns = tp.sample_ptr[smp + 1] - s0, self = n - s0;
     f4 ap = f4zero(), aq = f4zero();
     const int e0 = tp.edge_ptr[n];
-    for (int k = 0; k < ns - 1; ++k) ap += ld_f4(dz1 + (size_t)tp.edge_row[e0 + k] * HP + f);
-    for (int k = 0; k < ns; ++k) {
-        if (k == self) continue;
-        const int row = tp.edge_row[tp.edge_ptr[s0 + k] + self - (self > k ? 1 : 0)];
-        aq += ld_f4(dz1 + (size_t)row * HP + f);
+    const float* col = dz1 + (on ? f : 0);
+    // list position j (0 .. ns - 2) of the target list is sample member k = j + (j >= self); n's own position in that member's list
+    auto qrow = [&](int j) { const int k = j + (j >= self ? 1 : 0); return tp.edge_row[tp.edge_ptr[s0 + k] + self - (self > k ? 1 : 0)]; };
+    int j = wave;
+    for (; j + 12 < ns - 1; j += 16) {
+        const int r0 = tp.edge_row[e0 + j], r1 = tp.edge_row[e0 + j + 4], r2 = tp.edge_row[e0 + j + 8], r3 = tp.edge_row[e0 + j + 12];
+        const int q0 = qrow(j), q1 = qrow(j + 4), q2 = qrow(j + 8), q3 = qrow(j + 12);
+        const f4 a0 = ld_f4(col + (size_t)r0 * HP), a1 = ld_f4(col + (size_t)r1 * HP), a2 = ld_f4(col + (size_t)r2 * HP), a3 = ld_f4(col + (size_t)r3 * HP);
+        const f4 b0 = ld_f4(col + (size_t)q0 * HP), b1 = ld_f4(col + (size_t)q1 * HP), b2 = ld_f4(col + (size_t)q2 * HP), b3 = ld_f4(col + (size_t)q3 * HP);
+        ap += (a0 + a1) + (a2 + a3);
+        aq += (b0 + b1) + (b2 + b3);
     }
-    st_f4(dP + (size_t)n * HP + f, ap);
-    st_f4(dQ + (size_t)n * HP + f, aq);
+    for (; j < ns - 1; j += 4) {
+        ap += ld_f4(col + (size_t)tp.edge_row[e0 + j] * HP);
+        aq += ld_f4(col + (size_t)qrow(j) * HP);
+    }
+    if (wave > 0) { part[wave - 1][0][lane] = ap; part[wave - 1][1][lane] = aq; }
+    __syncthreads();
+    if (wave == 0 && on) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { ap += part[w][0][lane]; aq += part[w][1][lane]; }
+        st_f4(dP + (size_t)n * HP + f, ap);
+        st_f4(dQ + (size_t)n * HP + f, aq);
+    }
 }
 
 // =====================================================================================================

@@ -1434,7 +1434,7 @@ int oard_edge_node_sums(const oard_config* c, const oard_topology* topo, const f
     const TopoDev& tp = topo->parts[0].d;
     const RDims d(c->hidden, c->num_radial);
     if (d.HP > 256) return OARD_EINVAL;
-    LAUNCH(F_GCL_BWD, k_edge_node_sums, tp.N, 64, (hipStream_t)stream, tp, dz1, d.HP, dP, dQ);
+    LAUNCH(F_GCL_BWD, k_edge_node_sums, tp.N, 256, (hipStream_t)stream, tp, dz1, d.HP, dP, dQ);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
 }

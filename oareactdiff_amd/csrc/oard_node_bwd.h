@@ -228,12 +228,17 @@ __global__ __launch_bounds__(WAVES * 64, OARD_SCAL_BWD_MINW) void k_scalarize_bw
 // registers and nothing is scattered with atomics.  The [A, 3H]-sized gather / product / scatter chain this replaces is
 // what an eager formulation spends most of its node-stage time on.
 // =====================================================================================================
-struct Strided3 {            // element (row, k, ch) of a [rows][3][channels] tensor with arbitrary strides
+struct Strided3 {            // element (row, k, ch) of a [rows][3][channels] tensor with arbitrary strides (multiples of 4 floats)
     const float* p;
     int row, comp;
     OARD_DEV float at(size_t r, int k, int ch) const { return p[r * (size_t)row + (size_t)k * comp + ch]; }
+    OARD_DEV f4 at4(size_t r, int k, int ch) const { return ld_f4(p + r * (size_t)row + (size_t)k * comp + ch); }
 };
 
+// Round 4 (second version): four channels per lane (float4 accesses: 49 lanes cover H = 196), the four waves of the workgroup take
+// the group members j = wave (mod 4), both roles of a member in one iteration with all 22 float4 operands requested before the
+// first use; the waves' partial sums of d xq[n] / d vec[n] are added in wave order.  Was: one channel per thread (the fourth wave
+// of a node held 4 channels), one role at a time, 2 (ng - 1) dependent round trips per thread: 307 us per layer at B = 64.
 template <class D>
 __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* __restrict__ geo, Strided3 xq, Strided3 vec,
                                                       const float* __restrict__ cd, Strided3 cr, const float* __restrict__ gX,
@@ -241,86 +246,95 @@ __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* _
                                                       float* __restrict__ dxq, float* __restrict__ dvec, int o_comp, int xcross) {
     // xcross: reflect_equiv = False (the message's x (x) coord_cross term, leftnet.py:268-272)
     // outputs d xq / d vec: [N][3][o_comp] (o_comp = H: dense; o_comp = HP: padded, the pads are written as zeros)
-    const int n = blockIdx.x, ch = threadIdx.x;
-    if (ch >= D::H) {
-        if (ch < o_comp) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { dxq[((size_t)n * 3 + k) * o_comp + ch] = 0.f; dvec[((size_t)n * 3 + k) * o_comp + ch] = 0.f; }
-            // padded mode: the per-edge gradients feed an MFMA kernel next (W^T rows of the pads are zero, but 0 x NaN is NaN)
-            const int qg = tp.node_sample[n] * tp.n_obj + tp.node_obj[n];
-            const int p0 = tp.grp_ptr[qg], pn = tp.grp_ptr[qg + 1] - p0, me = n - p0;
-            for (int kk = 0; kk < pn; ++kk) {
-                if (kk == me) continue;
-                const size_t a = (size_t)tp.act_ptr[n] + kk - (kk > me ? 1 : 0);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    dcd[a * (size_t)(3 * D::HP) + (size_t)k * D::HP + ch] = 0.f;
-                    dcr[a * (size_t)(3 * D::HP) + (size_t)k * D::HP + ch] = 0.f;
-                }
-            }
-        }
-        return;
-    }
+    static_assert(D::H % 4 == 0 && D::HP % 4 == 0 && D::HP <= 256, "four channels per lane, one wave per row");
+    __shared__ f4 part[3][6][64];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, ch = 4 * lane;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool real = ch < D::H, pad = !real && ch < o_comp;
     const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt_h = 1.0f / sqrtf((float)D::H);
     const int q_grp = tp.node_sample[n] * tp.n_obj + tp.node_obj[n];
     const int g0 = tp.grp_ptr[q_grp], ng = tp.grp_ptr[q_grp + 1] - g0, self = n - g0;
     const int a_n = tp.act_ptr[n];
-    const float xn[3] = {xq.at(n, 0, ch), xq.at(n, 1, ch), xq.at(n, 2, ch)};
-    const float wn[3] = {vec.at(n, 0, ch), vec.at(n, 1, ch), vec.at(n, 2, ch)};
-    const float gxn = gX[(size_t)n * gx_row + ch];
-    const float gvn[3] = {gV.at(n, 0, ch), gV.at(n, 1, ch), gV.at(n, 2, ch)};
-    float ax[3] = {0.f, 0.f, 0.f};                       // d xq[n]
-    float av[3] = {gvn[0], gvn[1], gvn[2]};              // d vec_in[n]: identity path of vec_a = vec_in + dvec
-    for (int kk = 0; kk < ng; ++kk) {
-        if (kk == self) continue;
-        const int m = g0 + kk;
-#pragma unroll
-        for (int role = 0; role < 2; ++role) {
-            // role 0: edge (m -> n), n is the target;  role 1: edge (n -> m), n is the source
-            const size_t a = role == 0 ? (size_t)a_n + kk - (kk > self ? 1 : 0) : (size_t)tp.act_ptr[m] + self - (self > kk ? 1 : 0);
-            const float* ge = geo + a * GEO_STRIDE;
-            const float u[3] = {ge[2], ge[3], ge[4]};
-            const float* cdr = cd + a * (size_t)(3 * D::HP) + ch;
-            const float c[3] = {cdr[0], cdr[D::HP], cdr[2 * D::HP]};
-            const float r[3] = {cr.at(a, 0, ch), cr.at(a, 1, ch), cr.at(a, 2, ch)};
-            // target-side quantities of this edge (the node itself in role 0, the partner in role 1)
-            float gx, gv[3], xt[3], xs_src[3], w[3];
-            if (role == 0) {
-                gx = gxn;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { gv[k] = gvn[k]; xt[k] = xn[k]; xs_src[k] = xq.at(m, k, ch); w[k] = vec.at(m, k, ch); }
-            } else {
-                gx = gX[(size_t)m * gx_row + ch];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { gv[k] = gV.at(m, k, ch); xt[k] = xq.at(m, k, ch); xs_src[k] = xn[k]; w[k] = wn[k]; }
-            }
-            const float q[3] = {c[0] * r[0], c[1] * r[1], c[2] * r[2]};
-            const float xs[3] = {xs_src[0] + xt[0], xs_src[1] + xt[1], xs_src[2] + xt[2]};
-            const float a2 = xs[1] * q[1] * inv_sqrt3;
-            const float ga2 = (gv[0] * w[0] + gv[1] * w[1] + gv[2] * w[2]) * inv_sqrt_h;
-            const float ga3 = (gv[0] * u[0] + gv[1] * u[1] + gv[2] * u[2]) * inv_sqrt_h;
-            // reflect_equiv = False: the vector message holds x (x) coord_cross as well - its cotangent joins the scalar message's
-            const float gxc = xcross ? gx + (gv[0] * ge[5] + gv[1] * ge[6] + gv[2] * ge[7]) * inv_sqrt_h : gx;
-            const float dm[3] = {gxc, ga2 * inv_sqrt3, ga3};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) ax[k] += dm[k] * q[k];             // d xs -> d xq of BOTH end points; this is n's share
-            if (role == 0) {
+    constexpr size_t ES = (size_t)3 * D::HP;              // row stride of cd / dcd / dcr
+    f4 ax[3] = {f4zero(), f4zero(), f4zero()};           // d xq[n]
+    f4 av[3] = {f4zero(), f4zero(), f4zero()};           // d vec_in[n]
+    if (real) {
+        const f4 xn[3] = {xq.at4(n, 0, ch), xq.at4(n, 1, ch), xq.at4(n, 2, ch)};
+        const f4 wn[3] = {vec.at4(n, 0, ch), vec.at4(n, 1, ch), vec.at4(n, 2, ch)};
+        const f4 gxn = ld_f4(gX + (size_t)n * gx_row + ch);
+        const f4 gvn[3] = {gV.at4(n, 0, ch), gV.at4(n, 1, ch), gV.at4(n, 2, ch)};
+        if (wave == 0) { av[0] = gvn[0]; av[1] = gvn[1]; av[2] = gvn[2]; }      // identity path of vec_a = vec_in + dvec
+        for (int j = wave; j < ng - 1; j += 4) {
+            const int kk = j + (j >= self ? 1 : 0), m = g0 + kk;
+            // edge t = (m -> n): n is the target;  edge s = (n -> m): n is the source
+            const size_t at = (size_t)a_n + j, as = (size_t)tp.act_ptr[m] + self - (self > kk ? 1 : 0);
+            const float* get = geo + at * GEO_STRIDE;
+            const float* ges = geo + as * GEO_STRIDE;
+            const float* cdt = cd + at * ES + ch;
+            const float* cds = cd + as * ES + ch;
+            const f4 ct[3] = {ld_f4(cdt), ld_f4(cdt + D::HP), ld_f4(cdt + 2 * D::HP)};
+            const f4 rt[3] = {cr.at4(at, 0, ch), cr.at4(at, 1, ch), cr.at4(at, 2, ch)};
+            const f4 cs[3] = {ld_f4(cds), ld_f4(cds + D::HP), ld_f4(cds + 2 * D::HP)};
+            const f4 rs[3] = {cr.at4(as, 0, ch), cr.at4(as, 1, ch), cr.at4(as, 2, ch)};
+            const f4 xm[3] = {xq.at4(m, 0, ch), xq.at4(m, 1, ch), xq.at4(m, 2, ch)};
+            const f4 wm[3] = {vec.at4(m, 0, ch), vec.at4(m, 1, ch), vec.at4(m, 2, ch)};
+            const f4 gxm = ld_f4(gX + (size_t)m * gx_row + ch);
+            const f4 gvm[3] = {gV.at4(m, 0, ch), gV.at4(m, 1, ch), gV.at4(m, 2, ch)};
+            const f4 xs[3] = {xm[0] + xn[0], xm[1] + xn[1], xm[2] + xn[2]};     // xq[source] + xq[target], the same for both edges
+            // ---- edge t: cotangents of the target n, source-side vectors of m ----
+            {
+                const f4 q[3] = {ct[0] * rt[0], ct[1] * rt[1], ct[2] * rt[2]};
+                const f4 ga2 = (gvn[0] * wm[0] + gvn[1] * wm[1] + gvn[2] * wm[2]) * inv_sqrt_h;
+                const f4 ga3 = (gvn[0] * get[2] + gvn[1] * get[3] + gvn[2] * get[4]) * inv_sqrt_h;
+                // reflect_equiv = False: the vector message holds x (x) coord_cross as well - its cotangent joins the scalar message's
+                const f4 gxc = xcross ? gxn + (gvn[0] * get[5] + gvn[1] * get[6] + gvn[2] * get[7]) * inv_sqrt_h : gxn;
+                const f4 dm[3] = {gxc, ga2 * inv_sqrt3, ga3};
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float dq = dm[k] * xs[k];
-                    dcd[a * (size_t)(3 * D::HP) + (size_t)k * D::HP + ch] = dq * r[k];
-                    dcr[a * (size_t)(3 * D::HP) + (size_t)k * D::HP + ch] = dq * c[k];
+                    ax[k] += dm[k] * q[k];                                      // d xs -> d xq of BOTH end points; this is n's share
+                    const f4 dq = dm[k] * xs[k];
+                    st_f4(dcd + at * ES + (size_t)k * D::HP + ch, dq * rt[k]);
+                    st_f4(dcr + at * ES + (size_t)k * D::HP + ch, dq * ct[k]);
                 }
-            } else {
+            }
+            // ---- edge s: cotangents of the target m, source-side vectors of n ----
+            {
+                const f4 q[3] = {cs[0] * rs[0], cs[1] * rs[1], cs[2] * rs[2]};
+                const f4 a2 = xs[1] * q[1] * inv_sqrt3;
+                const f4 ga2 = (gvm[0] * wn[0] + gvm[1] * wn[1] + gvm[2] * wn[2]) * inv_sqrt_h;
+                const f4 ga3 = (gvm[0] * ges[2] + gvm[1] * ges[3] + gvm[2] * ges[4]) * inv_sqrt_h;
+                const f4 gxc = xcross ? gxm + (gvm[0] * ges[5] + gvm[1] * ges[6] + gvm[2] * ges[7]) * inv_sqrt_h : gxm;
+                ax[0] += gxc * q[0]; ax[1] += (ga2 * inv_sqrt3) * q[1]; ax[2] += ga3 * q[2];
 #pragma unroll
-                for (int x = 0; x < 3; ++x) av[x] += gv[x] * a2 * inv_sqrt_h;   // d vec[source = n]
+                for (int x = 0; x < 3; ++x) av[x] += gvm[x] * a2 * inv_sqrt_h;  // d vec[source = n]
+            }
+        }
+    } else if (pad) {
+        // padded mode: the per-edge gradients feed an MFMA kernel next (W^T rows of the pads are zero, but 0 x NaN is NaN)
+        for (int j = wave; j < ng - 1; j += 4) {
+            const size_t at = (size_t)a_n + j;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                st_f4(dcd + at * ES + (size_t)k * D::HP + ch, f4zero());
+                st_f4(dcr + at * ES + (size_t)k * D::HP + ch, f4zero());
             }
         }
     }
+    if (wave > 0) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        dxq[((size_t)n * 3 + k) * o_comp + ch] = ax[k];
-        dvec[((size_t)n * 3 + k) * o_comp + ch] = av[k];
+        for (int k = 0; k < 3; ++k) { part[wave - 1][k][lane] = ax[k]; part[wave - 1][3 + k][lane] = av[k]; }
+    }
+    __syncthreads();
+    if (wave == 0 && (real || pad)) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ax[k] += part[w][k][lane]; av[k] += part[w][3 + k][lane]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            st_f4(dxq + ((size_t)n * 3 + k) * o_comp + ch, ax[k]);
+            st_f4(dvec + ((size_t)n * 3 + k) * o_comp + ch, av[k]);
+        }
     }
 }
 

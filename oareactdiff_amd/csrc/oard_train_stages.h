@@ -476,7 +476,7 @@ static int tr_gcl_edge_bwd(const TrainCtx& x, int l, const float* dagg, float* d
     long long gate_rows = 0;
     float* gatep = (g_gate_fold && HP > H) ? x.f(x.w.gatep) : nullptr;
     TR_TRY(gcl_backward_impl<D>(x.c, tp, x.pb, x.bo.layer[l], l, x.tape, x.to, dagg, dew, dz3, mout, dz2, da, dz1, x.st, gatep, &gate_rows));
-    LAUNCH(F_GCL_BWD, k_edge_node_sums, N, 64, x.st, tp, (const float*)dz1, HP, dP, dQ);
+    LAUNCH(F_GCL_BWD, k_edge_node_sums, N, 256, x.st, tp, (const float*)dz1, HP, dP, dQ);
     x.fork();
     const long long rows3 = l == NL - 1 ? A : E;          // rows whose forward evaluated edge_out_trans
     TR_TRY(wg(x, dz3, WP, WP, W, W, W, mout, HP, HP, 0, H, H, H, rows3, x.g(g + 8), H, x.g(g + 9)));                               // edge_out_trans
