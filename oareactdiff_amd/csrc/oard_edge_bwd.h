@@ -369,6 +369,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_bwd(TopoDev tp, const 
     st_f4(grow + 16 * (WB - 1), pend);
 }
 
+// Workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD with its own L2.  Kernels with one workgroup per node that read rows
+// shared by the nodes of one group (both end points of an edge read the edge's row) want the nodes of a group on ONE XCD: the
+// workgroups of an XCD (b, b + 8, b + 16, ...) get runs of 32 consecutive node indices.  A bijection on [0, nblk); the last
+// nblk % 256 workgroups keep their index.
+#ifndef OARD_XCD_RUNS
+#define OARD_XCD_RUNS 1
+#endif
+OARD_DEV int xcd_run32(int b, int nblk) {
+    if (b >= (nblk & ~255)) return b;
+    const int x = b & 7, s = b >> 3;
+    return (((s >> 5) * 8 + x) << 5) + (s & 31);
+}
+
 // =====================================================================================================
 // dP[n] = sum of dz1 over the edges whose SOURCE is n, dQ[n] = over the edges whose TARGET is n (the node terms
 // P[src] + Q[tgt] of edge_mlp.0 were hoisted to the nodes in the forward).  One 256-thread block per node: wave w takes
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_bwd(TopoDev tp, const 
 __global__ __launch_bounds__(256) void k_edge_node_sums(TopoDev tp, const float* __restrict__ dz1, int HP,
                                                         float* __restrict__ dP, float* __restrict__ dQ) {
     __shared__ f4 part[3][2][64];
-    const int n = blockIdx.x, lane = threadIdx.x & 63, f = lane * 4;
+    const int n = OARD_XCD_RUNS ? xcd_run32(blockIdx.x, gridDim.x) : (int)blockIdx.x, lane = threadIdx.x & 63, f = lane * 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool on = f < HP;
     const int smp = tp.node_sample[n], s0 = tp.sample_ptr[smp], ns = tp.sample_ptr[smp + 1] - s0, self = n - s0;

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* _
     // outputs d xq / d vec: [N][3][o_comp] (o_comp = H: dense; o_comp = HP: padded, the pads are written as zeros)
     static_assert(D::H % 4 == 0 && D::HP % 4 == 0 && D::HP <= 256, "four channels per lane, one wave per row");
     __shared__ f4 part[3][6][64];
-    const int n = blockIdx.x, lane = threadIdx.x & 63, ch = 4 * lane;
+    const int n = OARD_XCD_RUNS ? xcd_run32(blockIdx.x, gridDim.x) : (int)blockIdx.x, lane = threadIdx.x & 63, ch = 4 * lane;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool real = ch < D::H, pad = !real && ch < o_comp;
     const float inv_sqrt3 = 0.57735026918962576f, inv_sqrt_h = 1.0f / sqrtf((float)D::H);
