@@ -1488,7 +1488,9 @@ int oard_lin3u_backward(const oard_config* c, const void* packed, int layer, con
 // ---- plan of the 16 x 16-tile kernel (oard_wgrad_t16.h): a pure function of the shape ------------------------------------------------
 struct WgtPlan { int ok, transposed, MT, NT, nPT, nQT, TM, TN, n_chunks, grid; long long rpc; };
 // kernel instantiations: (largest wave tile TM x TN, SiLU on the Q operand)
-#define OARD_WGT_INSTANCES X(6, 7, false) X(4, 7, true) X(4, 7, false) X(5, 7, true) X(5, 3, false)
+#ifndef OARD_WGT_INSTANCES
+#define OARD_WGT_INSTANCES X(6, 7, false) X(4, 7, true) X(4, 7, false) X(5, 7, true) X(5, 3, false) X(5, 5, true) X(6, 5, false)
+#endif
 static bool wgt_instance(int TM, int TN, bool silu) {
 #define X(tm_, tn_, s_) if (TM == tm_ && TN == tn_ && silu == s_) return true;
     OARD_WGT_INSTANCES
