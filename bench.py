@@ -184,7 +184,10 @@ def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
     """One training step = DDPMTrainer.training_step (loss, HIP backward, one all-reduce, adaptive clip, AdamW)."""
     from oareactdiff_amd import _capi
     from oareactdiff_amd.trainer import DDPMTrainer
-    tr = DDPMTrainer(dyn, timesteps=1000, norm_values=(1.0, 4.0, 10.0), scales=(1.0, 2.0, 1.0), pos_only=True)
+    # host_sync=False: the clip / skip decision and AdamW's scalars are taken on the device (oard_adamw_step_dev), so the timed steps
+    # contain no device -> host read; the returned info is fetched after the timed region.  OARD_BENCH_HOST_SYNC=1: the host decides.
+    tr = DDPMTrainer(dyn, timesteps=1000, norm_values=(1.0, 4.0, 10.0), scales=(1.0, 2.0, 1.0), pos_only=True,
+                     host_sync=bool(os.environ.get("OARD_BENCH_HOST_SYNC")))
     batches = [make_training_batch(B, nf, 4321 + k, dev) for k in range(2)]
     dyn.nan_check = "async"
     for i in range(warmup):
@@ -201,6 +204,7 @@ def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
         dist.barrier()
     dt = time.perf_counter() - t0
     out = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "batch_per_gpu": B, "loss": info["loss"],
+           "host_sync_in_step": bool(tr.host_sync),
            "grad_norm": info.get("grad_norm"), "trainable_parameters": int(tr.flat_grad.numel()),
            "all_reduce_bytes": int(tr.flat_grad.numel() * 4) if world > 1 else 0, "seconds": dt}
     # two more steps with per-family kernel timing on rank 0; EVERY rank runs them (each step holds a collective).  The timed
@@ -551,7 +555,9 @@ def main():
                                           f"AdamW amsgrad), LEFTNet H=196 R=96 L=6, B={B} reactions/GPU x 3 objects x {nf} atoms "
                                           f"(N={B * 3 * nf}, E={E}), pos_only training as train_ts1x.py",
                               "batch_per_gpu": B, "atoms_per_object": nf,
-                              "parallelism": f"dp{world} (one flat fp32 gradient bucket, one all-reduce per step)"},
+                              "parallelism": f"dp{world} (one flat fp32 gradient bucket, one all-reduce per step)",
+                              "launch": "host decides the clipping (one device -> host read per step)" if os.environ.get("OARD_BENCH_HOST_SYNC")
+                                        else "no host sync inside the step (clip / skip decision and AdamW scalars on the device)"},
                    "train_step": leg}
             if leg.get("tflops_whole_step"):
                 out["roofline"] = {"bound": "mfma", "kernel": "whole training step (forward + backward edge kernels' algorithmic FLOPs)",

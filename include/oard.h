@@ -397,6 +397,18 @@ int oard_adamw_step(float* param_dev, const float* grad_dev, float* exp_avg_dev,
                     int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, int amsgrad,
                     double grad_scale, oard_stream_t stream);
 
+/* The optimiser step WITHOUT a host round trip (round 4): the adaptive clipping decision of pl_trainer.py:391-418 (max_norm = 1.5 mean +
+ * 3 std of the last <= `capacity` gradient norms, utils/training_tools.py:6-23) taken by one device thread, then AdamW with the scalars it
+ * derived.  clip_state (device, doubles, 4 + capacity + 8 entries): [0] entries in the history, [1] optimiser steps taken so far, [2] steps
+ * skipped so far, [3] reserved, [4 ..) the history, newest first; the caller initialises [0 .. 4 + capacity) and may read it back at any time.
+ * grad_norm / flag (device, float): the gradient's 2-norm and the non-finite flag of the step (flag != 0 or a non-finite norm: the step is
+ * skipped - parameters, moments, history and step count untouched, [2] counts it).  clip = 0: no clipping (history untouched).
+ * out4 (device, float[4]): grad_norm, max_norm (NaN when not clipping / skipped), the clipping factor applied, 1 if skipped. */
+int oard_adamw_step_dev(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, float* max_exp_avg_sq_dev,
+                        int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int amsgrad, int clip,
+                        double* clip_state_dev, int capacity, const float* grad_norm_dev, const float* flag_dev, float* out4_dev,
+                        oard_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

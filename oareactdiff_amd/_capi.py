@@ -25,7 +25,7 @@ EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_by
            "oard_equi_backward_dx", "oard_scalarize_backward", "oard_equi_msg_backward", "oard_lin3u_forward", "oard_lin3u_backward", "oard_wgrad_scratch_bytes", "oard_wgrad",
            "oard_train_scratch_bytes", "oard_train_scratch_poison", "oard_train_scratch_entry", "oard_train_tail_backward",
            "oard_train_layer_backward", "oard_train_init_backward", "oard_train_stage_backward",
-           "oard_loss_prepare", "oard_loss_terms", "oard_adamw_step", "oard_nan_replace"]
+           "oard_loss_prepare", "oard_loss_terms", "oard_adamw_step", "oard_adamw_step_dev", "oard_nan_replace"]
 STAGE_RECOMPUTE, STAGE_UPDATE, STAGE_MESSAGE, STAGE_GCL_NODE, STAGE_NODE_PRE, STAGE_GCL_EDGE, STAGE_EQUI_EDGE = range(7)
 SCRATCH_XH, SCRATCH_XQ, SCRATCH_CR, SCRATCH_DCD, SCRATCH_DCR = range(1, 6)
 
@@ -124,6 +124,7 @@ def lib() -> C.CDLL:
     L.oard_loss_terms.argtypes = [cfgp, vp, pvp, pvp, pvp, pvp, pvp, vp, vp, ci, pf, pf, pf, ci, ci, vp, vp, pvp, vp]; L.oard_loss_terms.restype = ci
     cd = C.c_double
     L.oard_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, cd, cd, cd, cd, cd, i64, ci, cd, vp]; L.oard_adamw_step.restype = ci
+    L.oard_adamw_step_dev.argtypes = [vp, vp, vp, vp, vp, i64, cd, cd, cd, cd, cd, ci, ci, vp, ci, vp, vp, vp, vp]; L.oard_adamw_step_dev.restype = ci
     L.oard_debug_stop_after.argtypes = [C.c_int]; L.oard_debug_stop_after.restype = C.c_int
     L.oard_debug_option.argtypes = [C.c_char_p, C.c_int]; L.oard_debug_option.restype = C.c_int
     L.oard_timing_enable.argtypes = [C.c_int]; L.oard_timing_enable.restype = C.c_int

@@ -1883,6 +1883,20 @@ int oard_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
     return OARD_OK;
 }
 
+int oard_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq, int64_t n, double lr,
+                        double beta1, double beta2, double eps, double weight_decay, int amsgrad, int clip, double* clip_state,
+                        int capacity, const float* grad_norm, const float* flag, float* out4, oard_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || (amsgrad && !max_exp_avg_sq) || n < 0 || !clip_state || capacity < 1 || capacity > 64 ||
+        !grad_norm || !flag || !out4)
+        return OARD_EINVAL;
+    LAUNCH(F_OTHER, k_clip_decide, 1, 64, (hipStream_t)stream, clip_state, capacity, grad_norm, flag, clip, lr, beta1, beta2, eps, weight_decay, out4);
+    if (n > 0)
+        LAUNCH(F_OTHER, k_adamw_dev, cdiv(n, 256), 256, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, (long long)n, amsgrad,
+               reinterpret_cast<const AdamScal*>(clip_state + 4 + capacity));
+    HIP_TRY(hipGetLastError());
+    return OARD_OK;
+}
+
 // scratch buffers a test may want to look at (xq, cr, d cd, d cr of the last recompute / message stage)
 int oard_train_scratch_entry(const oard_config* c, const oard_topology* topo, int which, size_t* offset_bytes, int64_t* rows,
                              int64_t* row_floats) {

@@ -23,6 +23,7 @@ from __future__ import annotations
 import copy
 import math
 import os
+from collections.abc import Mapping
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -58,14 +59,53 @@ class Queue:
         return float(np.std(self.items))
 
 
+class LazyInfo(Mapping):
+    """What `training_step` returns with `host_sync=False`: the same keys as the eager dict (loss, skipped, grad_norm, max_grad_norm,
+    error_t_k, unorm_error_t_k), held as two small device tensors and copied to the host the first time any of them is read."""
+
+    def __init__(self, stats: Tensor, out4: Tensor, K: int, scales: List[float], clip: bool):
+        self._dev = (stats, out4)
+        self._K, self._scales, self._clip = K, scales, clip
+        self._d: Optional[Dict[str, float]] = None
+
+    def _get(self) -> Dict[str, float]:
+        if self._d is None:
+            stats, out4 = (t.tolist() for t in self._dev)
+            K, d = self._K, {}
+            for k in range(K):
+                d[f"error_t_{k}"] = stats[3 + k] / (self._scales[k] + 1e-4)
+                d[f"unorm_error_t_{k}"] = stats[3 + K + k]
+            if self._clip:
+                d["grad_norm"], d["max_grad_norm"] = out4[0], out4[1]
+            d["loss"] = stats[2]
+            d["skipped"] = int(out4[3] != 0)
+            self._d, self._dev = d, None
+        return self._d
+
+    def __getitem__(self, key):
+        return self._get()[key]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __len__(self):
+        return len(self._get())
+
+
 class DDPMTrainer:
     def __init__(self, dynamics: nn.Module, noise_schedule: str = "polynomial_2", timesteps: int = 1000,
                  precision: float = 1e-5, norm_values: Sequence[float] = (1.0, 1.0, 1.0),
                  norm_biases: Sequence[float] = (0.0, 0.0, 0.0), loss_type: str = "l2", pos_only: bool = False,
                  scales: Sequence[float] = (1.0, 1.0, 1.0), fixed_idx: Optional[List[int]] = None,
                  optimizer_config: Optional[Dict] = None, clip_grad: bool = True,
-                 process_group: Optional["dist.ProcessGroup"] = None, fused: Optional[bool] = None):
+                 process_group: Optional["dist.ProcessGroup"] = None, fused: Optional[bool] = None, host_sync: bool = True):
+        """`host_sync=False` (fused steps only): the adaptive-clipping decision, the skip decision and AdamW's step-dependent scalars
+        are evaluated on the device (`oard_adamw_step_dev`), so a training step contains NO device -> host read; `training_step`
+        then returns a `LazyInfo` whose values are fetched when they are first looked at.  Arithmetic and state are the same as with
+        `host_sync=True` (the clipping history is summed in numpy's order); the clipping / skip messages are not printed."""
         self.dynamics = dynamics
+        self.host_sync = bool(host_sync)
+        self._clip_state = None                        # device mirror of (history, opt_step, skipped_steps) while host_sync is off
         self.loss = DiffusionLoss(dynamics, noise_schedule, timesteps, precision, norm_values=norm_values,
                                   norm_biases=norm_biases, pos_only=pos_only, fixed_idx=fixed_idx, loss_type=loss_type,
                                   scales=scales)
@@ -101,6 +141,8 @@ class DDPMTrainer:
             raise ValueError("fused=True needs the HIP EGNNDynamics on a ROCm device, float32 parameters and loss_type='l2' "
                              f"(got loss_type={loss_type!r}, dtype={self.params[0].dtype}, device={self.params[0].device})")
         self.fused = can_fuse if fused is None else bool(fused)
+        if not self.host_sync and not self.fused:
+            raise ValueError("host_sync=False is a mode of the fused step (HIP EGNNDynamics on a ROCm device, l2 loss)")
         if self.fused:
             # the HIP module: (1) its backward accumulates straight into the .grad views of the bucket; (2) the parameters
             # themselves become views of ONE flat buffer, so that AdamW is a single kernel over it (oard_adamw_step) and
@@ -134,6 +176,7 @@ class DDPMTrainer:
         """Everything a bit-identical continuation of the training needs besides the module's own state_dict(): the optimiser state
         (fused: flat AdamW moments + step counter + the hyper-parameters of `optimizer.param_groups`; generic: torch's), the clipping
         history and the skipped-step counter."""
+        self._pull_clip_state()
         sd: Dict = {"fused": bool(self.fused), "names": list(self.names), "skipped_steps": int(self.skipped_steps),
                     "gradnorm_queue": list(self.gradnorm_queue.items) if self.clip_grad else None}
         if self.fused:
@@ -150,6 +193,7 @@ class DDPMTrainer:
             raise ValueError("trainer state belongs to a different parameter list")
         if bool(sd["fused"]) != bool(self.fused):
             raise ValueError(f"trainer state was saved with fused={sd['fused']}, this trainer runs fused={self.fused}")
+        self._clip_state = None                        # rebuilt from the host copies at the next sync-free step
         self.skipped_steps = int(sd["skipped_steps"])
         if self.clip_grad and sd.get("gradnorm_queue") is not None:
             self.gradnorm_queue.items = [float(x) for x in sd["gradnorm_queue"]]
@@ -162,6 +206,30 @@ class DDPMTrainer:
                     getattr(self, k).copy_(sd[k].to(self.flat_param.device))
         else:
             self.optimizer.load_state_dict(sd["optimizer"])
+
+    # ---- host_sync=False: history / step counter / skip counter live on the device between reads ------------------------------------------
+    CLIP_CAPACITY = 50                                 # utils/training_tools.py:9 (Queue(max_len=50))
+
+    def _push_clip_state(self) -> Tensor:
+        """Device copy of the host-side clipping history, optimiser step count and skip count (layout: include/oard.h, oard_adamw_step_dev)."""
+        cap = self.CLIP_CAPACITY
+        items = list(self.gradnorm_queue.items) if self.clip_grad else []
+        host = torch.zeros(4 + cap + 8, dtype=torch.float64)
+        host[0], host[1], host[2] = len(items), self.opt_step, self.skipped_steps
+        if items:
+            host[4: 4 + len(items)] = torch.tensor(items, dtype=torch.float64)
+        self._clip_state = host.to(self.flat_grad.device)
+        return self._clip_state
+
+    def _pull_clip_state(self) -> None:
+        """Refresh `gradnorm_queue`, `opt_step`, `skipped_steps` from the device (one host sync; no-op while host_sync is on)."""
+        if self._clip_state is None:
+            return
+        host = self._clip_state.cpu()
+        n = int(host[0])
+        self.opt_step, self.skipped_steps = int(host[1]), int(host[2])
+        if self.clip_grad:
+            self.gradnorm_queue.items = [float(x) for x in host[4: 4 + n].tolist()]
 
     # pl_trainer.py:208-282
     def compute_loss(self, batch, training: bool = True, **kw) -> Tuple[Tensor, Dict[str, float]]:
@@ -308,6 +376,25 @@ class DDPMTrainer:
         if self.collectives:
             self.all_reduce_gradients()
             norm = torch.linalg.vector_norm(self.flat_grad, 2.0)
+        if not self.host_sync:
+            # no host read: one device thread takes the clip / skip decision, AdamW reads its scalars from device memory
+            stats_dev = torch.cat([norm.reshape(1), self._bucket[-1:], means])
+            state = self._clip_state if self._clip_state is not None else self._push_clip_state()
+            out4 = torch.empty(4, dtype=torch.float32, device=stats_dev.device)
+            o = self.optimizer.param_groups[0]
+            stream = torch.cuda.current_stream(self.flat_grad.device).cuda_stream
+            with torch.cuda.device(self.flat_grad.device):
+                _capi.check(_capi.lib().oard_adamw_step_dev(
+                    self.flat_param.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                    self.max_exp_avg_sq.data_ptr(), self.flat_param.numel(), float(o["lr"]), float(o["betas"][0]), float(o["betas"][1]),
+                    float(o.get("eps", 1e-8)), float(o.get("weight_decay", 0.0)), 1 if o.get("amsgrad", False) else 0,
+                    1 if self.clip_grad else 0, state.data_ptr(), self.CLIP_CAPACITY, stats_dev.data_ptr(),
+                    stats_dev.data_ptr() + 4, out4.data_ptr(), stream), "oard_adamw_step_dev")
+            dyn._packed_key = dyn._packed_bwd_key = None      # the weights changed (unless the step was skipped: repacking is harmless)
+            return LazyInfo(stats_dev, out4, K, [float(x) for x in self.loss.scales], self.clip_grad)
+        if self._clip_state is not None:               # host_sync was switched on again: the host copies become the truth
+            self._pull_clip_state()
+            self._clip_state = None
         stats = torch.cat([norm.reshape(1), self._bucket[-1:], means]).tolist()        # the one host sync
         grad_norm, flag = stats[0], stats[1]
         info: Dict[str, float] = {}

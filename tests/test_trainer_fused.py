@@ -11,13 +11,13 @@ from _grad_cases import CNF, NODE_NFS, GradCase
 pytestmark = pytest.mark.gpu
 
 
-def _trainer(c, dev, fused, pos_only):
+def _trainer(c, dev, fused, pos_only, **kw):
     from oareactdiff_amd.dynamics import EGNNDynamics
     from oareactdiff_amd.trainer import DDPMTrainer
     dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=NODE_NFS, edge_nf=0, condition_nf=CNF, device=dev)
     dyn.load_state_dict(c.state_dict(), strict=True)
     return DDPMTrainer(dyn, timesteps=c.meta["T"], norm_values=c.meta["norm_values"], scales=(1.0, 2.0, 1.0), pos_only=pos_only,
-                       fused=fused)
+                       fused=fused, **kw)
 
 
 @pytest.mark.parametrize("name,pos_only", [("g9_grad_prod_l2", False), ("g9_grad_h32", True), ("g9_grad_prod_n23", True)])
@@ -192,6 +192,55 @@ def test_fused_step_follows_optimizer_param_groups_and_resumes_from_state_dict()
     assert rest_a == rest_b and torch.equal(a.flat_param, b.flat_param)
     assert torch.equal(a.exp_avg_sq, b.exp_avg_sq) and a.opt_step == b.opt_step == 5
     assert a.gradnorm_queue.items == b.gradnorm_queue.items
+
+
+def test_step_without_host_sync_takes_the_same_decisions():
+    """`host_sync=False` (round 4): the clipping decision (pl_trainer.py:391-418: 1.5 mean + 3 std of the last <= 50 norms), the skip
+    decision and AdamW's step-dependent scalars on the device, no device -> host read inside the step.  Against the host-side
+    decision over eight steps that contain clipped steps (a small history with more than 8 entries: numpy's pairwise summation
+    order), unclipped steps and a skipped step (a NaN position): same losses, same history, same counters, same weights."""
+    from oareactdiff_amd.trainer import LazyInfo
+    c = GradCase("g9_grad_h32")
+    dev = torch.device("cuda:0")
+    B = len(c.meta["sizes"])
+    good = (c.reps(torch.float32, dev), torch.zeros(B, 1, device=dev))
+    bad_reps = c.reps(torch.float32, dev)
+    bad_reps[0]["pos"] = bad_reps[0]["pos"].clone()
+    bad_reps[0]["pos"][0, 0] = float("nan")
+    bad = (bad_reps, torch.zeros(B, 1, device=dev))
+    hist = [3e-3 * (1 + 0.1 * k) for k in range(11)]          # far below the real norms: the first steps clip and push max_norm
+
+    def run(host_sync):
+        tr = _trainer(c, dev, True, True, host_sync=host_sync)
+        tr.gradnorm_queue.items = list(hist)
+        infos = []
+        for k in range(8):
+            torch.manual_seed(50 + k)
+            infos.append(tr.training_step(bad if k == 4 else good))
+            if k == 2:                                         # a large entry: the following steps are not clipped
+                if host_sync:
+                    tr.gradnorm_queue.items.insert(0, 1e6)
+                else:
+                    tr._pull_clip_state(); tr.gradnorm_queue.items.insert(0, 1e6); tr._clip_state = None
+        return tr, infos
+    a, ia = run(True)
+    b, ib = run(False)
+    assert all(isinstance(i, LazyInfo) for i in ib) and all(isinstance(i, dict) for i in ia)
+    sa, sb = a.state_dict(), b.state_dict()                    # pulls the device-side history and counters
+    assert [i["skipped"] for i in ia] == [i["skipped"] for i in ib] == [0, 0, 0, 0, 1, 0, 0, 0]
+    assert [i["loss"] for i in ia if i["skipped"] == 0] == [i["loss"] for i in ib if i["skipped"] == 0]
+    clipped = [i["grad_norm"] > i["max_grad_norm"] for i in ia if i["skipped"] == 0]
+    assert any(clipped) and not all(clipped), clipped
+    for x, y in zip(ia, ib):
+        assert set(x) == set(y)
+        if not x["skipped"]:
+            assert x["grad_norm"] == y["grad_norm"] and abs(x["max_grad_norm"] - y["max_grad_norm"]) <= 1e-6 * abs(x["max_grad_norm"])
+    assert sa["opt_step"] == sb["opt_step"] == 7 and sa["skipped_steps"] == sb["skipped_steps"] == 1
+    assert sa["gradnorm_queue"] == sb["gradnorm_queue"], (sa["gradnorm_queue"][:3], sb["gradnorm_queue"][:3])
+    d = float((a.flat_param - b.flat_param).abs().max())
+    print(f"host decision vs device decision after 8 steps: max |dw| = {d:.3e} (identical: {torch.equal(a.flat_param, b.flat_param)})")
+    assert torch.allclose(a.flat_param, b.flat_param, rtol=1e-6, atol=1e-9)
+    assert torch.allclose(a.max_exp_avg_sq, b.max_exp_avg_sq, rtol=1e-6, atol=1e-12)
 
 
 def test_fused_true_is_refused_where_the_fused_kernels_do_not_apply():

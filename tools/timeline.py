@@ -53,6 +53,24 @@ def main():
     print("time with exactly ONE kernel in flight, by kernel:")
     for n, v in sorted(fam_alone.items(), key=lambda kv: -kv[1])[:12]:
         print(f"  {n:40s} {v / 1e6:8.3f} ms")
+    # idle gaps (nothing in flight): total by the kernel that ends the gap, and the longest ones
+    gaps = defaultdict(lambda: [0, 0.0])
+    longest = []
+    k = 0
+    gap_start = None
+    for t, d, n in ev:
+        if d == 1 and k == 0 and gap_start is not None:
+            g_ = t - gap_start
+            gaps[n][0] += 1
+            gaps[n][1] += g_
+            longest.append((g_, n))
+        k += d
+        if k == 0:
+            gap_start = t
+    print("idle gaps by the kernel that ends them: count, total ms, avg us")
+    for n, (cnt, tot) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:16]:
+        print(f"  {n:40s} {cnt:6d} {tot / 1e6:8.3f} {tot / cnt / 1e3:8.1f}")
+    print("longest gaps (us):", ", ".join(f"{g_ / 1e3:.0f} before {n}" for g_, n in sorted(longest, reverse=True)[:10]))
     agg = defaultdict(list)
     for n, a, b, q in rows:
         agg[n].append((b - a) / 1e3)
