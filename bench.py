@@ -151,7 +151,10 @@ def pmc_traffic(kernel: str, prefix: str = None, tag: str = None):
 
 def make_training_batch(B: int, n_atoms: int, seed: int, dev):
     """Synthetic Transition1x-shaped batch in the layout of dataset/base_dataset.py:55-88:
-    per object {size [B], pos [n,3], one_hot [n,5] int64, charge [n,1] int64, mask [n]} + conditions [B,1]."""
+    per object {size [B], pos [n,3], one_hot [n,5] int64, charge [n,1] int64, mask [n]} + conditions [B,1], built on the host like a
+    collate function does and moved to the device by DDPMTrainer.to_device (which keeps the host copies of mask / size beside the
+    device tensors, so a new batch layout costs the step no device -> host copy)."""
+    from oareactdiff_amd.trainer import DDPMTrainer
     g = torch.Generator().manual_seed(seed)
     reps = []
     size = torch.full((B,), n_atoms, dtype=torch.long)
@@ -164,9 +167,8 @@ def make_training_batch(B: int, n_atoms: int, seed: int, dev):
         one_hot = torch.zeros(n, 5, dtype=torch.long)
         one_hot[torch.arange(n), typ] = 1
         charge = torch.tensor([1, 6, 7, 8])[typ].view(n, 1)
-        reps.append({"size": size.to(dev), "pos": pos.to(dev), "one_hot": one_hot.to(dev), "charge": charge.to(dev),
-                     "mask": mask.to(dev)})
-    return reps, torch.zeros(B, 1, device=dev)
+        reps.append({"size": size.clone(), "pos": pos, "one_hot": one_hot, "charge": charge, "mask": mask.clone()})
+    return DDPMTrainer.to_device((reps, torch.zeros(B, 1)), dev, non_blocking=False)
 
 
 def edge_counts(B, nf):
@@ -188,23 +190,26 @@ def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
     # contain no device -> host read; the returned info is fetched after the timed region.  OARD_BENCH_HOST_SYNC=1: the host decides.
     tr = DDPMTrainer(dyn, timesteps=1000, norm_values=(1.0, 4.0, 10.0), scales=(1.0, 2.0, 1.0), pos_only=True,
                      host_sync=bool(os.environ.get("OARD_BENCH_HOST_SYNC")))
-    batches = [make_training_batch(B, nf, 4321 + k, dev) for k in range(2)]
+    # every step a batch the trainer has never seen (new tensors: its layout caches miss, a topology is built and dropped per step), as in
+    # a real run over a dataset; OARD_BENCH_CACHED_BATCHES=1: two alternating batches whose layouts stay cached (rounds 2-3 measured that)
+    n_b = 2 if os.environ.get("OARD_BENCH_CACHED_BATCHES") else warmup + steps
+    batches = [make_training_batch(B, nf, 4321 + k, dev) for k in range(n_b)]
     dyn.nan_check = "async"
     for i in range(warmup):
-        info = tr.training_step(batches[i % 2])
+        info = tr.training_step(batches[i % n_b])
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(steps):
-        info = tr.training_step(batches[i % 2])
+        info = tr.training_step(batches[(warmup + i) % n_b])
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     out = {"ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "batch_per_gpu": B, "loss": info["loss"],
-           "host_sync_in_step": bool(tr.host_sync),
+           "host_sync_in_step": bool(tr.host_sync), "new_batch_layout_every_step": n_b > 2,
            "grad_norm": info.get("grad_norm"), "trainable_parameters": int(tr.flat_grad.numel()),
            "all_reduce_bytes": int(tr.flat_grad.numel() * 4) if world > 1 else 0, "seconds": dt}
     # two more steps with per-family kernel timing on rank 0; EVERY rank runs them (each step holds a collective).  The timed

@@ -83,7 +83,8 @@ struct TopoDev {
 #define OARD_MAX_PARTS 8
 struct TopoPart {
     TopoDev d;
-    void* dev_block = nullptr;     // one allocation holding every table of this part
+    void* dev_block = nullptr;     // one allocation holding every table of this part (from the table pool, oard_hip.hip)
+    size_t dev_cap = 0;            // its capacity in the pool
     size_t ws_off = 0;             // byte offset of this part's slice of the workspace
     int conc = 1;                  // sub-batches of this topology that run concurrently (launch-shape heuristics)
     mutable size_t vec_final = 0;  // workspace offset (within the slice) of the vec buffer holding the final state
@@ -100,6 +101,12 @@ struct oard_topology {
     // reference-order tables (whole batch) for oard_topology_check_edge_index: dense sample id, rank of the node inside its sample,
     // first reference-order edge id of the node
     void* ref_block = nullptr;
+    size_t ref_cap = 0;
+    // streams that have been given work reading this topology's tables (noted by the entry points): oard_topology_destroy records an
+    // event on each and the table pool hands the blocks out again only after those events have fired - no hipFree (a device-wide sync)
+    mutable hipStream_t used_on[4] = {};
+    mutable int n_used = 0;
+    mutable bool used_many = false;    // more than 4 distinct streams: destroy falls back to a device synchronisation
     const int *ref_sample = nullptr, *ref_rank = nullptr;
     const long long* ref_ptr = nullptr;
     int N_ref = 0;

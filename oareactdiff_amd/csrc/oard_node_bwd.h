@@ -243,7 +243,8 @@ template <class D>
 __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* __restrict__ geo, Strided3 xq, Strided3 vec,
                                                       const float* __restrict__ cd, Strided3 cr, const float* __restrict__ gX,
                                                       int gx_row, Strided3 gV, float* __restrict__ dcd, float* __restrict__ dcr,
-                                                      float* __restrict__ dxq, float* __restrict__ dvec, int o_comp, int xcross) {
+                                                      float* __restrict__ dxq, float* __restrict__ dvec, int o_comp, int xcross, int zero_spare = 0) {
+    // zero_spare: dcd / dcr have a spare row A (padding columns of the consumer's last MFMA tile read it): written as zeros here
     // xcross: reflect_equiv = False (the message's x (x) coord_cross term, leftnet.py:268-272)
     // outputs d xq / d vec: [N][3][o_comp] (o_comp = H: dense; o_comp = HP: padded, the pads are written as zeros)
     static_assert(D::H % 4 == 0 && D::HP % 4 == 0 && D::HP <= 256, "four channels per lane, one wave per row");
@@ -256,6 +257,8 @@ __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* _
     const int g0 = tp.grp_ptr[q_grp], ng = tp.grp_ptr[q_grp + 1] - g0, self = n - g0;
     const int a_n = tp.act_ptr[n];
     constexpr size_t ES = (size_t)3 * D::HP;              // row stride of cd / dcd / dcr
+    if (zero_spare && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < (int)ES; i += 256) { dcd[(size_t)tp.A * ES + i] = 0.f; dcr[(size_t)tp.A * ES + i] = 0.f; }
     f4 ax[3] = {f4zero(), f4zero(), f4zero()};           // d xq[n]
     f4 av[3] = {f4zero(), f4zero(), f4zero()};           // d vec_in[n]
     if (real) {

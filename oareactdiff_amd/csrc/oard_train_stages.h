@@ -396,12 +396,10 @@ static int tr_msg_bwd(const TrainCtx& x, int l, const float* gs_a, const float* 
     const int N = tp.N, HP = D::HP, H = D::H;
     { ScopedLaunch sl_(F_NODE, x.st);
       hipLaunchKernelGGL(k_scale_rows, EW_GRID((long long)N * HP), 0, x.st, gs_a, 0.70710678118654752f, (long long)N * HP, gx); }
-    // spare row A of the per-edge gradients (padding columns of the last MFMA tile read it)
-    HIP_TRY(hipMemsetAsync(x.f(x.w.dcd) + (size_t)tp.A * 3 * HP, 0, (size_t)3 * HP * sizeof(float), x.st));
-    HIP_TRY(hipMemsetAsync(x.f(x.w.dcr) + (size_t)tp.A * 3 * HP, 0, (size_t)3 * HP * sizeof(float), x.st));
+    // (spare row A of the per-edge gradients - padding columns of the consumer's last MFMA tile read it - is zeroed by the kernel)
     const Strided3 xq3{x.f(x.w.xq), 3 * HP, HP}, vec3{x.t(x.to.vec_in[l]), 3 * HP, HP}, cr3{x.f(x.w.cr), 3 * HP, HP}, gv3{gvec_a, 3 * HP, HP};
     LAUNCH(F_NODE, (k_equi_msg_bwd<D>), N, 256, x.st, tp, x.t(x.to.geo), xq3, vec3, x.t(x.to.cd[l]), cr3, (const float*)gx, HP, gv3,
-           x.f(x.w.dcd), x.f(x.w.dcr), dxq, dvec_in, HP, x.c->reflect_equiv ? 0 : 1);
+           x.f(x.w.dcd), x.f(x.w.dcr), dxq, dvec_in, HP, x.c->reflect_equiv ? 0 : 1, 1);
     const int m = x.pi.msg0 + 9 * l;
     x.fork();
     TR_TRY(wg(x, x.f(x.w.dcr), 3 * HP, 3 * HP, H, HP, 3 * H, x.t(x.to.rbuf), D::RP, D::RP, 0, D::R, D::R, D::R, tp.A, x.g(m + 6), D::R, nullptr));

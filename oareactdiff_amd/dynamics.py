@@ -387,18 +387,21 @@ class EGNNDynamics(nn.Module):
             raise _capi.OardError("t has fewer rows than samples")
         return tt.reshape(-1).contiguous(), 0
 
-    def _get_train_topology(self, cfg, edge_index: Tensor, n_frag_switch: Tensor, combined_mask: Tensor, stream: int):
-        """One (single sub-batch) topology per layout, edge_index verified on it when it is built.  Cached like the inference
-        topologies, by the identity of the three tensors: a loader that reuses its batch tensors (bench.py, fixed-size batches
-        through DiffusionLoss's layout cache) pays the host copy of the masks, the table uploads and the one `ok.item()` of the
-        edge_index check once, not every step."""
+    def _get_train_topology(self, cfg, edge_index: Optional[Tensor], n_frag_switch: Tensor, combined_mask: Tensor, stream: int,
+                            device=None):
+        """One (single sub-batch) topology per layout.  `edge_index` given: verified against the implicit complete graph when the
+        topology is built (one host read); `None` (DDPMTrainer's fused step, which never materialises an edge list): nothing to
+        verify.  `combined_mask` / `n_frag_switch` may be host tensors (`device` = the GPU).  Cached by the identity of the tensors:
+        a loader that reuses its batch tensors pays the table build once; a new layout costs ~1.5 ms of host time and no device
+        synchronisation (training.TrainTopology)."""
         from . import training
-        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
+        key = (0 if edge_index is None else edge_index.data_ptr(), 0 if edge_index is None else edge_index._version,
+               () if edge_index is None else tuple(edge_index.shape),
                n_frag_switch.data_ptr(), n_frag_switch._version, combined_mask.data_ptr(), combined_mask._version,
                combined_mask.numel())
         topo = self._train_topo_cache.get(key)
         if topo is None:
-            topo = training.TrainTopology(cfg, combined_mask, n_frag_switch, stream, edge_index=edge_index)
+            topo = training.TrainTopology(cfg, combined_mask, n_frag_switch, stream, edge_index=edge_index, device=device)
             topo.key_tensors = (edge_index, n_frag_switch, combined_mask)       # keep the addresses of the key alive
             self._train_topo_cache[key] = topo
             while len(self._train_topo_cache) > 4:
@@ -426,7 +429,7 @@ class EGNNDynamics(nn.Module):
         return xs, tt, t_scalar, cond
 
     def _run_forward_train(self, cfg, topo, packed: Tensor, xs: List[Tensor], tt: Tensor, t_scalar: int, cond: Optional[Tensor],
-                           stream: int):
+                           stream: int, reuse_tape: bool = False):
         """oard_forward_train on prepared inputs -> (outs, TrainState); no autograd involved (DDPMTrainer's fused step calls this
         directly and feeds the closed-form loss gradient to training.backward_sweep)."""
         from . import training
@@ -437,8 +440,18 @@ class EGNNDynamics(nn.Module):
         need = L.oard_workspace_bytes(C.byref(cfg), topo.handle)
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        # one tape per call (it lives until that call's backward has run; the caching allocator recycles it)
-        tape = torch.empty(L.oard_tape_bytes(C.byref(cfg), topo.handle), dtype=torch.uint8, device=dev)
+        # one tape per call (it lives until that call's backward has run; the caching allocator recycles it).  reuse_tape (the fused
+        # trainer: one forward, then its backward, on one stream): ONE grow-only buffer - batch layouts of changing size would otherwise
+        # have the allocator carve multi-GB blocks of ever new sizes
+        tape_bytes = L.oard_tape_bytes(C.byref(cfg), topo.handle)
+        if reuse_tape:
+            tb = getattr(self, "_tape_buf", None)
+            if tb is None or tb.numel() < tape_bytes or tb.device != dev:
+                self._tape_buf = None
+                tb = self._tape_buf = torch.empty(tape_bytes + tape_bytes // 8, dtype=torch.uint8, device=dev)
+            tape = tb[:tape_bytes]
+        else:
+            tape = torch.empty(tape_bytes, dtype=torch.uint8, device=dev)
         status = torch.zeros(2, dtype=torch.int32, device=dev)
         xp = (C.c_void_p * n_obj)(*[x.data_ptr() for x in xs])
         op = (C.c_void_p * n_obj)(*[o.data_ptr() for o in outs])

@@ -52,17 +52,18 @@ class DiffusionLoss:
         self.node_nfs = list(getattr(dynamics, "node_nfs", node_nfs or []))
         self._layouts: "OrderedDict[tuple, tuple]" = OrderedDict()
 
-    def _layout(self, masks: List[Tensor], sizes: List[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    def _layout(self, masks: List[Tensor], sizes: List[Tensor], need_edges: bool = True) -> Tuple[Tensor, Optional[Tensor], Tensor]:
         """(combined_mask, edge_index, n_frag_switch) of a batch (en_diffusion.py:75-83), cached by the identity of the batch's
         `mask` / `size` tensors: a loader that hands the same tensors again (fixed-size batches) gets the same three tensors
-        back, which is what lets the dynamics reuse its topology (keyed on their addresses) without a host sync."""
-        key = tuple((t.data_ptr(), t._version, t.numel()) for t in list(masks) + list(sizes))
+        back, which is what lets the dynamics reuse its topology (keyed on their addresses) without a host sync.
+        need_edges=False (the fused training step, whose kernels walk the implicit complete graph): no edge list is built."""
+        key = tuple((t.data_ptr(), t._version, t.numel()) for t in list(masks) + list(sizes)) + (bool(need_edges),)
         hit = self._layouts.get(key)
         if hit is not None:
             self._layouts.move_to_end(key)
             return hit[0]
         combined_mask = torch.cat(masks)
-        val = (combined_mask, get_edges_index(combined_mask, remove_self_edge=True), get_n_frag_switch(sizes))
+        val = (combined_mask, get_edges_index(combined_mask, remove_self_edge=True) if need_edges else None, get_n_frag_switch(sizes))
         self._layouts[key] = (val, list(masks) + list(sizes))       # the key tensors stay alive with the entry
         while len(self._layouts) > 4:
             self._layouts.popitem(last=False)

@@ -44,9 +44,16 @@ def _pad16(n: int) -> int:
 class TrainTopology:
     """parts == 1 topology plus the index tables the stage functions need (internal order, int64 on the device)."""
 
-    def __init__(self, cfg, combined_mask: Tensor, n_frag_switch: Tensor, stream: int, edge_index: Optional[Tensor] = None):
+    def __init__(self, cfg, combined_mask: Tensor, n_frag_switch: Tensor, stream: int, edge_index: Optional[Tensor] = None,
+                 device: Optional[torch.device] = None):
+        """`combined_mask` / `n_frag_switch` may be HOST tensors (with `device` naming the GPU): a loader that keeps the CPU copies of
+        the batch's masks (DDPMTrainer.to_device) saves the step the device -> host copy - a wait for everything queued on the
+        stream.  The tables are built on the host, uploaded through a pinned buffer on the library's own stream and pooled
+        (oard_hip.hip, table pool): creating and dropping a topology per step does not synchronise the device."""
         L = _capi.lib()
-        dev = combined_mask.device
+        dev = torch.device(device) if device is not None else combined_mask.device
+        if dev.type != "cuda":
+            raise _capi.OardError("TrainTopology needs a ROCm device (pass device= with host masks)")
         cm = combined_mask.detach().to("cpu", torch.int64).contiguous()
         nfs = n_frag_switch.detach().to("cpu", torch.int64).contiguous()
         h = C.c_void_p()
