@@ -60,6 +60,55 @@ __global__ __launch_bounds__(WAVES * 64) void k_rows_dense(RowsDense a) {
     }
 }
 
+// The same layer on LONG inputs (the inner-edge rows: rbf_proj, radial_lin): RG 16-row groups per workgroup, the weight chunks of an
+// output tile loaded ONCE and used for all RG groups.  k_rows_dense re-reads the whole weight matrix from L2 for every 16 rows: at
+// A = 97 152 rows x 39 output tiles x 6 chunks that is 1.4 GB of L2 traffic per launch (146 us, L2-bound); here a quarter of it.
+template <int KB, int EPI, int WAVES, int RG>
+__global__ __launch_bounds__(WAVES * 64) void k_rows_dense_long(RowsDense a) {
+    static_assert(KB <= 13, "weight chunks of one tile are held in registers");
+    __shared__ __attribute__((aligned(16))) float xin[RG * KB * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.x * (16 * RG);
+    for (int i = wave; i < RG * KB; i += WAVES) {
+        const int rg = i / KB, b = i % KB;
+        const long long r = r0 + 16 * rg + (lane & 15);
+        const size_t row = (size_t)(r < a.rows ? r : a.rows - 1);
+        const f4 v = b < a.KB1 ? ld_blk(a.X, row, a.ldx, b, lane) : ld_blk(a.X2, row, a.ldx2, b - a.KB1, lane);
+        lds_st(xin, i, lane, v);
+    }
+    __syncthreads();
+    for (int t = wave; t < a.MT; t += WAVES) {
+        const float* base = a.W + ((size_t)t * KB * 64 + lane) * 4;
+        f4 w[KB];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) w[b] = ld_f4(base + (size_t)b * 256);
+        const f4 bias = a.bias != nullptr ? ld_vec(a.bias, t, lane) : f4zero();
+#pragma unroll 1                                      // unrolled, hipcc hoists the LDS reads of all groups (208 registers at KB = 13: spills)
+        for (int rg = 0; rg < RG; ++rg) {
+            f4 c0 = bias, c1 = f4zero();
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const f4 x = lds_blk(xin, rg * KB + b, lane);
+                if (b & 1) c1 = mma_chunk(w[b], x, c1);
+                else c0 = mma_chunk(w[b], x, c0);
+            }
+            f4 acc = c0 + c1;
+            const long long r = r0 + 16 * rg + (lane & 15);
+            if (r >= a.rows) continue;
+            const size_t row = (size_t)r;
+            if (EPI == EPI_SILU) {
+                if (a.Zo != nullptr) st_blk(a.Zo, row, a.ldzo, t, lane, acc);
+                acc = silu4(acc);
+            } else if (EPI == EPI_MUL_DSILU) {
+                acc = acc * dsilu4(ld_blk(a.Z, row, a.ldz, t, lane));
+            } else if (EPI == EPI_ADD) {
+                acc = ld_blk(a.Z, row, a.ldz, t, lane) + acc * a.scale;
+            }
+            st_blk(a.Y, row, a.ldy, t, lane, acc);
+        }
+    }
+}
+
 // ---- LayerNorm on rows (torch.nn.LayerNorm: biased variance, eps = 1e-5 inside the sqrt) ---------------------------------------
 // one wave per row; HP <= 256 (4 features per lane).  gamma / beta may be nullptr (no affine part).
 // Y = LN(X + (Xadd ? Xadd : 0)); Sum (optional) receives X + Xadd (the tensor the statistics are taken of)

@@ -175,11 +175,20 @@ struct TrainCtx {
     float* g(int idx) const { return grads ? grads[idx] : nullptr; }
 };
 
+#ifndef OARD_ROWS_LONG
+#define OARD_ROWS_LONG 1
+#endif
 // Y = epi(W X + b) on rows; KB is a template parameter of the kernel, dispatched over the block counts the model has
 template <int KB, int EPI>
 static void rows_dense_launch(hipStream_t st, const RowsDense& a) {
     if (a.rows <= 0 || a.MT <= 0) return;
     ScopedLaunch sl_(F_NODE, st);
+    if constexpr (KB <= 13) {
+        if (OARD_ROWS_LONG && a.rows >= 16384) {                  // long inputs (inner-edge rows): 4 row groups per workgroup share the weight loads
+            hipLaunchKernelGGL((k_rows_dense_long<KB, EPI, 8, 4>), dim3((unsigned)cdiv(a.rows, 64)), dim3(512), 0, st, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_rows_dense<KB, EPI, 8>), dim3((unsigned)cdiv(a.rows, 16)), dim3(512), 0, st, a);
 }
 template <int KB, int EPI = EPI_NONE>
