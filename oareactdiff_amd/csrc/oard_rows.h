@@ -60,6 +60,51 @@ __global__ __launch_bounds__(WAVES * 64) void k_rows_dense(RowsDense a) {
     }
 }
 
+// Two layers on the same 16 rows in ONE launch (round 4): Y1 = epi1(W1 X) as k_rows_dense does (stored - the weight-gradient GEMMs
+// read it), kept in LDS as the input of up to two second layers  Y2_j = epi2_j(W2_j Y1),  epi2 in {none, add}.  The node adjoints are chains
+// of such pairs (dz = (W^T dy) SiLU'(z); dx = V^T dz [+ residual]); every fused pair saves a ~15-us launch and the 8-us dispatch gap behind it.
+struct RowsOut2 { const float* W; float* Y; int ldy; int MT; const float* Zadd; int ldz; };     // Zadd != nullptr: Y = Zadd + acc
+struct RowsDense2 { RowsDense a; RowsOut2 o[2]; int n2; };
+template <int KB, int EPI, int WAVES, int KB2>
+__global__ __launch_bounds__(WAVES * 64) void k_rows_dense2(RowsDense2 q) {
+    const RowsDense& a = q.a;
+    __shared__ __attribute__((aligned(16))) float xin[KB * 256];
+    __shared__ __attribute__((aligned(16))) float y1[KB2 * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r = (long long)blockIdx.x * 16 + (lane & 15);
+    const bool valid = r < a.rows;
+    const size_t row = (size_t)(valid ? r : a.rows - 1);
+    for (int b = wave; b < KB; b += WAVES) {
+        const f4 v = b < a.KB1 ? ld_blk(a.X, row, a.ldx, b, lane) : ld_blk(a.X2, row, a.ldx2, b - a.KB1, lane);
+        lds_st(xin, b, lane, v);
+    }
+    __syncthreads();
+    for (int t = wave; t < KB2; t += WAVES) {                     // a.MT == KB2
+        f4 acc = a.bias != nullptr ? ld_vec(a.bias, t, lane) : f4zero();
+        acc = dense_tile_lds<KB>(a.W, t, xin, lane, acc);
+        if (EPI == EPI_SILU) {
+            if (a.Zo != nullptr && valid) st_blk(a.Zo, row, a.ldzo, t, lane, acc);
+            acc = silu4(acc);
+        } else if (EPI == EPI_MUL_DSILU) {
+            acc = acc * dsilu4(ld_blk(a.Z, row, a.ldz, t, lane));
+        } else if (EPI == EPI_ADD) {
+            acc = ld_blk(a.Z, row, a.ldz, t, lane) + acc * a.scale;
+        }
+        lds_st(y1, t, lane, acc);
+        if (valid) st_blk(a.Y, row, a.ldy, t, lane, acc);
+    }
+    __syncthreads();
+    for (int j = 0; j < q.n2; ++j) {
+        const RowsOut2& o = q.o[j];
+        for (int t = wave; t < o.MT; t += WAVES) {
+            f4 acc = dense_tile_lds<KB2>(o.W, t, y1, lane, f4zero());
+            if (!valid) continue;
+            if (o.Zadd != nullptr) acc = ld_blk(o.Zadd, row, o.ldz, t, lane) + acc;
+            st_blk(o.Y, row, o.ldy, t, lane, acc);
+        }
+    }
+}
+
 // The same layer on LONG inputs (the inner-edge rows: rbf_proj, radial_lin): RG 16-row groups per workgroup, the weight chunks of an
 // output tile loaded ONCE and used for all RG groups.  k_rows_dense re-reads the whole weight matrix from L2 for every 16 rows: at
 // A = 97 152 rows x 39 output tiles x 6 chunks that is 1.4 GB of L2 traffic per launch (146 us, L2-bound); here a quarter of it.

@@ -200,6 +200,32 @@ static void rows_dense(const TrainCtx& x, long long rows, const float* X, int ld
     a.Z = Z; a.ldz = ldz; a.Zo = Zo; a.ldzo = ldzo; a.rows = rows; a.MT = MT; a.scale = scale;
     rows_dense_launch<KB, EPI>(x.st, a);
 }
+// first layer as rows_dense (its arguments up to `scale`), then up to two second layers on its output (k_rows_dense2); the first layer must
+// have D::HT-many output tiles (MT == KB2).  OARD_ROWS_FUSE2 = 0: the same as separate launches (A/B, bit-identical)
+#ifndef OARD_ROWS_FUSE2
+#define OARD_ROWS_FUSE2 1
+#endif
+template <int KB, int EPI, int KB2>
+static void rows_dense2(const TrainCtx& x, long long rows, const float* X, int ldx, const float* W, float* Y, int ldy, const float* X2, int ldx2,
+                        int KB1, const float* Z, int ldz, float* Zo, int ldzo, const RowsOut2& o0, const RowsOut2* o1 = nullptr) {
+    if (!OARD_ROWS_FUSE2) {
+        rows_dense<KB, EPI>(x, rows, X, ldx, W, KB2, Y, ldy, nullptr, X2, ldx2, KB1, Z, ldz, Zo, ldzo);
+        for (const RowsOut2* o : {&o0, o1}) {
+            if (!o) continue;
+            if (o->Zadd) rows_dense<KB2, EPI_ADD>(x, rows, Y, ldy, o->W, o->MT, o->Y, o->ldy, nullptr, nullptr, 0, KB2, o->Zadd, o->ldz);
+            else rows_dense<KB2>(x, rows, Y, ldy, o->W, o->MT, o->Y, o->ldy);
+        }
+        return;
+    }
+    RowsDense2 q;
+    RowsDense& a = q.a;
+    a.X = X; a.ldx = ldx; a.X2 = X2 ? X2 : X; a.ldx2 = X2 ? ldx2 : ldx; a.KB1 = KB1; a.W = W; a.bias = nullptr; a.Y = Y; a.ldy = ldy;
+    a.Z = Z; a.ldz = ldz; a.Zo = Zo; a.ldzo = ldzo; a.rows = rows; a.MT = KB2; a.scale = 1.0f;
+    q.o[0] = o0; q.o[1] = o1 ? *o1 : o0; q.n2 = o1 ? 2 : 1;
+    if (rows <= 0) return;
+    ScopedLaunch sl_(F_NODE, x.st);
+    hipLaunchKernelGGL((k_rows_dense2<KB, EPI, 8, KB2>), dim3((unsigned)cdiv(rows, 16)), dim3(512), 0, x.st, q);
+}
 // out[c * ostride] (+)= scale * sum_{r in [r0, r1)} w(r) act(X[r][c])
 static void colsum(const TrainCtx& x, const float* X, int ld, long long r0, long long r1, int ncols, float* out, int accumulate = 1,
                    const float* wrow = nullptr, int x_silu = 0, float scale = 1.0f) {
@@ -361,15 +387,16 @@ static int tr_update_bwd(const TrainCtx& x, int l, const float* ds, const float*
     { ScopedLaunch sl_(F_NODE, x.st);
       hipLaunchKernelGGL(k_upd_sc, EW_GRID(NH), 0, x.st, (const float*)v12, x1, N, HP, inv_sqrt_h, sc, x.f(x.w.vdot));
       hipLaunchKernelGGL(k_lin3u_fwd, EW_GRID(NH), 0, x.st, x.wb + lo.l3u, (const float*)sc, NH, scal); }        // frame-scalar MLP :333
-    rows_dense<2 * HT, EPI_SILU>(x, N, s_a, HP, x.wb + lo.xv0, HT, hx, HP, nullptr, scal, HP, HT, nullptr, 0, zx, HP);      // :337-339
-    rows_dense<HT>(x, N, hx, HP, x.wb + lo.xv2 + (size_t)2 * HT * HT * 256, HT, cvec, HP);                       // c = third part of xvec_proj.2
+    // hx = SiLU(xvec_proj.0 [s_a | scalar]) (:337-339), c = third part of xvec_proj.2 hx - one launch
+    rows_dense2<2 * HT, EPI_SILU, HT>(x, N, s_a, HP, x.wb + lo.xv0, hx, HP, scal, HP, HT, nullptr, 0, zx, HP,
+                                      RowsOut2{x.wb + lo.xv2 + (size_t)2 * HT * HT * 256, cvec, HP, HT, nullptr, 0});
     // ---- adjoint ----
     { ScopedLaunch sl_(F_NODE, x.st);
       hipLaunchKernelGGL(k_upd_seed, EW_GRID(NH), 0, x.st, ds, dvec, (const float*)v12, (const float*)cvec, N, HP, inv_sqrt_h, dabc, dv12); }
-    rows_dense<3 * HT, EPI_MUL_DSILU>(x, N, dabc, 3 * HP, x.pb + nl.xv2T, HT, dzx, HP, nullptr, nullptr, 0, 3 * HT, zx, HP);
-    // d [s_a | scalar] = xvec_proj.0^T dzx:  the s half lands on ds (identity path of s_out = s_a + ...), the scalar half goes to lin3
-    rows_dense<HT, EPI_ADD>(x, N, dzx, HP, x.pb + nl.xv0T, HT, gs_a, HP, nullptr, nullptr, 0, HT, ds, HP);
-    rows_dense<HT>(x, N, dzx, HP, x.pb + nl.xv0T + (size_t)HT * HT * 256, HT, dscal, HP);
+    // dzx = (xvec_proj.2^T dabc) SiLU'(zx);  d [s_a | scalar] = xvec_proj.0^T dzx:  the s half lands on ds (identity path of s_out = s_a + ...),
+    // the scalar half goes to lin3 - one launch
+    { const RowsOut2 o_s{x.pb + nl.xv0T, gs_a, HP, HT, ds, HP}, o_c{x.pb + nl.xv0T + (size_t)HT * HT * 256, dscal, HP, HT, nullptr, 0};
+      rows_dense2<3 * HT, EPI_MUL_DSILU, HT>(x, N, dabc, 3 * HP, x.pb + nl.xv2T, dzx, HP, nullptr, 0, 3 * HT, zx, HP, nullptr, 0, o_s, &o_c); }
     // lin3 adjoint + its parameter gradients in one pass (k_lin3u_bwd_fused): per-wave partial blocks, then a fixed-order reduce
     constexpr int L3_WAVES = 4, L3_BLOCKS = 512;
     { ScopedLaunch sl_(F_NODE, x.st);
@@ -430,14 +457,14 @@ static int tr_gcl_node_bwd(const TrainCtx& x, int l, const float* gx, const floa
     const float* agg = x.t(x.to.agg[l]);
     const float* s_mid = x.t(x.to.s_mid[l]);
     float *dzq = x.f(x.w.dzq), *dxln = x.f(x.w.dxln), *lng = x.f(x.w.lng), *dsm = x.f(x.w.dsm), *dzm = x.f(x.w.dzm);
-    rows_dense<3 * HT, EPI_MUL_DSILU>(x, N, dxq, 3 * HP, x.pb + nl.xp2T, HT, dzq, HP, nullptr, nullptr, 0, 3 * HT, x.f(x.w.zq), HP);
-    rows_dense<HT>(x, N, dzq, HP, x.pb + nl.xp0T, HT, dxln, HP);
+    rows_dense2<3 * HT, EPI_MUL_DSILU, HT>(x, N, dxq, 3 * HP, x.pb + nl.xp2T, dzq, HP, nullptr, 0, 3 * HT, x.f(x.w.zq), HP, nullptr, 0,
+                                           RowsOut2{x.pb + nl.xp0T, dxln, HP, HT, nullptr, 0});      // dzq, then dxln = x_proj.0^T dzq
     { ScopedLaunch sl_(F_NODE, x.st);                         // d s_mid = gx + LN_msg^T dxln
       hipLaunchKernelGGL(k_rows_ln_bwd, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, x.st, s_mid, HP, H, HP, x.wb + lo.ln_q_w, (const float*)dxln,
                          gx, dsm, lng, (long long)N); }
-    rows_dense<HT, EPI_MUL_DSILU>(x, N, dsm, HP, x.pb + nl.nm1T, HT, dzm, HP, nullptr, nullptr, 0, HT, x.f(x.w.zm), HP);
-    rows_dense<HT, EPI_ADD>(x, N, dzm, HP, x.pb + nl.nm0T, HT, dxh, HP, nullptr, nullptr, 0, HT, dsm, HP);      // residual path + xh half
-    rows_dense<HT>(x, N, dzm, HP, x.pb + nl.nm0T + (size_t)HT * HT * 256, HT, dagg, HP);                         // agg half
+    { const RowsOut2 o_x{x.pb + nl.nm0T, dxh, HP, HT, dsm, HP},                                                 // residual path + xh half
+                     o_a{x.pb + nl.nm0T + (size_t)HT * HT * 256, dagg, HP, HT, nullptr, 0};                      // agg half
+      rows_dense2<HT, EPI_MUL_DSILU, HT>(x, N, dsm, HP, x.pb + nl.nm1T, dzm, HP, nullptr, 0, HT, x.f(x.w.zm), HP, nullptr, 0, o_x, &o_a); }
     x.fork();
     colsum(x, lng, HP, 0, N, H, x.g(m + 7));                  // message_layers.l.x_layernorm.weight
     colsum(x, dxln, HP, 0, N, H, x.g(m + 8));                 // .bias
