@@ -355,9 +355,9 @@ static int tr_recompute(const TrainCtx& x, int l) {
     { ScopedLaunch sl_(F_NODE, x.st);                                                   // xln = LN_msg(s_mid)   :245
       hipLaunchKernelGGL(k_rows_ln_fwd, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, x.st, s_mid, (const float*)nullptr, HP, D::H, HP,
                          x.wb + lo.ln_q_w, x.wb + lo.ln_q_b, x.f(x.w.xln), (float*)nullptr, (long long)N); }
-    rows_dense<D::HT, EPI_SILU>(x, N, x.f(x.w.xln), HP, x.wb + lo.xp0, D::HT, x.f(x.w.hq), HP, nullptr, nullptr, 0, D::HT, nullptr, 0,
-                                x.f(x.w.zq), HP);
-    rows_dense<D::HT>(x, N, x.f(x.w.hq), HP, x.wb + lo.xp2, 3 * D::HT, x.f(x.w.xq), 3 * HP);
+    // hq = SiLU(x_proj.0 xln), xq = x_proj.2 hq - one launch
+    rows_dense2<D::HT, EPI_SILU, D::HT>(x, N, x.f(x.w.xln), HP, x.wb + lo.xp0, x.f(x.w.hq), HP, nullptr, 0, D::HT, nullptr, 0, x.f(x.w.zq), HP,
+                                        RowsOut2{x.wb + lo.xp2, x.f(x.w.xq), 3 * HP, 3 * D::HT, nullptr, 0});
     // cr = rbf_proj(rbf) on the inner edges                                             :247
     rows_dense<D::RB>(x, tp.A, x.t(x.to.rbuf), D::RP, x.wb + lo.rbfp, 3 * D::HT, x.f(x.w.cr), 3 * HP);
     HIP_TRY(hipGetLastError());
