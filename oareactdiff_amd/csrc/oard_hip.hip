@@ -949,21 +949,39 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
 // ------------------------------------------------------------------------------------------------
 void oard_topology_destroy(oard_topology* tp);
 
+// ---- the library's own streams (round 4) --------------------------------------------------------------------------------------------------
+// THREE non-blocking streams per device, created once: the sub-batch streams of every multi-part topology (side[1..3]), the gradient
+// stream of the training sweep ([0]) and the stream of the table uploads ([2]).  The ROCm runtime serves a process's streams from 4
+// hardware queues; with the caller's stream these make exactly 4.  Streams created per topology / per purpose (rounds 1-3) made the queue a
+// compute stream lands on depend on what had been created before it: one extra stream and two sub-batches of the B = 64 denoising step
+// shared a queue (17.9 -> 20.5 ms).
+static hipStream_t* device_streams() {
+    static hipStream_t all[64][3] = {};
+    static std::mutex m;
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    std::lock_guard<std::mutex> lk(m);
+    if (!all[d][0])
+        for (int i = 0; i < 3; ++i)
+            if (hipStreamCreateWithFlags(&all[d][i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); all[d][i] = nullptr; }
+    return all[d];
+}
+
 // ---- table pool (round 4) ---------------------------------------------------------------------------------------------------------------
 // Training sees a new batch layout every step, so a topology is built and dropped per step.  hipMalloc / blocking hipMemcpy on the null
-// stream / hipFree each wait for the device - a pipeline drain per step (measured: + 18 ms on a 68-ms step).  Instead: device blocks come
-// from a free list (capacity-matched, at most 2 x the request), the tables are packed into ONE pinned staging buffer and uploaded by ONE
-// hipMemcpyAsync on a private non-blocking stream (the host waits for that copy only), and a destroyed topology's blocks return to the list
-// behind events recorded on the streams that used it.
+// stream / hipFree each wait for the device - a pipeline drain per step (measured: + 18 ms on a 68-ms step).  Instead: device blocks and
+// pinned staging blocks come from free lists (capacity-matched, at most 2 x the request); the tables are packed into ONE pinned block and
+// uploaded by ONE hipMemcpyAsync on the library's third stream (device_streams) - the host does not wait, and in training, where that
+// stream is otherwise idle, the copy runs beside the previous step - with an event behind it that every stream waits for before its first
+// use of the topology; a destroyed topology's blocks return to the lists behind events recorded on the streams that used it.
 struct TablePool {
     struct Free { void* p; size_t cap; };
-    struct Pending { void* p; size_t cap; hipEvent_t ev[4]; int n_ev; };
+    struct Pending { void* p; size_t cap; hipEvent_t ev[4]; int n_ev; int kind; };
     std::mutex m;
-    std::vector<Free> free_;
+    std::vector<Free> free_[2];                        // kind 0: device memory, 1: pinned host memory
     std::vector<Pending> pending;
     std::vector<hipEvent_t> spare_events;
-    char* stage = nullptr; size_t stage_cap = 0;       // pinned
-    hipStream_t up = nullptr;
 };
 static TablePool& table_pool() {
     static TablePool pools[64];
@@ -971,6 +989,7 @@ static TablePool& table_pool() {
     (void)hipGetDevice(&d);
     return pools[d & 63];
 }
+static void pool_raw_free(void* p, int kind) { if (kind == 0) (void)hipFree(p); else (void)hipHostFree(p); }
 static void pool_collect(TablePool& tp) {               // pending -> free where every event has fired (non-blocking)
     for (size_t i = 0; i < tp.pending.size();) {
         TablePool::Pending& q = tp.pending[i];
@@ -978,74 +997,77 @@ static void pool_collect(TablePool& tp) {               // pending -> free where
         for (int k = 0; k < q.n_ev && done; ++k) done = hipEventQuery(q.ev[k]) == hipSuccess;
         if (!done) { ++i; continue; }
         for (int k = 0; k < q.n_ev; ++k) tp.spare_events.push_back(q.ev[k]);
-        tp.free_.push_back({q.p, q.cap});
+        tp.free_[q.kind].push_back({q.p, q.cap});
         tp.pending[i] = tp.pending.back();
         tp.pending.pop_back();
     }
     (void)hipGetLastError();                              // hipEventQuery's hipErrorNotReady is not an error
 }
-static void* pool_alloc(size_t bytes, size_t* cap) {
+static void* pool_alloc(size_t bytes, size_t* cap, int kind = 0) {
     TablePool& tp = table_pool();
     std::lock_guard<std::mutex> lk(tp.m);
     pool_collect(tp);
+    std::vector<TablePool::Free>& fl = tp.free_[kind];
     int best = -1;
-    for (int i = 0; i < (int)tp.free_.size(); ++i)
-        if (tp.free_[i].cap >= bytes && tp.free_[i].cap <= 2 * bytes + (1u << 20) && (best < 0 || tp.free_[i].cap < tp.free_[best].cap)) best = i;
+    for (int i = 0; i < (int)fl.size(); ++i)
+        if (fl[i].cap >= bytes && fl[i].cap <= 2 * bytes + (1u << 20) && (best < 0 || fl[i].cap < fl[best].cap)) best = i;
     if (best >= 0) {
-        void* p = tp.free_[best].p;
-        *cap = tp.free_[best].cap;
-        tp.free_[best] = tp.free_.back();
-        tp.free_.pop_back();
+        void* p = fl[best].p;
+        *cap = fl[best].cap;
+        fl[best] = fl.back();
+        fl.pop_back();
         return p;
     }
-    while (tp.free_.size() > 16) {                        // blocks of shapes that no longer occur
-        (void)hipFree(tp.free_.front().p);
-        tp.free_.erase(tp.free_.begin());
+    while (fl.size() > 16) {                              // blocks of shapes that no longer occur
+        pool_raw_free(fl.front().p, kind);
+        fl.erase(fl.begin());
     }
     void* p = nullptr;
     *cap = align_up(bytes + bytes / 8, (size_t)1 << 16);  // some slack: the next layout of about this size fits as well
-    if (hipMalloc(&p, *cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const hipError_t e = kind == 0 ? hipMalloc(&p, *cap) : hipHostMalloc(&p, *cap, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
-// returns the block to the pool; usable again once everything enqueued so far on `streams` has run
-static void pool_release(void* p, size_t cap, const hipStream_t* streams, int n_streams, bool sync_device) {
+// returns the block to the pool; usable again once everything enqueued so far on `streams` (and on the upload stream) has been executed
+static void pool_release(void* p, size_t cap, const hipStream_t* streams, int n_streams, bool sync_device, int kind = 0) {
     if (!p) return;
     TablePool& tp = table_pool();
     std::lock_guard<std::mutex> lk(tp.m);
-    if (sync_device) { (void)hipDeviceSynchronize(); tp.free_.push_back({p, cap}); return; }
-    TablePool::Pending q{p, cap, {}, 0};
-    for (int k = 0; k < n_streams && k < 4; ++k) {
+    if (sync_device) { (void)hipDeviceSynchronize(); tp.free_[kind].push_back({p, cap}); return; }
+    TablePool::Pending q{p, cap, {}, 0, kind};
+    hipStream_t all[5] = {device_streams()[2]};           // the upload stream first, then the streams of use
+    int n = 1;
+    for (int k = 0; k < n_streams && k < 4; ++k) if (streams[k] != all[0]) all[n++] = streams[k];
+    for (int k = 0; k < n && q.n_ev < 4; ++k) {
         hipEvent_t e = nullptr;
         if (!tp.spare_events.empty()) { e = tp.spare_events.back(); tp.spare_events.pop_back(); }
-        else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipDeviceSynchronize(); tp.free_.push_back({p, cap}); return; }
-        (void)hipEventRecord(e, streams[k]);
+        else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipDeviceSynchronize(); tp.free_[kind].push_back({p, cap}); return; }
+        (void)hipEventRecord(e, all[k]);
         q.ev[q.n_ev++] = e;
     }
-    if (q.n_ev == 0) tp.free_.push_back({p, cap});        // never used on the device
-    else tp.pending.push_back(q);
+    if (n > 4) { (void)hipDeviceSynchronize(); }          // (4 user streams + the upload stream: wait instead of a fifth event)
+    tp.pending.push_back(q);
 }
-// packs `items` into the pinned staging buffer and uploads them with one asynchronous copy on the pool's own stream
+// packs `items` into a pinned block and enqueues ONE asynchronous copy on the upload stream; the pinned block (returned) stays with the
+// topology until it is destroyed
 struct UploadItem { const void* src; size_t bytes; size_t off; };
-static int pool_upload(void* dev, const std::vector<UploadItem>& items, size_t total) {
-    TablePool& tp = table_pool();
-    std::lock_guard<std::mutex> lk(tp.m);
-    if (!tp.up && hipStreamCreateWithFlags(&tp.up, hipStreamNonBlocking) != hipSuccess) return OARD_EHIP;
-    if (tp.stage_cap < total) {
-        if (tp.stage) (void)hipHostFree(tp.stage);
-        tp.stage = nullptr; tp.stage_cap = 0;
-        const size_t want = align_up(total + total / 4, (size_t)1 << 20);
-        if (hipHostMalloc((void**)&tp.stage, want, hipHostMallocDefault) != hipSuccess) return OARD_EHIP;
-        tp.stage_cap = want;
+static int pool_upload(void* dev, const std::vector<UploadItem>& items, size_t total, void** stage_out, size_t* stage_cap) {
+    char* stage = (char*)pool_alloc(total, stage_cap, 1);
+    if (!stage) return OARD_EHIP;
+    for (const UploadItem& it : items) memcpy(stage + it.off, it.src, it.bytes);
+    if (hipMemcpyAsync(dev, stage, total, hipMemcpyHostToDevice, device_streams()[2]) != hipSuccess) {
+        (void)hipGetLastError();
+        pool_release(stage, *stage_cap, nullptr, 0, true, 1);
+        return OARD_EHIP;
     }
-    for (const UploadItem& it : items) memcpy(tp.stage + it.off, it.src, it.bytes);
-    HIP_TRY(hipMemcpyAsync(dev, tp.stage, total, hipMemcpyHostToDevice, tp.up));
-    HIP_TRY(hipStreamSynchronize(tp.up));                 // this copy only: the caller's streams keep running
+    *stage_out = stage;
     return OARD_OK;
 }
-// an entry point is about to enqueue work on `st` that reads the topology's tables
+// an entry point is about to enqueue work on `st` that reads the topology's tables: the stream's first use waits for the upload
 static void topo_touch(const oard_topology* tp, hipStream_t st) {
     if (!tp) return;
     for (int i = 0; i < tp->n_used; ++i) if (tp->used_on[i] == st) return;
+    if (tp->ready) (void)hipStreamWaitEvent(st, tp->ready, 0);
     if (tp->n_used < 4) tp->used_on[tp->n_used++] = st; else tp->used_many = true;
 }
 
@@ -1140,7 +1162,7 @@ static int build_part(const oard_config* c, const int64_t* cm, const int64_t* nf
     size_t cap = 0;
     char* dev = (char*)pool_alloc(cur, &cap);
     if (!dev) return OARD_EHIP;
-    if (int rc = pool_upload(dev, items, cur)) { pool_release(dev, cap, nullptr, 0, false); return rc; }
+    if (int rc = pool_upload(dev, items, cur, &part.stage, &part.stage_cap)) { pool_release(dev, cap, nullptr, 0, false); return rc; }
     part.dev_cap = cap;
     part.dev_block = dev;
     TopoDev& d = part.d;
@@ -1198,7 +1220,7 @@ int oard_topology_create_parts(const oard_config* c, const int64_t* cm, const in
         tp->ref_block = pool_alloc(b_all, &tp->ref_cap);
         if (!tp->ref_block) { delete tp; return OARD_EHIP; }
         const std::vector<UploadItem> ref_items = {{tab.data(), b_int, 0}, {ref_ptr_ref.data(), (size_t)N * sizeof(long long), align_up(b_int, 8)}};
-        if (int rc = pool_upload(tp->ref_block, ref_items, b_all)) { oard_topology_destroy(tp); return rc; }
+        if (int rc = pool_upload(tp->ref_block, ref_items, b_all, &tp->ref_stage, &tp->ref_stage_cap)) { oard_topology_destroy(tp); return rc; }
         tp->ref_sample = (const int*)tp->ref_block; tp->ref_rank = tp->ref_sample + N;
         tp->ref_ptr = (const long long*)((char*)tp->ref_block + align_up(b_int, 8));
         tp->N_ref = N;
@@ -1218,10 +1240,14 @@ int oard_topology_create_parts(const oard_config* c, const int64_t* cm, const in
     if (n_parts > 1) {
         HIP_TRY(hipEventCreateWithFlags(&tp->ev_fork, hipEventDisableTiming));
         for (int p = 1; p < n_parts; ++p) {
-            HIP_TRY(hipStreamCreateWithFlags(&tp->side[p], hipStreamNonBlocking));
+            tp->side[p] = device_streams()[(p - 1) % 3];     // shared by all topologies of the device (more than 4 parts: a debug setting)
+            if (!tp->side[p]) { oard_topology_destroy(tp); return OARD_EHIP; }
             HIP_TRY(hipEventCreateWithFlags(&tp->ev_join[p], hipEventDisableTiming));
         }
     }
+    // the uploads sit on the upload stream: every stream waits for this event before its first use of the topology (topo_touch)
+    HIP_TRY(hipEventCreateWithFlags(&tp->ready, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(tp->ready, device_streams()[2]));
     *out = tp;
     return OARD_OK;
 }
@@ -1232,11 +1258,13 @@ void oard_topology_destroy(oard_topology* tp) {
     // callers' streams cover their work as well
     for (int p = 0; p < OARD_MAX_PARTS; ++p) {
         pool_release(tp->parts[p].dev_block, tp->parts[p].dev_cap, tp->used_on, tp->n_used, tp->used_many);
-        if (tp->side[p]) (void)hipStreamDestroy(tp->side[p]);
+        pool_release(tp->parts[p].stage, tp->parts[p].stage_cap, nullptr, 0, false, 1);          // read by the upload stream only
         if (tp->ev_join[p]) (void)hipEventDestroy(tp->ev_join[p]);
     }
     if (tp->ev_fork) (void)hipEventDestroy(tp->ev_fork);
     pool_release(tp->ref_block, tp->ref_cap, tp->used_on, tp->n_used, tp->used_many);
+    pool_release(tp->ref_stage, tp->ref_stage_cap, nullptr, 0, false, 1);
+    if (tp->ready) (void)hipEventDestroy(tp->ready);
     delete tp;
 }
 int64_t oard_topology_num_nodes(const oard_topology* tp) { return tp ? tp->N : 0; }

@@ -85,6 +85,8 @@ struct TopoPart {
     TopoDev d;
     void* dev_block = nullptr;     // one allocation holding every table of this part (from the table pool, oard_hip.hip)
     size_t dev_cap = 0;            // its capacity in the pool
+    void* stage = nullptr;         // pinned block the tables were uploaded from (kept until the topology is destroyed)
+    size_t stage_cap = 0;
     size_t ws_off = 0;             // byte offset of this part's slice of the workspace
     int conc = 1;                  // sub-batches of this topology that run concurrently (launch-shape heuristics)
     mutable size_t vec_final = 0;  // workspace offset (within the slice) of the vec buffer holding the final state
@@ -102,6 +104,9 @@ struct oard_topology {
     // first reference-order edge id of the node
     void* ref_block = nullptr;
     size_t ref_cap = 0;
+    void* ref_stage = nullptr;
+    size_t ref_stage_cap = 0;
+    hipEvent_t ready = nullptr;        // recorded on the null stream behind the table uploads
     // streams that have been given work reading this topology's tables (noted by the entry points): oard_topology_destroy records an
     // event on each and the table pool hands the blocks out again only after those events have fired - no hipFree (a device-wide sync)
     mutable hipStream_t used_on[4] = {};

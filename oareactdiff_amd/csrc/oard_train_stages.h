@@ -113,7 +113,8 @@ static TrainStreams& train_streams() {
     TrainStreams& t = all[d & 63];
     if (!t.tried) {
         t.tried = true;
-        bool ok = hipStreamCreateWithFlags(&t.w, hipStreamNonBlocking) == hipSuccess;
+        t.w = device_streams()[0];                     // the library's first stream (oard_hip.hip: device_streams)
+        bool ok = t.w != nullptr;
         for (int i = 0; ok && i < 32; ++i) ok = hipEventCreateWithFlags(&t.pool[i], hipEventDisableTiming) == hipSuccess;
         for (int i = 0; ok && i <= OARD_MAX_LAYERS; ++i) ok = hipEventCreateWithFlags(&t.layer_done[i], hipEventDisableTiming) == hipSuccess;
         t.ok = ok;
