@@ -8,7 +8,8 @@
  * The reference has no FFI of its own (it is pure Python on torch ops); the interface each
  * entry point replaces is therefore the Python call it stands in for, cited per function.
  * Conventions: every function returns 0 on success or a negative OARD_E* code; nothing here
- * synchronises the stream or the device except oard_topology_create (host work + uploads);
+ * synchronises a stream or the device (oard_topology_create does its work on the host and leaves
+ * ONE asynchronous upload behind; the only waits are in oard_topology_check_edge_index, a verification call);
  * all `*_dev` pointers are device pointers on the current HIP device; float tensors are
  * contiguous row-major fp32; the library never touches torch.
  * Threading: calls on DISTINCT (topology, workspace, tape, scratch) objects may run concurrently from several host threads /
