@@ -264,12 +264,15 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X
 // lanes x nc4 column quads (RL = 256 / nc4), a thread adds rows rb + rl, rb + rl + RL, ... of its quad in ascending order, the RL lane
 // sums are then added in lane order - a fixed order.  CSL_ROWS rows per block -> part[q][c] as k_colsum_part.  (The one-thread-per-
 // column kernel above spent 1.66 ms per training step, most of it on the six [E][196] sums of the att_mlp weight gradient.)
+// rows per block: 512 on the long edge-level inputs; node-level inputs (a few thousand rows) get 32, i.e. > 100 blocks instead of 9 (the
+// sums are a function of (rows, rows per block) only - still a fixed order)
 #define CSL_ROWS 512
+#define CSL_ROWS_SHORT 32
 __global__ __launch_bounds__(256) void k_colsum_long(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
-                                                     const float* __restrict__ wrow, int x_silu, float* __restrict__ part) {
+                                                     const float* __restrict__ wrow, int x_silu, float* __restrict__ part, int rows_per_block) {
     __shared__ f4 red[256];
     const int nc4 = ncols >> 2, RL = 256 / nc4, rl = threadIdx.x / nc4, c4 = threadIdx.x - rl * nc4;
-    const long long rb = r0 + (long long)blockIdx.x * CSL_ROWS, re = rb + CSL_ROWS < r1 ? rb + CSL_ROWS : r1;
+    const long long rb = r0 + (long long)blockIdx.x * rows_per_block, re = rb + rows_per_block < r1 ? rb + rows_per_block : r1;
     f4 s = f4zero();
     if (rl < RL) {
         const float* p = X + 4 * c4;

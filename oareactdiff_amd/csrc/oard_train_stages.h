@@ -240,8 +240,10 @@ static void colsum(const TrainCtx& x, const float* X, int ld, long long r0, long
         return;
     }
     if (r1 - r0 >= 8 * CSL_ROWS && (ncols & 3) == 0 && ncols >= 8 && ncols <= 1024 && (ld & 3) == 0 && (((uintptr_t)X) & 15) == 0) {
-        const int nchl = (int)cdiv(r1 - r0, CSL_ROWS);                // long and wide enough: float4 loads, several row lanes per block
-        hipLaunchKernelGGL(k_colsum_long, dim3((unsigned)nchl), dim3(256), 0, x.stw, X, ld, r0, r1, ncols, wrow, x_silu, part);
+        // (the partial buffer holds rows / 64 x 1024 floats: 32-row chunks only for ncols <= 512)
+        const int rpb = r1 - r0 >= 64 * CSL_ROWS ? CSL_ROWS : (ncols <= 512 ? CSL_ROWS_SHORT : 2 * CSL_ROWS_SHORT);
+        const int nchl = (int)cdiv(r1 - r0, rpb);                     // long and wide enough: float4 loads, several row lanes per block
+        hipLaunchKernelGGL(k_colsum_long, dim3((unsigned)nchl), dim3(256), 0, x.stw, X, ld, r0, r1, ncols, wrow, x_silu, part, rpb);
         hipLaunchKernelGGL(k_colsum_fin, dim3((unsigned)cdiv(ncols, 4)), dim3(256), 0, x.stw, (const float*)part, nchl, ncols, out, accumulate, scale);
         return;
     }
