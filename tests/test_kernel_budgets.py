@@ -20,6 +20,9 @@ BUDGETS = {
     r"^void k_wgrad_t16<": 0,
     r"^void k_wgrad_q<": 0,
     r"^void k_scalarize_bwd<Dims<196, 96>, \d+, (true|false)>": 0,
+    r"^void k_equi_msg_bwd<Dims<196, 96> >": 0,
+    r"^void k_rows_dense2<": 0,
+    r"^void k_rows_dense_long<": 0,
     r"^void k_gcl_edge_b3<": 0,
     r"^void k_equi_edge_b3<Dims<196, 96>, false>": 0,
     r"^void k_equi_edge_b3<Dims<196, 96>, true>": 20,        # the optional split-precision TRAINING-mode forward (tape stores)
