@@ -22,7 +22,7 @@
 #include "oard_edge_bwd.h"
 #include "oard_node_bwd.h"
 
-#define OARD_VERSION 2010
+#define OARD_VERSION 2020
 
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "liboard_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
