@@ -62,8 +62,16 @@ class DiffusionLoss:
         if hit is not None:
             self._layouts.move_to_end(key)
             return hit[0]
-        combined_mask = torch.cat(masks)
-        val = (combined_mask, get_edges_index(combined_mask, remove_self_edge=True) if need_edges else None, get_n_frag_switch(sizes))
+        if not need_edges and all(t.device.type == "cpu" for t in list(masks) + list(sizes)):
+            # host tensors (DDPMTrainer.to_device's copies): numpy, not torch - on a many-core host every torch CPU op that opens an
+            # OpenMP region costs milliseconds (measured on the 256-thread host of the MI355X box: 26 ms for these two lines)
+            import numpy as np
+            cm = np.concatenate([m.numpy().astype(np.int64, copy=False) for m in masks])
+            nfs = np.repeat(np.arange(len(sizes), dtype=np.int64), [int(s.numpy().sum()) for s in sizes])
+            val = (torch.from_numpy(cm), None, torch.from_numpy(nfs))
+        else:
+            combined_mask = torch.cat(masks)
+            val = (combined_mask, get_edges_index(combined_mask, remove_self_edge=True) if need_edges else None, get_n_frag_switch(sizes))
         self._layouts[key] = (val, list(masks) + list(sizes))       # the key tensors stay alive with the entry
         while len(self._layouts) > 4:
             self._layouts.popitem(last=False)
