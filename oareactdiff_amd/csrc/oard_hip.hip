@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <chrono>
 #include <utility>
 
 #include "oard_kernels.h"
@@ -955,6 +956,26 @@ void oard_topology_destroy(oard_topology* tp);
 // hardware queues; with the caller's stream these make exactly 4.  Streams created per topology / per purpose (rounds 1-3) made the queue a
 // compute stream lands on depend on what had been created before it: one extra stream and two sub-batches of the B = 64 denoising step
 // shared a queue (17.9 -> 20.5 ms).
+// Which hardware queue a stream lands on depends on how many streams the process created before it (measured, tools/queue_probe.py: 1, 2
+// or 4 foreign streams created first and the denoising step is 20.3 instead of 17.9 ms - RCCL creates streams, so does any host program).
+// So the three streams are CHOSEN: up to 8 candidates are created and a candidate is taken if a 300-us spin kernel on it overlaps with
+// the same kernel on the null stream and on every stream taken so far (wall time of the pair < 1.6 x the time of one).  ~10 ms, once per
+// device; OARD_NO_STREAM_CALIBRATION=1 takes the first three.
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static double spin_pair_us(hipStream_t a, hipStream_t b, bool both) {
+    const long long ticks = 30000;                        // ~300 us of the 100-MHz wall clock (measured below, not assumed)
+    (void)hipDeviceSynchronize();
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks);
+    if (both) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks);
+    (void)hipStreamSynchronize(a);
+    if (both) (void)hipStreamSynchronize(b);
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+static bool streams_overlap(hipStream_t a, hipStream_t b, double one_us) { return spin_pair_us(a, b, true) < 1.6 * one_us; }
 static hipStream_t* device_streams() {
     static hipStream_t all[64][3] = {};
     static std::mutex m;
@@ -962,9 +983,27 @@ static hipStream_t* device_streams() {
     (void)hipGetDevice(&d);
     d &= 63;
     std::lock_guard<std::mutex> lk(m);
-    if (!all[d][0])
-        for (int i = 0; i < 3; ++i)
-            if (hipStreamCreateWithFlags(&all[d][i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); all[d][i] = nullptr; }
+    if (!all[d][0]) {
+        hipStream_t cand[8] = {};
+        int n_cand = 0, taken = 0;
+        for (; n_cand < 8; ++n_cand)
+            if (hipStreamCreateWithFlags(&cand[n_cand], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        const bool calibrate = getenv("OARD_NO_STREAM_CALIBRATION") == nullptr;
+        bool used[8] = {};
+        double one_us = 0;
+        if (calibrate && n_cand > 0) { (void)spin_pair_us(nullptr, nullptr, false); one_us = spin_pair_us(nullptr, nullptr, false); }
+        for (int c = 0; c < n_cand && taken < 3 && calibrate; ++c) {
+            bool ok = streams_overlap(nullptr, cand[c], one_us);
+            for (int k = 0; k < taken && ok; ++k) ok = streams_overlap(all[d][k], cand[c], one_us);
+            if (ok) { all[d][taken++] = cand[c]; used[c] = true; }
+        }
+        for (int c = 0; c < n_cand && taken < 3; ++c)      // not enough independent queues (or calibration off): take what there is
+            if (!used[c]) { all[d][taken++] = cand[c]; used[c] = true; }
+        for (int c = 0; c < n_cand; ++c)
+            if (!used[c]) (void)hipStreamDestroy(cand[c]);
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+    }
     return all[d];
 }
 
