@@ -1988,6 +1988,7 @@ int oard_train_stage_backward(const oard_config* c, const oard_topology* topo, c
         default: return OARD_EINVAL;
     }
     if (rc == OARD_OK) rc = wgq_flush();
+    x.join();                   // a test entry: its callers read the gradients (and poison / overwrite the scratch) in the caller's stream order
     return rc;
 }
 
