@@ -495,7 +495,7 @@ static TapeOff make_tape(const oard_config* c, const TopoDev& td) {
 
 // `tape` != NULL: training-mode forward (TapeOff layout): every layer's input edge state lives in its own tape
 // buffer (the update is out of place), the edge kernels store their pre-activations, and the node state at the
-// layer boundaries is copied out.  One launch shape, layer-0 / last-layer shortcuts always on.
+// layer boundaries is written straight into its tape slots (no copies).  One launch shape, layer-0 / last-layer shortcuts always on.
 template <class D>
 static int forward_impl(const oard_config* c, const TopoPart* topo, const float* wb, const float* const* xh,
                         const float* t, int t_scalar, const float* cond, float* const* out, char* ws, char* tape,
@@ -507,19 +507,25 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     const TapeOff to = train ? make_tape(c, tp) : TapeOff{};
     const int emb = embed_dim(c);
     float* pos = (float*)(ws + w.pos); double* pf64 = (double*)(ws + w.pf64); float* pf32 = (float*)(ws + w.pf32);
-    float* x1 = (float*)(ws + w.x1); float* pp0 = (float*)(ws + w.pp0); int* labels = (int*)(ws + w.labels);
-    float* hin = (float*)(ws + w.hin); float* zemb = (float*)(ws + w.zemb); float* nb = (float*)(ws + w.nb);
+    // training: the buffers whose final contents the tape keeps (hin, geo, rbuf, pp0, x1, the vector state at the layer boundaries) ARE
+    // their tape slots - the kernels write them in place of a device-to-device copy afterwards (round 4: 12 of the 25 copies per step)
+    auto slot = [&](size_t ws_off, size_t tape_off) -> float* { return train ? (float*)(tape + tape_off) : (float*)(ws + ws_off); };
+    float* x1 = slot(w.x1, to.x1); float* pp0 = slot(w.pp0, to.pp0); int* labels = (int*)(ws + w.labels);
+    float* hin = slot(w.hin, to.hin); float* zemb = (float*)(ws + w.zemb); float* nb = (float*)(ws + w.nb);
     float* s = (float*)(ws + w.s); float* s1 = (float*)(ws + w.s1); float* ne1 = (float*)(ws + w.ne1);
     float* xhb = (float*)(ws + w.xh); float* P = (float*)(ws + w.P); float* Q = (float*)(ws + w.Q);
-    float* xq = (float*)(ws + w.xq); float* vec = (float*)(ws + w.vec); float* v2buf = (float*)(ws + w.v2buf);
+    float* xq = (float*)(ws + w.xq); float* vec = slot(w.vec, to.vec_in[0]); float* v2buf = (float*)(ws + w.v2buf);
     float* scal = (float*)(ws + w.sc0); float* vdot = (float*)(ws + w.vdot);
-    float* geo = (float*)(ws + w.geo); double* d64 = (double*)(ws + w.d64); float* rbuf = (float*)(ws + w.rbuf);
+    float* geo = slot(w.geo, to.geo); double* d64 = (double*)(ws + w.d64); float* rbuf = slot(w.rbuf, to.rbuf);
     float* mbuf = (float*)(ws + w.mbuf); float* xmsg = (float*)(ws + w.xmsg);
     float* vmsg = (float*)(ws + w.vmsg); float* dpos = (float*)(ws + w.dpos); float* hout = (float*)(ws + w.hout);
     t_small = (w.small_a && !train) ? SmallScratch{(float*)(ws + w.small_a), (float*)(ws + w.small_b)} : SmallScratch{nullptr, nullptr};
     // edge state entering layer l (inference: one buffer updated in place)
     auto ew_at = [&](int l) -> float* { return train ? (float*)(tape + to.ew[l]) : (float*)(ws + w.ew); };
     float* ew = ew_at(0);
+    // scalar node state entering layer l / after the GCL node update of layer l (inference: one buffer updated in place)
+    auto s_at = [&](int l) -> float* { return train ? (float*)(tape + to.s_in[l]) : s; };
+    auto s_mid_at = [&](int l) -> float* { return train ? (float*)(tape + to.s_mid[l]) : s; };
 
     ObjPtrs op;
     memset(&op, 0, sizeof(op));
@@ -533,10 +539,6 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     const int node_variant = train ? 1 : g_node_variant;
     const bool gcl_skip = train || g_gcl_skip;
     const int stop_after = train ? 0 : g_stop_after;
-    auto copy = [&](size_t dst_off, const void* src, size_t bytes) {
-        return hipMemcpyAsync(tape + dst_off, src, bytes, hipMemcpyDeviceToDevice, st);
-    };
-
     LAUNCH(F_OTHER, k_prep, cdiv(N, 128), 128, st, tp, op, wb, pos, hin, t, t_scalar, cond,
            c->condition_nf > 0 ? c->condition_nf : 0, c->condition_time, emb);
     LAUNCH(F_INIT, k_geom, tp.n_groups, 64, st, tp, (const float*)pos, cutoff, pf64, pf32, x1, pp0, labels);
@@ -557,22 +559,15 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     constexpr int NW = D::HT <= 16 ? D::HT : 8;
     const unsigned gNb = (unsigned)cdiv(N, tp.npb);
     if (node_variant >= 1) {
-        LAUNCH(F_INIT, (k_neighbor_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s, s1);
+        LAUNCH(F_INIT, (k_neighbor_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s_at(0), s1);
         LAUNCH(F_INIT, (k_s2v_agg_v1<D, NW>), gNb, NW * 64, st, tp, (const float*)s1, (const float*)ew, (const float*)geo, ne1);
     } else {
-        LAUNCH(F_INIT, (k_neighbor<D>), gN, 256, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s, s1);
+        LAUNCH(F_INIT, (k_neighbor<D>), gN, 256, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s_at(0), s1);
         LAUNCH(F_INIT, (k_s2v_agg<D>), gN, 256, st, tp, (const float*)s1, (const float*)ew, (const float*)geo, ne1);
     }
     // small launches: one workgroup per (64 edges, hidden tile) instead of per 64 edges
     if (A > 0) LAUNCH2(F_INIT, (k_scalarize<D>), gA, (gA * topo->conc <= 2048 ? D::HT : 1), 256, st, tp, wb, po, (const float*)ne1, (const float*)geo, ew);
     HIP_TRY(hipMemsetAsync(vec, 0, (size_t)N * 3 * D::HP * sizeof(float), st));
-    if (train) {
-        HIP_TRY(copy(to.hin, hin, (size_t)N * 16 * 4));
-        HIP_TRY(copy(to.geo, geo, (size_t)(A + 1) * GEO_STRIDE * 4));
-        HIP_TRY(copy(to.rbuf, rbuf, (size_t)(A + 1) * D::RP * 4));
-        HIP_TRY(copy(to.pp0, pp0, (size_t)N * 4));
-        HIP_TRY(copy(to.x1, x1, (size_t)N * 3 * 4));
-    }
     if (stop_after == 1) return OARD_OK;
 
     float* vec2 = (float*)(ws + w.vec2);
@@ -584,12 +579,9 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
         const unsigned gN16 = (unsigned)cdiv(N, tp.npb);
         float* ew_in = ew_at(l);
         float* ew_out = ew_at(l + 1);
-        if (train) {
-            HIP_TRY(copy(to.s_in[l], s, (size_t)N * D::HP * 4));
-            HIP_TRY(copy(to.vec_in[l], vcur, (size_t)N * 3 * D::HP * 4));
-        }
+        if (train) vnext = (float*)(tape + to.vec_in[l + 1]);  // vcur == tape slot vec_in[l]
 
-        if (nv1) LAUNCH(F_NODE, (k_node_pre_v1<D, NW>), gN16, NW * 64, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
+        if (nv1) LAUNCH(F_NODE, (k_node_pre_v1<D, NW>), gN16, NW * 64, st, tp, wb, po, lo, (const float*)s_at(l), (const float*)pp0, xhb, P, Q);
         else LAUNCH(F_NODE, (k_node_pre<D>), gN, 256, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
         if (E > 0) {
             if (gcl_variant == 0) {
@@ -603,12 +595,11 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
             }
         }
         const bool rows = tp.npb <= 4;                       // small batches: gathers walk the rows with the wave's columns (row_lanes)
-        if (nv1 && rows) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW, true>), gN16, NW * 64, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq,
+        if (nv1 && rows) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW, true>), gN16, NW * 64, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s_mid_at(l), xq,
                                 train ? (float*)(tape + to.agg[l]) : nullptr);
-        else if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW, false>), gN16, NW * 64, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq,
+        else if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW, false>), gN16, NW * 64, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s_mid_at(l), xq,
                              train ? (float*)(tape + to.agg[l]) : nullptr);
         else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
-        if (train) HIP_TRY(copy(to.s_mid[l], s, (size_t)N * D::HP * 4));
         if (stop_after == 100 + 10 * l + 1) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
         if (equi_variant == 0) {
             if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew_out, (const float*)rbuf,
@@ -623,7 +614,7 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                 if (rc != OARD_OK) return rc;
             }
 #define EQUI_NODE_V1(ROWS_, XC_) LAUNCH(F_NODE, (k_equi_node_v1<D, NW, ROWS_, XC_>), gN16, NW * 64, st, tp, wb, lo, (const float*)vmsg, \
-                       (const float*)xq, (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext, \
+                       (const float*)xq, (const float*)geo, (const float*)x1, (const float*)s_mid_at(l), s_at(l + 1), (const float*)vcur, vnext, \
                        train ? (float*)(tape + to.s_a[l]) : nullptr, train ? (float*)(tape + to.vec_a[l]) : nullptr)
             if (nv1 && rows) {
                 if (lo.xcross) EQUI_NODE_V1(true, true); else EQUI_NODE_V1(true, false);
@@ -639,13 +630,9 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                          (const float*)v2buf, s, vcur);
         if (stop_after == 100 + 10 * l + 2) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
     }
-    topo->vec_final = (size_t)((char*)vcur - ws);
-    if (train) {
-        HIP_TRY(copy(to.s_in[c->num_layers], s, (size_t)N * D::HP * 4));
-        HIP_TRY(copy(to.vec_in[c->num_layers], vcur, (size_t)N * 3 * D::HP * 4));
-    }
+    if (!train) topo->vec_final = (size_t)((char*)vcur - ws);
     if (node_variant >= 1)
-        LAUNCH(F_NODE, (k_out_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)s, (const float*)vcur, dpos, hout, status);
+        LAUNCH(F_NODE, (k_out_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)s_at(c->num_layers), (const float*)vcur, dpos, hout, status);
     else
         LAUNCH(F_NODE, (k_out<D>), gN, 256, st, tp, wb, po, (const float*)s, (const float*)vcur, dpos, hout, status);
     LAUNCH(F_OTHER, k_post, cdiv(N, 128), 128, st, tp, op, wb, (const float*)dpos, (const float*)hout, emb);

@@ -413,9 +413,11 @@ template <class D, int WAVES, bool ROWS = false, bool XC = false>
 __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const float* __restrict__ wb, LayerOff lo,
                                                              const float* __restrict__ qbuf, const float* __restrict__ xq,
                                                              const float* __restrict__ geo, const float* __restrict__ x1,
-                                                             float* __restrict__ s, const float* __restrict__ vec_in,
+                                                             const float* s, float* s_out, const float* __restrict__ vec_in,
                                                              float* __restrict__ vec_out,
                                                              float* __restrict__ sa_out, float* __restrict__ va_out /* training tape: state after the aggregation, or NULL */) {
+    // s: scalar state entering the stage (s_mid), s_out: the state leaving it - the same buffer in inference (every element is read and
+    // later written by the same lane), the tape slots s_mid[l] / s_in[l + 1] in training
     constexpr int HT = D::HT;
     constexpr int TPW = (HT + WAVES - 1) / WAVES;            // tiles owned per wave (upper bound)
     __shared__ __attribute__((aligned(16))) float sm[6 * HT * 256 + 48 * 12];
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
             const int t = nb.wave + i * WAVES;
             if (t < HT && nb.valid) {
                 const f4 a = acc[3 * i], b = acc[3 * i + 1], c = acc[3 * i + 2];
-                st_blk(s, n, D::HP, t, nb.lane, lds_blk(in, t, nb.lane) + (a + b + vdk[i]) * inv_sqrt2);
+                st_blk(s_out, n, D::HP, t, nb.lane, lds_blk(in, t, nb.lane) + (a + b + vdk[i]) * inv_sqrt2);
 #pragma unroll
                 for (int x = 0; x < 3; ++x)
                     st_blk(vec_out, (size_t)n * 3 + x, D::HP, t, nb.lane,
