@@ -331,7 +331,8 @@ int oard_wgrad(const float* dY_dev, int ldY, int ncY, int o_len, int o_pad, int 
  * a table of device pointers in the canonical parameter order of oard_pack_weights (nn.Linear shapes; NULL entries are skipped;
  * encoders / decoders shared by several objects simply appear several times).  `params_dev` is the same table for the weights
  * themselves.  Node cotangents are [N][HP] / [3N][HP] float32 with zero pads, the edge-state cotangent is [E+1][WP].  All scratch
- * is the caller's (`oard_train_scratch_bytes`); nothing allocates or synchronises.  `packed_bwd_dev` = oard_pack_weights_bwd.
+ * is the caller's (`oard_train_scratch_bytes`); nothing synchronises, and the library's own job tables (the grouped weight-gradient
+ * launches) travel through a ring of pinned / device slots that is allocated once per device, at its first use.  `packed_bwd_dev` = oard_pack_weights_bwd.
  *   oard_train_tail_backward   grad_out[k] ([n_k][node_nf_k], reference rows; NULL = zero) -> ds, dvec of the final node state
  *   oard_train_layer_backward  one layer: ds / dvec / dew in place (cotangents of the layer's outputs -> of its inputs)
  *   oard_train_init_backward   ds0, dew (cotangents of the state entering layer 0) -> init-head and encoder gradients

@@ -8,6 +8,7 @@ import os
 from .build import LIB
 
 OARD_MAX_OBJECTS = 8
+ABI_VERSION = 2030            # OARD_VERSION of csrc/oard_hip.hip (checked by lib(): a stale library is refused, not misread)
 OARD_OK, OARD_EINVAL, OARD_ENOTCOMPLETE, OARD_EHIP, OARD_ENOMEM = 0, -1, -2, -3, -4
 ERRORS = {OARD_EINVAL: "invalid argument / unsupported configuration", OARD_ENOTCOMPLETE: "topology is not complete-per-sample",
           OARD_EHIP: "HIP runtime error", OARD_ENOMEM: "workspace too small"}
@@ -69,6 +70,10 @@ def lib() -> C.CDLL:
     vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
     cfgp = C.POINTER(OardConfig)
     L.oard_version.restype = C.c_int
+    got = L.oard_version()
+    if got != ABI_VERSION:      # e.g. an OARD_LIB override / ablation build that predates a change of oard_config: its fields would be misread
+        raise OardError(f"{LIB} has ABI version {got}, this package expects {ABI_VERSION}: rebuild it "
+                        "(`python -m oareactdiff_amd.build --force`, or the script that made the OARD_LIB build)")
     L.oard_supported.argtypes = [cfgp]; L.oard_supported.restype = C.c_int
     L.oard_param_count.argtypes = [cfgp]; L.oard_param_count.restype = sz
     L.oard_packed_bytes.argtypes = [cfgp]; L.oard_packed_bytes.restype = sz
@@ -131,7 +136,7 @@ def lib() -> C.CDLL:
     L.oard_timing_reset.argtypes = []; L.oard_timing_reset.restype = C.c_int
     L.oard_timing_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]; L.oard_timing_get.restype = C.c_int
     for env, opt in (("OARD_GCL_VARIANT", b"gcl_variant"), ("OARD_EQUI_VARIANT", b"equi_variant"),
-                     ("OARD_NODE_VARIANT", b"node_variant"), ("OARD_GCL_SKIP", b"gcl_skip"), ("OARD_PARTS", b"parts"), ("OARD_SEQUENTIAL", b"sequential"), ("OARD_POISON", b"poison"), ("OARD_AUTO_SMALL", b"auto_small"), ("OARD_AUTO_TINY", b"auto_tiny"), ("OARD_NPB", b"npb"),
+                     ("OARD_NODE_VARIANT", b"node_variant"), ("OARD_GCL_SKIP", b"gcl_skip"), ("OARD_GCL_PERSIST", b"gcl_persist"), ("OARD_GCL_GRID", b"gcl_grid"), ("OARD_PARTS", b"parts"), ("OARD_SEQUENTIAL", b"sequential"), ("OARD_POISON", b"poison"), ("OARD_AUTO_SMALL", b"auto_small"), ("OARD_AUTO_TINY", b"auto_tiny"), ("OARD_NPB", b"npb"),
                      ("OARD_WGRAD_WGS", b"wgrad_wgs"), ("OARD_WGRAD_LDS", b"wgrad_lds"), ("OARD_WGRAD_T16", b"wgrad_t16"), ("OARD_WGRAD_QUEUE", b"wgrad_queue"), ("OARD_GATE_FOLD", b"gate_fold"), ("OARD_WGRAD_SHAPES", b"wgrad_shapes"), ("OARD_TRAIN_DUAL", b"train_dual"), ("OARD_SMALL_SPLIT", b"small_split"),
                      ("OARD_SKIP_FAMILIES", b"skip_families")):
         if os.environ.get(env) not in (None, ""):

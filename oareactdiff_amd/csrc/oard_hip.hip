@@ -13,6 +13,7 @@
 
 #include "oard_kernels.h"
 #include "oard_edge_v1.h"
+#include "oard_edge_p.h"      // persistent form of the GCL throughput shape (round 5)
 #include "oard_wgrad_t16.h"
 #include "oard_edge_b3.h"     // split-precision (3 x bf16, fp32 accumulate) variant of the GCL edge kernel: optional (debug option gcl_b3)
 #ifdef OARD_EXPERIMENTS
@@ -23,7 +24,7 @@
 #include "oard_edge_bwd.h"
 #include "oard_node_bwd.h"
 
-#define OARD_VERSION 2020
+#define OARD_VERSION 2030
 
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "liboard_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
@@ -75,6 +76,9 @@ int g_wgrad_t16 = 256;       // workgroups per weight-gradient GEMM of the 16 x 
 int g_wgrad_lds = 256;       // workgroups per weight-gradient GEMM of the LDS-panel kernel (0: always the per-wave-tile kernel k_wgrad)
 int g_wgrad_wgs = 512;       // workgroups per weight-gradient GEMM (row chunks x task groups): one round of 2 x 4 waves per CU
                             // (measured per training step: 384 -> 38.1 ms, 512 -> 30.7, 768 -> 36.0, 1024 -> 33.2, 2048 -> 38.1)
+int g_gcl_persist = 1;      // the fp32 GCL throughput shape as a persistent workgroup (oard_edge_p.h); 0: one 128-edge tile per workgroup
+int g_gcl_grid = 0;         // workgroups per launch of the persistent kernel: 0 = auto (one per CU when the launch has the chip to itself,
+                            //    half of them when sub-batches run concurrently), > 0 = that many
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
 // Arithmetic of the two MFMA edge stages: oard_config::precision (OARD_PREC_* bits, include/oard.h) - a property of the CALL, read
@@ -347,6 +351,18 @@ int set_lds(K kernel, size_t bytes) {
 #define GCL_RING3(TRAIN_, tape_) do { \
         LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_v1<D, 8, 2, S1, S3, TRAIN_, 2, 3>), cdiv(r1 - r0, 16 * 8), 8 * 64, \
                    (GclStream<D, 2>::LDS_BYTES / 2 * 3), st, tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, tape_); return OARD_OK; } while (0)
+static int device_cus() {
+    static int cus[64] = {};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    if (!cus[d]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 256; }
+        cus[d] = n;
+    }
+    return cus[d];
+}
 template <class D, bool S1, bool S3>
 int launch_gcl_v1s(int prec, int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* P, const float* Q, const float* u0,
                    const float* c0, long long r0, long long r1, const float* ew_in, float* ew_out, float* mbuf, const GclTape* tape, hipStream_t st) {
@@ -378,6 +394,18 @@ int launch_gcl_v1s(int prec, int variant, int conc, const TopoDev& tp, const flo
             if (prec & OARD_PREC_GCL_BF16X3) {
                 LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_b3<D, S1, S3>), cdiv(r1 - r0, 16 * 8), 8 * 64, (GclB3Stream<D>::LDS_BYTES), st, tp,
                            wb + lo.gcl_b3, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{});
+                return OARD_OK;
+            }
+            // A launch that has the chip to itself runs as persistent workgroups over half-tiles (oard_edge_p.h; same arithmetic, bit-identical
+            // rows): its last round is balanced (isolated 9.01 -> 8.62 ms per B = 64 step).  Concurrent sub-batches keep one tile per workgroup:
+            // there the other streams' kernels fill the tail, and workgroups that hold a CU for several tiles make THEM wait (measured:
+            // 17.93 ms per step with tiles, 18.05 - 18.3 with 64 ... 256 persistent workgroups per launch; gcl_persist = 2 forces it).
+            if (g_gcl_persist > 1 || (g_gcl_persist == 1 && conc == 1)) {
+                const long long nhalf = cdiv(cdiv(r1 - r0, 16), 4);
+                // gcl_grid < 0: -k = k rounds (128-row tiles) per workgroup
+                const long long want = g_gcl_grid > 0 ? g_gcl_grid : (g_gcl_grid < 0 ? cdiv(nhalf, 2LL * -g_gcl_grid) : (conc > 1 ? std::max(1, device_cus() / 2) : device_cus()));
+                LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_p<D, S1, S3>), std::min(nhalf, want), 8 * 64, (GclStream<D, 2>::LDS_BYTES / 2 * 3), st,
+                           tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf);
                 return OARD_OK;
             }
             GCL_RING3(false, GclTape{});
@@ -1238,6 +1266,7 @@ int oard_topology_create_parts(const oard_config* c, const int64_t* cm, const in
     int n_parts = parts > 0 ? parts : (B >= 32 ? 4 : (B >= 16 ? 2 : 1));
     n_parts = std::max(1, std::min(std::min(n_parts, OARD_MAX_PARTS), B));
     oard_topology* tp = new oard_topology();
+    (void)hipGetDevice(&tp->device);
     tp->n_obj = n_obj; tp->B = B; tp->n_parts = n_parts;
     {   // reference-order tables of oard_topology_check_edge_index: sample, rank inside the sample, first edge id of every node
         std::vector<int> tab(2 * (size_t)N), seen(B, 0);
@@ -1280,6 +1309,12 @@ int oard_topology_create_parts(const oard_config* c, const int64_t* cm, const in
 
 void oard_topology_destroy(oard_topology* tp) {
     if (!tp) return;
+    // reached from Python __del__ with whatever device happens to be current: the pool, the streams and the events are per device, so the
+    // blocks go back under the device they were created on (a device-A block on device B's free list would be handed out as B's memory)
+    int cur = tp->device;
+    (void)hipGetDevice(&cur);
+    if (cur != tp->device) (void)hipSetDevice(tp->device);
+    struct Restore { int cur, dev; ~Restore() { if (cur != dev) (void)hipSetDevice(cur); } } restore_{cur, tp->device};
     // the side streams of a multi-part topology are joined into the caller's stream at the end of every call, so events on the
     // callers' streams cover their work as well
     for (int p = 0; p < OARD_MAX_PARTS; ++p) {
@@ -1712,7 +1747,7 @@ size_t oard_wgrad_scratch_bytes(int ncY, int ncX, int64_t rows) {
 // ---- queue of short weight-gradient products (grouped launches, oard_edge_bwd.h: k_wgrad_q / k_wgrad_reduce_q) --------------------------
 // Active while a sweep entry point runs with a queue installed (oard_train_stages.h): wgrad_impl appends the per-wave-tile products
 // (k_wgrad<false, 7>) instead of launching them; wgq_flush launches the whole table.  Partials live in the queue's own scratch
-// region, one slice per job.  Job tables are cached on the device by content (a training step repeats the same tables).
+// region, one slice per job.  Job tables are uploaded per flush through a ring of pinned / device slots (wgq_flush).
 struct WgQueue {
     std::vector<WgqJob> jobs;
     char* region = nullptr; size_t region_bytes = 0, used = 0;
@@ -1727,38 +1762,61 @@ struct WgQueueScope {           // installs a queue for the duration of one swee
 };
 int g_gate_fold = 1;         // 0: att_mlp gradient sums by column-sum passes over [E][H] instead of inside k_gcl_edge_bwd (A/B)
 int g_wgrad_queue = 1;       // 0: every product is launched on its own (A/B, bit-identical)
+// The job table of a flush travels like the topology tables do (round 5; it used to be cached on the device by content, and a real run
+// with ragged molecule sizes - a different `rows` in every job, every step - missed that cache on every flush: hipMalloc + a blocking
+// null-stream hipMemcpy per flush, a device-wide synchronisation every 256 flushes): a per-device ring of WGQ_SLOTS slots, each a pinned
+// host block + a device block for WGQ_MAX_JOBS jobs, allocated once; a flush fills the next slot's pinned block, enqueues ONE
+// hipMemcpyAsync on the queue's own stream in front of its two launches and records an event behind them.  A slot is reused only after
+// its event has fired - the host waits there only if WGQ_SLOTS flushes are still in flight (a training step has ~16).
+#define WGQ_SLOTS 64
+#define WGQ_MAX_JOBS 64
+struct WgqRing {
+    std::mutex mu;
+    WgqJob* host = nullptr;      // [WGQ_SLOTS][WGQ_MAX_JOBS] pinned
+    WgqJob* dev = nullptr;       // [WGQ_SLOTS][WGQ_MAX_JOBS]
+    hipEvent_t ev[WGQ_SLOTS] = {};
+    bool busy[WGQ_SLOTS] = {};
+    int next = 0;
+};
+static WgqRing& wgq_ring() {
+    static WgqRing rings[64];
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return rings[d & 63];
+}
 static int wgq_flush() {
     WgQueue* q = t_wgq;
     if (!q || q->jobs.empty()) return OARD_OK;
-    struct Cached { std::vector<WgqJob> host; WgqJob* dev = nullptr; };
-    static std::mutex mu;
-    static std::vector<Cached> cache[64];
-    int devid = 0;
-    (void)hipGetDevice(&devid);
+    if (q->jobs.size() > WGQ_MAX_JOBS) return OARD_EINVAL;
+    WgqRing& rg = wgq_ring();
     const WgqJob* table = nullptr;
+    int slot = 0;
     {
-        std::lock_guard<std::mutex> lk(mu);
-        std::vector<Cached>& cv = cache[devid & 63];
-        for (const Cached& c : cv)
-            if (c.host.size() == q->jobs.size() && memcmp(c.host.data(), q->jobs.data(), q->jobs.size() * sizeof(WgqJob)) == 0) { table = c.dev; break; }
-        if (!table) {
-            if (cv.size() >= 256) {          // tables of workspaces that are gone: start over (nothing in flight may read them any more)
-                HIP_TRY(hipDeviceSynchronize());
-                for (Cached& c : cv) (void)hipFree(c.dev);
-                cv.clear();
-            }
-            Cached c;
-            c.host = q->jobs;
-            HIP_TRY(hipMalloc(&c.dev, c.host.size() * sizeof(WgqJob)));
-            HIP_TRY(hipMemcpy(c.dev, c.host.data(), c.host.size() * sizeof(WgqJob), hipMemcpyHostToDevice));
-            table = c.dev;
-            cv.push_back(std::move(c));
+        std::lock_guard<std::mutex> lk(rg.mu);
+        if (!rg.host) {
+            const size_t bytes = (size_t)WGQ_SLOTS * WGQ_MAX_JOBS * sizeof(WgqJob);
+            HIP_TRY(hipHostMalloc((void**)&rg.host, bytes, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void**)&rg.dev, bytes));
+            for (int i = 0; i < WGQ_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&rg.ev[i], hipEventDisableTiming));
         }
+        slot = rg.next;
+        rg.next = (rg.next + 1) % WGQ_SLOTS;
+        if (rg.busy[slot]) HIP_TRY(hipEventSynchronize(rg.ev[slot]));      // only when WGQ_SLOTS flushes are still in flight
+        rg.busy[slot] = true;
+        WgqJob* h = rg.host + (size_t)slot * WGQ_MAX_JOBS;
+        WgqJob* dv = rg.dev + (size_t)slot * WGQ_MAX_JOBS;
+        memcpy(h, q->jobs.data(), q->jobs.size() * sizeof(WgqJob));
+        HIP_TRY(hipMemcpyAsync(dv, h, q->jobs.size() * sizeof(WgqJob), hipMemcpyHostToDevice, q->st));
+        table = dv;
     }
     {
         ScopedLaunch sl_(F_WGRAD, q->st);
         hipLaunchKernelGGL((k_wgrad_q<7>), dim3(q->blocks), dim3(256), 0, q->st, table, (int)q->jobs.size());
         hipLaunchKernelGGL(k_wgrad_reduce_q, dim3(q->rblocks), dim3(256), 0, q->st, table, (int)q->jobs.size());
+    }
+    {
+        std::lock_guard<std::mutex> lk(rg.mu);
+        HIP_TRY(hipEventRecord(rg.ev[slot], q->st));            // the slot's pinned and device blocks are free again behind the two launches
     }
     q->jobs.clear(); q->used = 0; q->blocks = q->rblocks = 0;
     HIP_TRY(hipGetLastError());
@@ -1793,7 +1851,7 @@ static int wgrad_impl(const float* dY, int ldY, int ncY, int o_len, int o_pad, i
         OARD_WGT_INSTANCES
 #undef X
         if (!launched) return OARD_EINVAL;
-        {
+        {   // k_wgrad_t16 leaves TILE-MAJOR partials (1-KiB register images): k_wgt_reduce is their only reducer (oard_wgrad_t16.h)
             ScopedLaunch sl_(F_WGRAD, st);
             hipLaunchKernelGGL(k_wgt_reduce, dim3((unsigned)(t.MT * t.NT)), dim3(256), 0, st, partial, t.n_chunks, t.MT, t.NT, t.transposed,
                                o_len, o_pad, MO, i_len, i_pad, MI, dW, ldW, db, db ? ones : -1, acc);
@@ -2132,6 +2190,8 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "equi_variant") == 0) { g_equi_variant = value; return OARD_OK; }
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
+    if (strcmp(name, "gcl_persist") == 0) { g_gcl_persist = value; return OARD_OK; }
+    if (strcmp(name, "gcl_grid") == 0) { g_gcl_grid = value; return OARD_OK; }
     if (strcmp(name, "skip_families") == 0) { g_skip_families = value; return OARD_OK; }
     if (strcmp(name, "parts") == 0) { g_parts = value; return OARD_OK; }
     if (strcmp(name, "sequential") == 0) { g_sequential = value; return OARD_OK; }

@@ -92,6 +92,7 @@ struct TopoPart {
     mutable size_t vec_final = 0;  // workspace offset (within the slice) of the vec buffer holding the final state
 };
 struct oard_topology {
+    int device = 0;                // HIP device the tables live on (oard_topology_destroy returns them to THAT device's pool)
     int n_parts = 0;
     TopoPart parts[OARD_MAX_PARTS];
     int n_obj = 0, B = 0;

@@ -29,9 +29,16 @@
 // Both operands of an MFMA step are plain ds_read_b32 (lane (g, i): row 4 s + g, feature 16 t + i of the panel; the panel's
 // row strides are = 16 mod 32 floats, so the two rows a 32-lane half reads sit in different banks): 13 reads per 42 MFMAs,
 // requested one step ahead.
-// Deterministic: fixed chunking, per-chunk partials, the fixed-order reduce passes of oard_edge_bwd.h (k_wgrad_reduce /
-// k_bgrad_reduce).  Layout of the partials: [chunk][PP][QP], P-major (P = the operand with more tiles), psum [chunk][PP],
-// qsum [chunk][QP] - exactly k_wgrad's, so the reduce passes are shared.
+// Deterministic: fixed chunking, per-chunk partials, ONE fixed-order reduce pass.  Layout of the partials: TILE-MAJOR -
+// partial[(chunk * MT + p_tile) * NT + q_tile] is a 1-KiB image of the accumulator registers of that 16 x 16 tile (lane (g, i),
+// register r: P feature 16 p_tile + 4 g + r, Q feature 16 q_tile + i), one coalesced store per tile.  This is NOT k_wgrad's
+// [chunk][PP][QP] layout: the only valid reducer is k_wgt_reduce (below), which sums the chunks in order and scatters dW and -
+// from the padded output column of the ones trick - db; handing these partials to k_wgrad_reduce / k_bgrad_reduce gives wrong
+// gradients without any error.
+// Precondition on the operands: their PAD columns (196 -> 208, 588 -> 592, 684 -> 688) are read and multiplied like any other
+// column (their products land in output rows / columns the reduce never reads, or - the ones column - are overwritten in LDS),
+// so they must hold FINITE values: a NaN / Inf bit pattern there would not reach dW, but 0 x Inf in the same MFMA would.  Every
+// producer in oard_train_stages.h writes zero pads; wgrad_impl's callers own that invariant.
 #pragma once
 #include "oard_edge_bwd.h"
 
@@ -61,7 +68,7 @@ struct WgtArgs {
     long long r0, r1, rpc;                 // rows [r0, r1), rows per chunk (multiple of WGT_R)
     int n_chunks;
     int ones_side, ones_col;               // 1 / 2: column ones_col of P / Q reads as 1.0 (bias gradient through X's pad column); 0: none
-    float* partial;                        // [n_chunks][16 MT][16 NT]
+    float* partial;                        // [n_chunks][MT][NT] tile images of 256 floats (tile-major; reducer: k_wgt_reduce ONLY)
 };
 
 // part k of `n` tiles cut into `parts` nearly equal pieces (the larger pieces first): [start, start + size)

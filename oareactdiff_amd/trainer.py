@@ -111,6 +111,8 @@ class DDPMTrainer:
                                   scales=scales)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.time_collectives = False                      # True: all_reduce_gradients brackets the collective with timing events (collective_report)
+        self._collective_events = []
         # the collectives run with more than one rank - or, for a smoke test of the RCCL path on a one-GPU box, whenever a process
         # group exists and OARD_FORCE_COLLECTIVES is set (a one-rank broadcast / all-reduce is the identity)
         self.collectives = self.world > 1 or (dist.is_available() and dist.is_initialized()
@@ -283,9 +285,27 @@ class DDPMTrainer:
         """DDP's gradient averaging as one collective over the flat bucket (sum, then / world).  The last element of the
         bucket is the step's non-finite flag: summed with the gradients, > 0 on every rank if any rank raised it."""
         if self.collectives:
+            ev = None
+            if self.time_collectives and self._bucket.is_cuda:      # bench.py: the collective's own device time, events on the step's stream
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM, group=self.group)
+            if ev is not None:
+                ev[1].record()
+                self._collective_events.append(ev)
             if self.world > 1:
                 self.flat_grad.div_(self.world)
+
+    def collective_report(self, reset: bool = True) -> Dict[str, float]:
+        """Mean device time of the gradient all-reduce over the steps since the last report (`time_collectives = True`; synchronises)."""
+        ms = []
+        for a, b in self._collective_events:
+            b.synchronize()
+            ms.append(a.elapsed_time(b))
+        if reset:
+            self._collective_events = []
+        return {"all_reduce_calls": len(ms), "all_reduce_ms_mean": sum(ms) / len(ms) if ms else None,
+                "all_reduce_ms_max": max(ms) if ms else None, "all_reduce_bytes": int(self._bucket.numel() * self._bucket.element_size())}
 
     def clip_gradients(self, grad_norm: Optional[float] = None) -> Tuple[float, float]:
         """pl_trainer.py:391-418: allow 150 % of the recent mean norm + 3 standard deviations."""

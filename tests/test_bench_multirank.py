@@ -32,6 +32,13 @@ def test_bench_two_ranks_gloo_dry_run():
     # MAX over ranks: rank 1 sleeps 4 ms per step, rank 0 only 2 ms
     assert d["ms_per_step"] >= 3.9
     assert abs(d["value"] - 2 * 64 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-6     # whole-job aggregate
+    # the line verifies itself: world size as the backend reports it, one entry per rank with its own clock / host / pid
+    rk = d["ranks"]
+    assert rk["backend"] == "gloo" and rk["world_size"] == 2 and rk["expected_world_size"] == 2
+    assert [r["rank"] for r in rk["per_rank"]] == [0, 1] and len({r["pid"] for r in rk["per_rank"]}) == 2
+    assert rk["per_rank"][1]["busy_ms_per_step"] >= 3.9 > rk["per_rank"][0]["busy_ms_per_step"] >= 1.9 and rk["slowest_rank"] == 1
+    assert abs(max(r["ms_per_step"] for r in rk["per_rank"]) - d["ms_per_step"]) < 1e-6
+    assert all(k in rk["per_rank"][0] for k in ("device_index", "pci_bus_id", "device_name", "host", "local_rank"))
 
 
 import pytest  # noqa: E402
@@ -73,6 +80,9 @@ def test_bench_train_mode_two_ranks_under_the_launcher():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["metric"] == "training_steps_per_sec" and "all-reduce" in d["config"]["parallelism"]
+    rk = d["ranks"]                                          # train mode: the collective's own time and size, per rank
+    assert rk["world_size"] == 2 and len(rk["per_rank"]) == 2
+    assert all(r["all_reduce_bytes"] == 4096 and r["all_reduce_ms_mean"] > 0 for r in rk["per_rank"])
 
 
 def test_bench_single_process_dry_run():

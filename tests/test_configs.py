@@ -58,6 +58,30 @@ def test_benched_launch_reproduces_the_golden_reactions(parts):
         assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
 
 
+def test_benched_launch_persistent_and_tile_gcl_kernels_agree():
+    """The B = 64 launch bench.py times, as ONE sub-batch (the setting of `roofline`, where the persistent GCL kernel runs: 256
+    workgroups, shares of 18 / 19 half-tiles) against the tile kernel: the same numbers to the last bits (one difference in the
+    summation order of S1, csrc/oard_edge_p.h), and the persistent kernel bit-identical to itself on 97 workgroups."""
+    dev = torch.device("cuda:0")
+    c = Case("g2_prod_b2_n23")
+    B, nf = 64, 23
+    outs = []
+    for persist, grid in ((0, 0), (1, 0), (1, 97)):
+        with debug_options(parts=1, gcl_persist=persist, gcl_grid=grid):
+            dyn, _, _ = _prod_dynamics(dev, c.cfg)
+            cm, nfs, ei, masks = make_topology(B, nf)
+            xh = make_inputs(B, nf, masks, 99, "cpu")
+            g = torch.Generator().manual_seed(1)
+            t, cond = torch.rand(B, 1, generator=g), torch.rand(B, 1, generator=g)
+            with torch.no_grad():
+                out, _ = dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+            torch.cuda.synchronize()
+            outs.append([o.clone() for o in out])
+    for a, b, c2 in zip(*outs):
+        assert bool(torch.isfinite(a).all()) and torch.equal(b, c2)
+        assert (a - b).abs().max() <= 2e-6 * float(a.abs().max())
+
+
 def test_config1_single_reaction_t50_sampler():
     """BASELINE configs[0]: B=1, 20 atoms per object, T=50 polynomial_2, production dims.  The device sampler follows a
     float64 replay of the same noise over the 51 network calls (accumulated tolerance 5e-5), and every single network

@@ -335,16 +335,19 @@ def test_condition_and_time_change_the_output():
     assert (o0[k] - o1[k]).abs().max() > 1e-6 and (o0[k] - o2[k]).abs().max() > 1e-6
 
 
+@pytest.mark.parametrize("persist", [0, 2])
 @pytest.mark.parametrize("parts", [2, 3])
-def test_concurrent_sub_batches_are_bitwise_identical(parts):
+def test_concurrent_sub_batches_are_bitwise_identical(parts, persist):
     """oard_forward may split a batch into independent sub-batches that run on internal streams; reactions
-    never interact, so the result must be bit-identical to the single-part run."""
+    never interact, so the result must be bit-identical to the single-part run (with the same GCL edge kernel on both sides:
+    by default a single-part launch takes the persistent one, which sums S1 in a different order)."""
     from oareactdiff_amd import _capi
     dev = torch.device("cuda:0")
     c = Case("g3_cutoff_ragged")                      # three samples of different size
     L = _capi.lib()
     outs = []
     try:
+        L.oard_debug_option(b"gcl_persist", persist)
         for p in (1, parts):
             L.oard_debug_option(b"parts", p)
             dyn = _dyn(c, dev)
@@ -354,11 +357,39 @@ def test_concurrent_sub_batches_are_bitwise_identical(parts):
             outs.append([x.clone() for x in o])
     finally:
         L.oard_debug_option(b"parts", 0)
+        L.oard_debug_option(b"gcl_persist", 1)
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     v, h = c.split([o.cpu() for o in outs[1]])
     rv, rh = c.split(c.ref64)
     assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
+
+
+@pytest.mark.parametrize("name", ["g3_cutoff_ragged", "g2_prod_b2_n23"])
+def test_persistent_gcl_kernel_against_the_tile_kernel_and_over_grid_sizes(name):
+    """k_gcl_edge_p (csrc/oard_edge_p.h: persistent workgroups over half-tiles, balanced last round) against k_gcl_edge_v1 (one
+    128-edge tile per workgroup).  Same arithmetic; the one difference is where P[src] + Q[tgt] enters the sum of S1 (behind
+    the W1c product instead of in front of it), so the two agree to the last bits, not bit for bit - and the persistent kernel must
+    be bit-identical to ITSELF whatever the grid: 1 / 3 / 5 workgroups (shares of many rounds that end in full or half rounds),
+    one per CU, two tiles per workgroup (-2); the small cases make every share ragged (rows % 64 != 0, padding wave-tiles)."""
+    dev = torch.device("cuda:0")
+    c = Case(name)
+    rv, rh = c.split(c.ref64)
+    outs = {}
+    for persist, grid in ((0, 0), (2, 0), (2, 1), (2, 3), (2, 5), (2, -2)):      # 2: also when sub-batches run concurrently
+        with debug_options(gcl_persist=persist, gcl_grid=grid):
+            dyn = _dyn(c, dev)
+            with torch.no_grad():
+                o, _ = dyn(*_args(c, dev))
+            torch.cuda.synchronize()
+            outs[(persist, grid)] = [x.clone() for x in o]
+        v, h = c.split([x.cpu() for x in outs[(persist, grid)]])
+        assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
+    for grid in (1, 3, 5, -2):
+        for a, b in zip(outs[(2, 0)], outs[(2, grid)]):
+            assert torch.equal(a, b)
+    for a, b in zip(outs[(0, 0)], outs[(2, 0)]):
+        assert (a - b).abs().max() <= 2e-6 * max(float(a.abs().max()), 1e-6)
 
 
 @pytest.mark.parametrize("opts", [
