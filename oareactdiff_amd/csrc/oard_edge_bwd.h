@@ -811,12 +811,15 @@ __global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ d
 // Fixed-order sum of one value over the chunks by ONE WAVE: lane l adds chunks l, l + 64, ... in ascending order, then the 64
 // lane sums are combined by a fixed butterfly - deterministic, and ~n_chunks / 64 dependent loads per thread instead of n_chunks
 // (a single thread walking 1024 partials took 200 us per call: 18 + 24 such calls per training step).
+// Accumulated in float64 (round 5): these are sums of up to ~19 000 partials per output, and for cancellation-heavy outputs - the att_mlp
+// bias gradient is ONE scalar, the sum of a signed value over every edge - a float32 accumulator left 8e-6 ... 1.1e-5 of relative error
+// by itself (tests/test_grad_stages.py sat on its 1e-5 gate).  A few thousand float64 adds per training step.
 OARD_DEV float chunk_sum_wave(const float* __restrict__ p, size_t stride, int n_chunks, int lane) {
-    float s = 0.f;
-    for (int ch = lane; ch < n_chunks; ch += 64) s += p[(size_t)ch * stride];
+    double s = 0.0;
+    for (int ch = lane; ch < n_chunks; ch += 64) s += (double)p[(size_t)ch * stride];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    return s;
+    return (float)s;
 }
 // dW [MO][MI] and db [MO] from the small kernel's partials: one wave per output
 // ldW: row stride of the destination (a column slice of a wider nn.Linear weight); acc: add to the destination instead of overwriting

@@ -25,6 +25,14 @@
 #include "oard_node_bwd.h"
 
 #define OARD_VERSION 2030
+// The first-generation kernels (weights straight from L2, one wave per 16 nodes: gcl_variant / equi_variant / node_variant 0) are the
+// A/B baseline of round 1 and a cross-check in tests/test_hip_parity.py::test_every_kernel_variant_is_parity_green; they are compiled
+// into experiment builds (-DOARD_EXPERIMENTS) only - a product library refuses those variants (oard_debug_option returns OARD_EINVAL).
+#ifdef OARD_EXPERIMENTS
+static constexpr bool kV0 = true;
+#else
+static constexpr bool kV0 = false;
+#endif
 
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "liboard_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
@@ -589,10 +597,10 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     if (node_variant >= 1) {
         LAUNCH(F_INIT, (k_neighbor_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s_at(0), s1);
         LAUNCH(F_INIT, (k_s2v_agg_v1<D, NW>), gNb, NW * 64, st, tp, (const float*)s1, (const float*)ew, (const float*)geo, ne1);
-    } else {
+    } else if constexpr (kV0) {
         LAUNCH(F_INIT, (k_neighbor<D>), gN, 256, st, tp, wb, po, (const float*)zemb, (const float*)nb, (const float*)ew, s_at(0), s1);
         LAUNCH(F_INIT, (k_s2v_agg<D>), gN, 256, st, tp, (const float*)s1, (const float*)ew, (const float*)geo, ne1);
-    }
+    } else return OARD_EINVAL;
     // small launches: one workgroup per (64 edges, hidden tile) instead of per 64 edges
     if (A > 0) LAUNCH2(F_INIT, (k_scalarize<D>), gA, (gA * topo->conc <= 2048 ? D::HT : 1), 256, st, tp, wb, po, (const float*)ne1, (const float*)geo, ew);
     HIP_TRY(hipMemsetAsync(vec, 0, (size_t)N * 3 * D::HP * sizeof(float), st));
@@ -610,10 +618,12 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
         if (train) vnext = (float*)(tape + to.vec_in[l + 1]);  // vcur == tape slot vec_in[l]
 
         if (nv1) LAUNCH(F_NODE, (k_node_pre_v1<D, NW>), gN16, NW * 64, st, tp, wb, po, lo, (const float*)s_at(l), (const float*)pp0, xhb, P, Q);
-        else LAUNCH(F_NODE, (k_node_pre<D>), gN, 256, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
+        else if constexpr (kV0) LAUNCH(F_NODE, (k_node_pre<D>), gN, 256, st, tp, wb, po, lo, (const float*)s, (const float*)pp0, xhb, P, Q);
+        else return OARD_EINVAL;
         if (E > 0) {
             if (gcl_variant == 0) {
-                LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew_in, mbuf);
+                if constexpr (kV0) LAUNCH(F_GCL_EDGE, (k_gcl_edge<D>), gE, 256, st, tp, wb, lo, (const float*)P, (const float*)Q, ew_in, mbuf);
+                else return OARD_EINVAL;
             } else {
                 GclTape gt{};
                 if (train) gt = GclTape{(float*)(tape + to.z1[l]), (float*)(tape + to.z2[l]), (float*)(tape + to.att[l]), (float*)(tape + to.z3[l])};
@@ -627,13 +637,16 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                                 train ? (float*)(tape + to.agg[l]) : nullptr);
         else if (nv1) LAUNCH(F_NODE, (k_gcl_node_v1<D, NW, false>), gN16, NW * 64, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s_mid_at(l), xq,
                              train ? (float*)(tape + to.agg[l]) : nullptr);
-        else LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
+        else if constexpr (kV0) LAUNCH(F_NODE, (k_gcl_node<D>), gN, 256, st, tp, wb, lo, (const float*)xhb, (const float*)mbuf, s, xq);
+        else return OARD_EINVAL;
         if (stop_after == 100 + 10 * l + 1) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
         if (equi_variant == 0) {
-            if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew_out, (const float*)rbuf,
-                              (const float*)geo, (const float*)xq, (const float*)vcur, xmsg, vmsg);
-            LAUNCH(F_NODE, (k_equi_agg<D>), gN, 256, st, tp, wb, lo, (const float*)xmsg, (const float*)vmsg, (const float*)x1,
-                   s, vcur, v2buf, scal, vdot);
+            if constexpr (kV0) {
+                if (A > 0) LAUNCH(F_EQUI_EDGE, (k_equi_edge<D>), gA, 256, st, tp, wb, lo, (const float*)ew_out, (const float*)rbuf,
+                                  (const float*)geo, (const float*)xq, (const float*)vcur, xmsg, vmsg);
+                LAUNCH(F_NODE, (k_equi_agg<D>), gN, 256, st, tp, wb, lo, (const float*)xmsg, (const float*)vmsg, (const float*)x1,
+                       s, vcur, v2buf, scal, vdot);
+            } else return OARD_EINVAL;
         } else {
             if (A > 0) {
                 int rc = launch_equi_v1<D>(c->precision, equi_variant, topo->conc, tp, wb, lo, wb + lo.equi_stream, wb + lo.dp0b, ew_out, rbuf, vmsg,
@@ -648,21 +661,24 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
                 if (lo.xcross) EQUI_NODE_V1(true, true); else EQUI_NODE_V1(true, false);
             } else if (nv1) {
                 if (lo.xcross) EQUI_NODE_V1(false, true); else EQUI_NODE_V1(false, false);
-            } else {
+            } else if constexpr (kV0) {
                 LAUNCH(F_NODE, (k_equi_agg_v1<D>), gN, 256, st, tp, wb, lo, (const float*)vmsg, (const float*)xq,
                        (const float*)geo, (const float*)x1, s, (const float*)vcur, vnext, v2buf, scal, vdot);
-            }
+            } else return OARD_EINVAL;
             std::swap(vcur, vnext);
         }
-        if (!nv1) LAUNCH(F_NODE, (k_equi_upd<D>), gN, 256, st, tp, wb, lo, (const float*)scal, (const float*)vdot,
-                         (const float*)v2buf, s, vcur);
+        if constexpr (kV0) {
+            if (!nv1) LAUNCH(F_NODE, (k_equi_upd<D>), gN, 256, st, tp, wb, lo, (const float*)scal, (const float*)vdot,
+                             (const float*)v2buf, s, vcur);
+        }
         if (stop_after == 100 + 10 * l + 2) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
     }
     if (!train) topo->vec_final = (size_t)((char*)vcur - ws);
     if (node_variant >= 1)
         LAUNCH(F_NODE, (k_out_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)s_at(c->num_layers), (const float*)vcur, dpos, hout, status);
-    else
+    else if constexpr (kV0)
         LAUNCH(F_NODE, (k_out<D>), gN, 256, st, tp, wb, po, (const float*)s, (const float*)vcur, dpos, hout, status);
+    else return OARD_EINVAL;
     LAUNCH(F_OTHER, k_post, cdiv(N, 128), 128, st, tp, op, wb, (const float*)dpos, (const float*)hout, emb);
     HIP_TRY(hipGetLastError());
     return OARD_OK;
@@ -2186,9 +2202,12 @@ int oard_tap(const oard_config* c, const oard_topology* topo, const void* ws_, i
 int oard_debug_stop_after(int code) { g_stop_after = code; return OARD_OK; }
 int oard_debug_option(const char* name, int value) {
     if (!name) return OARD_EINVAL;
+    if (!kV0 && value == 0 && (strcmp(name, "gcl_variant") == 0 || strcmp(name, "equi_variant") == 0 || strcmp(name, "node_variant") == 0))
+        return OARD_EINVAL;                      // the first-generation kernels exist in experiment builds only
     if (strcmp(name, "gcl_variant") == 0) { g_gcl_variant = value; return OARD_OK; }
     if (strcmp(name, "equi_variant") == 0) { g_equi_variant = value; return OARD_OK; }
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
+    if (strcmp(name, "experiments") == 0) return kV0 ? OARD_OK : OARD_EINVAL;      // query: is this an experiment build?
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
     if (strcmp(name, "gcl_persist") == 0) { g_gcl_persist = value; return OARD_OK; }
     if (strcmp(name, "gcl_grid") == 0) { g_gcl_grid = value; return OARD_OK; }

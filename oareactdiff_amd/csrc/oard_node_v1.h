@@ -58,6 +58,14 @@ OARD_DEV TileJob tile_job(const float* __restrict__ wp, int t, const float* in) 
 #ifndef OARD_NODE_SEQ_G
 #define OARD_NODE_SEQ_G 7       // chunks per pipeline step
 #endif
+// k_node_pre_v1 / k_gcl_node_v1 run at 84 / 94 registers of their 128: a longer step puts more weight chunks in flight per L2 round trip
+// (these stages wait for their weight fetches, ~1.7 us per step, not for their MFMAs) - round 5
+#ifndef OARD_NODE_PRE_G
+#define OARD_NODE_PRE_G 10
+#endif
+#ifndef OARD_GCL_NODE_G
+#define OARD_GCL_NODE_G 10
+#endif
 // R = ring depth: the chunks of steps s+1 .. s+R-1 are in flight while step s issues its MFMAs ((R-1) x G x 4 VGPRs in flight,
 // R x G x 4 held).  R = 2 is the node kernels' shape (register budget of 13-wave workgroups); the latency edge kernels use R = 4:
 // with 7 chunks per step one step's MFMAs take ~0.4 us and an L2 round trip ~1.5 us, so three steps have to be in flight.
@@ -89,6 +97,65 @@ OARD_DEV void dense_seq(const TileJob (&job)[N], int lane, f4 (&acc)[N]) {
             }
         if (q == NG - 1) { acc[j] += c1; c1 = f4zero(); }
     }
+}
+// The same pipeline for tiles whose weights are applied to THREE input vectors (the x, y, z components of `vec` under vec_proj /
+// vec1_proj): job[j].in is the first input, the others follow at STRIDE floats; acc[3 j + k] belongs to input k.  Every weight
+// chunk is fetched ONCE and feeds 3 x 4 MFMAs - as separate jobs the three components re-fetched the same chunks, and these stages
+// are bound by the L2 round trips of their weight fetches, not by their MFMAs (round 5: 78 -> 26 chunk fetches per wave in
+// k_equi_node_v1's vec_proj).  One accumulator per (tile, input): the K blocks are summed in order (dense_seq sums even and odd
+// blocks separately - a last-bit difference).
+// The three B operands of a chunk are read by ONE volatile asm statement: written as plain LDS loads, hipcc moves the 3 x G reads of a
+// step - and, where two jobs share their inputs, the second job's as well - to the top of the block and spills them (660 bytes per lane in
+// k_equi_node_v1 at its 128-register cap; sched_barrier does not stop it, the motion happens before instruction scheduling).
+template <int STRIDE>
+OARD_DEV void lds_blk3(const float* in, int b, int lane, f4& x0, f4& x1, f4& x2) {
+    const unsigned addr = (unsigned)(size_t)(in + b * 256 + lane * 4);          // LDS byte address = low half of the generic pointer
+    static_assert(2 * STRIDE * 4 < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%4\n\tds_read_b128 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2) : "v"(addr), "n"(STRIDE * 4), "n"(2 * STRIDE * 4) : "memory");
+}
+// ... and the MFMAs are volatile asm statements as well (accumulator in place): as builtins hipcc regroups the three chains of a chunk by
+// accumulator - all chunks of x first, y and z operands parked in scratch meanwhile.  Volatile asm keeps program order.
+// (The hazard recogniser does not know these statements are MFMAs: the leading s_nop covers "VALU writes a VGPR -> XDL reads it as SrcC"
+// - hipcc zero-initialises an accumulator with v_mov right in front of its first MFMA; found as a 1e-3 error of dpos at H = 32.)
+OARD_DEV void mma_chunk_pinned(f4 a, f4 b, f4& acc) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %1, %5, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %2, %6, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %7, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0"
+                 : "+v"(acc) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+}
+template <int KB, int N, int STRIDE, int G = OARD_NODE_SEQ_G, int R = 2>
+OARD_DEV void dense_seq_xyz(const TileJob (&job)[N], int lane, f4 (&acc)[N * 3]) {
+    constexpr int NG = (KB + G - 1) / G, S = N * NG;
+    f4 a[R][G];
+    auto fetch = [&](int st) {
+        const int j1 = st / NG, q1 = st % NG;
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (q1 * G + i < KB) a[st % R][i] = ld_f4(job[j1].w + (size_t)(q1 * G + i) * 256 + lane * 4);
+    };
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st)
+        if (st < S) fetch(st);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+        const int j = st / NG, q = st % NG;
+        if (st + R - 1 < S) fetch(st + R - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (q * G + i < KB) {
+                f4 x0, x1, x2;
+                lds_blk3<STRIDE>(job[j].in, q * G + i, lane, x0, x1, x2);
+                mma_chunk_pinned(a[st % R][i], x0, acc[3 * j + 0]);
+                mma_chunk_pinned(a[st % R][i], x1, acc[3 * j + 1]);
+                mma_chunk_pinned(a[st % R][i], x2, acc[3 * j + 2]);
+            }
+    }
+    // the hazard recogniser does not look inside asm statements: cover the XDL-write -> VALU-read distance of the last MFMAs by hand
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
 }
 // LayerNorm statistics of an LDS vector (every wave computes them redundantly)
 template <int HT, int H>
@@ -198,7 +265,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_node_pre_v1(TopoDev tp, const fl
             job[i] = tile_job<D::PB>(wb + po.pe1, t, hid);
             acc[i] = ld_blk(s, nb.n, D::HP, t, nb.lane);
         }
-        dense_seq<D::PB, TPW>(job, nb.lane, acc);
+        dense_seq<D::PB, TPW, OARD_NODE_PRE_G>(job, nb.lane, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
             if (nb.wave + i * WAVES < D::HT) lds_st(sv, nb.wave + i * WAVES, nb.lane, acc[i]);
@@ -221,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_node_pre_v1(TopoDev tp, const fl
             job[i] = t < D::HT ? tile_job<D::HT>(wb + lo.W1a, t, xv) : tile_job<D::HT>(wb + lo.W1b, t - D::HT, xv);
             acc[i] = t < D::HT ? ld_vec(wb + lo.b1, t, nb.lane) : f4zero();
         }
-        dense_seq<D::HT, TPW2>(job, nb.lane, acc);
+        dense_seq<D::HT, TPW2, OARD_NODE_PRE_G>(job, nb.lane, acc);
 #pragma unroll
         for (int i = 0; i < TPW2; ++i) {
             const int t = nb.wave + i * WAVES;
@@ -296,7 +363,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
         f4 acc[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) { job[i] = tile_job<2 * D::HT>(wb + lo.nm0, tw[i], in); acc[i] = ld_vec(wb + lo.nm0b, tw[i], nb.lane); }
-        dense_seq<2 * D::HT, TPW>(job, nb.lane, acc);
+        dense_seq<2 * D::HT, TPW, OARD_GCL_NODE_G>(job, nb.lane, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
             if (nb.wave + i * WAVES < D::HT) lds_st(hm, tw[i], nb.lane, silu4(acc[i]));
@@ -307,7 +374,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
         f4 acc[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) { job[i] = tile_job<D::HT>(wb + lo.nm1, tw[i], hm); acc[i] = ld_vec(wb + lo.nm1b, tw[i], nb.lane); }
-        dense_seq<D::HT, TPW>(job, nb.lane, acc);
+        dense_seq<D::HT, TPW, OARD_GCL_NODE_G>(job, nb.lane, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
             if (nb.wave + i * WAVES < D::HT) {
@@ -329,7 +396,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
         f4 acc[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) { job[i] = tile_job<D::HT>(wb + lo.xp0, tw[i], xln); acc[i] = f4zero(); }
-        dense_seq<D::HT, TPW>(job, nb.lane, acc);
+        dense_seq<D::HT, TPW, OARD_GCL_NODE_G>(job, nb.lane, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
             if (nb.wave + i * WAVES < D::HT) lds_st(hq, tw[i], nb.lane, silu4(acc[i]));
@@ -343,7 +410,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gcl_node_v1(TopoDev tp, const fl
             job[i] = tile_job<D::HT>(wb + lo.xp2, min(nb.wave + i * WAVES, 3 * D::HT - 1), hq);
             acc[i] = f4zero();
         }
-        dense_seq<D::HT, TPW3>(job, nb.lane, acc);
+        dense_seq<D::HT, TPW3, OARD_GCL_NODE_G>(job, nb.lane, acc);
 #pragma unroll
         for (int i = 0; i < TPW3; ++i)
             if (nb.wave + i * WAVES < 3 * D::HT && nb.valid) st_blk(xq, nb.n, 3 * D::HP, nb.wave + i * WAVES, nb.lane, acc[i]);
@@ -540,16 +607,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
     for (int i = 0; i < TPW; ++i) {
         const int t = nb.wave + i * WAVES;
         if (t < HT) {                                    // wave-uniform
-            TileJob job[6];
+            TileJob job[2] = {tile_job<HT>(wb + lo.vp, t, vx), tile_job<HT>(wb + lo.vp, HT + t, vx)};   // each chunk feeds x, y and z
             f4 acc[6];
 #pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                job[2 * x] = tile_job<HT>(wb + lo.vp, t, vx + x * HT * 256);
-                job[2 * x + 1] = tile_job<HT>(wb + lo.vp, HT + t, vx + x * HT * 256);
-                acc[2 * x] = f4zero(); acc[2 * x + 1] = f4zero();
-            }
-            dense_seq<HT, 6, (ROWS ? 5 : OARD_NODE_SEQ_G)>(job, nb.lane, acc);      // 5: no scratch in the small-batch instantiation
-            const f4 v1[3] = {acc[0], acc[2], acc[4]}, v2[3] = {acc[1], acc[3], acc[5]};
+            for (int k = 0; k < 6; ++k) acc[k] = f4zero();
+            dense_seq_xyz<HT, 2, HT * 256, (ROWS ? 5 : OARD_NODE_SEQ_G)>(job, nb.lane, acc);   // 5: no scratch in the small-batch instantiation
+            const f4 v1[3] = {acc[0], acc[1], acc[2]}, v2[3] = {acc[3], acc[4], acc[5]};
 #pragma unroll
             for (int x = 0; x < 3; ++x) v2k[i][x] = v2[x];
             const f4 sc = v1[0] * fx + v1[1] * fy + v1[2] * fz;
@@ -765,16 +828,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_out_v1(TopoDev tp, const float* 
     }
     __syncthreads();
     {
-        TileJob job[3 * TPW];
+        TileJob job[TPW];
         f4 acc[3 * TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i)
+        for (int i = 0; i < TPW; ++i) {
+            job[i] = tile_job<HT>(wb + po.v1p, min(nb.wave + i * WAVES, HT - 1), vx);
 #pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                job[3 * i + x] = tile_job<HT>(wb + po.v1p, min(nb.wave + i * WAVES, HT - 1), vx + x * HT * 256);
-                acc[3 * i + x] = f4zero();
-            }
-        dense_seq<HT, 3 * TPW>(job, nb.lane, acc);
+            for (int x = 0; x < 3; ++x) acc[3 * i + x] = f4zero();
+        }
+        dense_seq_xyz<HT, TPW, HT * 256>(job, nb.lane, acc);       // every chunk of vec1_proj feeds x, y and z
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
             if (nb.wave + i * WAVES < HT) {

@@ -270,24 +270,28 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X
 #define CSL_ROWS_SHORT 32
 __global__ __launch_bounds__(256) void k_colsum_long(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
                                                      const float* __restrict__ wrow, int x_silu, float* __restrict__ part, int rows_per_block) {
-    __shared__ f4 red[256];
+    // float64 accumulators (round 5): the att_mlp gradients are sums of a signed value over every edge whose terms largely cancel (condition
+    // ~ sqrt(E)); with float32 running sums the bias gradient - one scalar - carried ~1e-5 of relative error.  The kernel is bound by its loads.
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    __shared__ d4 red[256];
     const int nc4 = ncols >> 2, RL = 256 / nc4, rl = threadIdx.x / nc4, c4 = threadIdx.x - rl * nc4;
     const long long rb = r0 + (long long)blockIdx.x * rows_per_block, re = rb + rows_per_block < r1 ? rb + rows_per_block : r1;
-    f4 s = f4zero();
+    d4 s = {0.0, 0.0, 0.0, 0.0};
     if (rl < RL) {
         const float* p = X + 4 * c4;
 #pragma unroll 4
         for (long long r = rb + rl; r < re; r += RL) {
             f4 v = ld_f4(p + (size_t)r * ld);
             if (x_silu) v = silu4(v);
-            s += wrow != nullptr ? v * wrow[r] : v;
+            if (wrow != nullptr) v = v * wrow[r];
+            s += (d4){(double)v.x, (double)v.y, (double)v.z, (double)v.w};
         }
     }
     red[threadIdx.x] = s;
     __syncthreads();
     if (rl == 0) {
         for (int k = 1; k < RL; ++k) s += red[k * nc4 + c4];
-        st_f4(part + (size_t)blockIdx.x * ncols + 4 * c4, s);
+        st_f4(part + (size_t)blockIdx.x * ncols + 4 * c4, (f4){(float)s.x, (float)s.y, (float)s.z, (float)s.w});
     }
 }
 // narrow matrices (ncols <= 16, e.g. the [items][12] operand of the frame-scalar MLP's last layer): one thread per ROW slice instead

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Soak of the GPU suite (run on the GPU box): `pytest -m gpu` N times under each of the three environments the library ships for -
+# the suite's pinned launch shapes (default), the library's own launch-shape heuristics (OARD_TEST_SHAPES=auto), the split-precision
+# edge kernels (OARD_GCL_B3 / OARD_EQUI_B3 / OARD_TRAIN_B3) - plus the first-generation kernels on an experiment build.
+# An ordering bug (a missing stream join, a scratch buffer reused too early) shows up as a run that fails once in a few: one line
+# per run, pass / fail counts, into gpurun_out/<tag>_soak.txt.     usage: tools/soak_tests.sh [tag] [runs per environment]
+tag=${1:-round5}; n=${2:-5}
+out=gpurun_out/${tag}_soak.txt
+mkdir -p gpurun_out; : > $out
+run() {   # name, env...
+  local name=$1; shift
+  for i in $(seq 1 $n); do
+    line=$(env "$@" timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -1)
+    echo "$name run $i: $line" | tee -a $out
+  done
+}
+run default OARD_SOAK=1
+run shapes_auto OARD_TEST_SHAPES=auto
+run split_precision OARD_GCL_B3=1 OARD_EQUI_B3=1 OARD_TRAIN_B3=1
+# the first-generation (v0) kernels only exist in an experiment build: build it here (hipcc is on the box), run the variant test on it
+exp=$GRAFT_REPO_ROOT/oareactdiff_amd/csrc/liboard_exp.so
+if [ ! -f $exp ]; then
+  (cd oareactdiff_amd/csrc && timeout 900 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-result \
+     "-DOARD_DIMS_LIST=X(196,96)X(32,8)X(32,32)" -DOARD_EXPERIMENTS oard_hip.hip -o liboard_exp.so) > gpurun_out/${tag}_exp_build.log 2>&1
+fi
+line=$(OARD_LIB=$exp timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -k "every_kernel_variant" -p no:cacheprovider 2>&1 | tail -1)
+echo "experiment build, test_every_kernel_variant_is_parity_green: $line" | tee -a $out
