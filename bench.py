@@ -175,11 +175,12 @@ def edge_counts(B, nf):
     return B * 3 * nf * (3 * nf - 1), B * 3 * nf * (nf - 1)
 
 
-def fwd_flops(E, A):
+def fwd_flops(E, A, A_act=None):
     """Algorithmic FLOPs per step of the two hot forward kernels (inter-object edges: no S1 in the first layer - constant
-    initial state - and no S3 in the last - nothing reads the result)."""
+    initial state - and no S3 in the last - nothing reads the result).  EquiMessage is charged for the inner edges INSIDE the cutoff
+    only (A_act; SURVEY.md 8d F_req: it is exactly zero on the others, and the kernel skips them)."""
     return {"gcl_edge": 2.0 * (L * MAC_GCL_EDGE * E - (MAC_GCL_S1 + MAC_GCL_S3) * (E - A)),
-            "equi_edge": 2.0 * L * MAC_EQUI_EDGE * A}
+            "equi_edge": 2.0 * L * MAC_EQUI_EDGE * (A if A_act is None or A_act < 0 else A_act)}
 
 
 def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
@@ -364,11 +365,11 @@ def kernel_families(dyn, step, dev, calls=3):
 PEAK_BF16_MFMA = 2.5e15                       # MI355X_MICROARCH.md:42 (dense; the sparse figure is twice that)
 
 
-def roofline_of(fam, E, A, precision, traffic_prefix=None):
+def roofline_of(fam, E, A, precision, traffic_prefix=None, A_act=None):
     """`roofline` object of the dominant edge kernel: ALGORITHMIC FLOPs per second in both precisions.  fp32: against the fp32 MFMA
     peak.  bf16x3: both edge families run on bf16 MFMAs - six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block of the fp32 product -
     so the roof is the dense bf16 MFMA peak / 6; the executed bf16 rate is a separate key."""
-    flops = fwd_flops(E, A)
+    flops = fwd_flops(E, A, A_act)
     dom = max(flops, key=lambda f: fam[f]["ms_per_step"])
     oth = [f for f in flops if f != dom][0]
     ach = flops[dom] / (fam[dom]["ms_per_step"] * 1e-3)
@@ -381,6 +382,8 @@ def roofline_of(fam, E, A, precision, traffic_prefix=None):
             "other_kernel": {"kernel": "k_" + oth, "achieved": flops[oth] / (fam[oth]["ms_per_step"] * 1e-3) / 1e12,
                              "frac": flops[oth] / (fam[oth]["ms_per_step"] * 1e-3) / PEAK_F32_MFMA,
                              "algorithmic_flops_per_step": flops[oth], "kernel_ms_per_step": fam[oth]["ms_per_step"]}}
+    roof["inner_edges"] = A
+    roof["active_inner_edges"] = A if A_act is None or A_act < 0 else A_act      # same-object edges inside the cutoff in the timed inputs
     if traffic is not None:
         roof["hbm_gbps_while_running"] = traffic / (fam[dom]["ms_per_step"] * 1e-3) / 1e9
         t2, _ = pmc_traffic("k_" + oth, traffic_prefix)
@@ -410,14 +413,29 @@ def sampler_run(dyn, wl, T_run, dev):
     warm = DiffusionSampler(dyn, "polynomial_2", 4, 1e-5, pos_only=True)
     warm.sample(B, frag, conditions=wl.cond, h0=h0)                     # warm-up (topology, buffers)
     smp = DiffusionSampler(dyn, "polynomial_2", T_run, 1e-5, pos_only=True)
+    # head and tail of the SAME run: events on the loop's stream after network calls 1, 101, T - 100 and T (no host wait inside the loop).
+    # With untrained weights the positions leave the 10 A cutoff after a few hundred steps; EquiMessage then has no edge to run on.
+    marks = {}
+    want = (1, 101, T_run - 100, T_run) if T_run >= 300 else ()
+
+    def cb(i):
+        if i in want:
+            marks[i] = torch.cuda.Event(enable_timing=True)
+            marks[i].record()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
-    smp.sample(B, frag, conditions=wl.cond, h0=h0)
+    smp.sample(B, frag, conditions=wl.cond, h0=h0, step_callback=cb)
     torch.cuda.synchronize(dev)
     dts = time.perf_counter() - t1
     per_call = dts / (T_run + 1)
+    tail_active = dyn.active_inner_edges()                 # of the LAST network call of the run
+    head = None
+    if len(marks) == 4:
+        head = {"ms_per_call_first_100": marks[1].elapsed_time(marks[101]) / 100.0,
+                "ms_per_call_last_100": marks[T_run - 100].elapsed_time(marks[T_run]) / 100.0}
     return {"T": T_run, "network_calls": T_run + 1, "seconds": dts, "batch": B,
             "ms_per_network_call_incl_sampler_step": per_call * 1e3,
+            "inner_edges": edge_counts(B, nf)[1], "active_inner_edges_in_the_last_call": tail_active, "head_and_tail": head,
             "reactions_per_sec_measured" if T_run == 1000 else "reactions_per_sec_T1000_projected":
                 B / dts if T_run == 1000 else B / (1001 * per_call),
             "note": "with untrained weights the trajectory leaves the 10 A cutoff after a few hundred steps, so the "
@@ -437,7 +455,7 @@ def second_line(dev, B, nf, steps, warmup, quick):
                                            "accumulate; everything else f32)",
            "value": B * steps / dt, "unit": "reaction-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
            "reactions_per_sec_T1000": B * steps / dt / 1001.0,
-           "roofline": roofline_of(kernel_families(dyn, step, dev), E, A, "bf16x3", PROFILE_TAG + "_bf16x3")}
+           "roofline": roofline_of(kernel_families(dyn, step, dev), E, A, "bf16x3", PROFILE_TAG + "_bf16x3", dyn.active_inner_edges())}
     if not quick:
         out["sampler_loop"] = sampler_run(dyn, wl, 1000, dev)
     return out
@@ -448,7 +466,7 @@ def config5(dev, steps=6, warmup=2):
     reactions x 3 x 128 atoms (N = 1 536, E = 588 288 edge rows of 2 752 B, A = 195 072 inner edges), fp32, two position scales:
     N(0, 1) (every intra-object pair inside the 10 A cutoff) and x 3 (the cutoff bites: ragged active set, node labelling).  Per
     variant: ms per step (default schedule), per-family kernel time (one sub-batch), TFLOP/s of the two edge kernels against the
-    fp32 MFMA peak (the kernels run every inner row whether masked or not: same FLOPs in both variants), HBM GB/s from the
+    fp32 MFMA peak (EquiMessage runs - and is charged for - the inner edges inside the cutoff only: `active_inner_edges`), HBM GB/s from the
     committed PMC passes of this workload (profiles/<round>_cfg5{n,x3}_pmc_*, tools/profile_cfg5.sh)."""
     B, nf = 4, 128
     E, A = edge_counts(B, nf)
@@ -461,7 +479,7 @@ def config5(dev, steps=6, warmup=2):
         dt = timed_steps(step, steps, warmup, dev)
         assert int(dyn.last_status[0].item()) == 0, "NaN in config 5"
         fam = kernel_families(dyn, step, dev, calls=2)
-        roof = roofline_of(fam, E, A, "f32", PROFILE_TAG + "_cfg5" + ("n" if key == "n01" else "x3"))
+        roof = roofline_of(fam, E, A, "f32", PROFILE_TAG + "_cfg5" + ("n" if key == "n01" else "x3"), dyn.active_inner_edges())
         out["variants"][key] = {"pos_scale": scale, "ms_per_step": dt / steps * 1e3, "reaction_steps_per_sec": B * steps / dt,
                                 "edge_rows_per_sec": E * steps / dt, "roofline": roof}
         del dyn, wl
@@ -672,7 +690,7 @@ def main():
     std = (B, nf) == (64, 23)
     if rank == 0 and "roofline" not in skip:               # per-kernel durations (HIP events on the launch stream)
         prefix = (PROFILE_TAG if args.precision == "f32" else PROFILE_TAG + "_bf16x3") if std else "no-PMC-pass-for-this-shape"
-        roof = roofline_of(kernel_families(dyn, eager_step, dev), E, A, args.precision, prefix)
+        roof = roofline_of(kernel_families(dyn, eager_step, dev), E, A, args.precision, prefix, dyn.active_inner_edges())
 
     # the real sampling loop (row N1): the BASELINE metric's reactions/s, MEASURED (T = 1000 unless --quick)
     sampler_leg = train = second = cfg5 = None

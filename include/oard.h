@@ -127,6 +127,14 @@ int oard_forward(const oard_config* cfg, const oard_topology* topo, const void* 
                  void* workspace_dev, size_t workspace_bytes, int32_t* status_dev,
                  oard_stream_t stream);
 
+/* Inner (same-object) edges that were inside the cutoff in the LAST inference-mode oard_forward on this workspace - the rows
+ * EquiMessage actually ran (model/leftnet.py:748-753: the others carry an exactly-zero message and are skipped; equal to
+ * oard_topology_num_inner_edges while nothing is masked).  A measurement aid (bench.py charges the roofline with it):
+ * synchronises the stream and copies one int per sub-batch.  -1 if the forward did not build the list (training mode, debug
+ * option equi_skip = 0). */
+int oard_active_inner_edges(const oard_config* cfg, const oard_topology* topo, const void* workspace_dev, size_t workspace_bytes,
+                            int64_t* n_active_host, oard_stream_t stream);
+
 /* ---- sampler step (next row N1) ----------------------------------------------------------------
  * Replaces the element-wise part of EnVariationalDiffusion.sample_p_zs_given_zt / sample_normal /
  * sample_p_xh_given_z0 (oa_reactdiff/diffusion/en_diffusion.py:562-702) and the CoM-free noise of

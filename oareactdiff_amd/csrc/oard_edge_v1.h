@@ -571,12 +571,15 @@ struct EquiStream {
 // (Three slabs with the barrier inside the phase, as in k_gcl_edge_v1, were measured here too: 7.09-7.14 ms per step against
 // 7.10-7.13 ms - the phases of this kernel are twice as long and its barrier wait was small to begin with; not kept.)
 // (Two K blocks of T1 per phase - half of T1's barriers, 74-chunk slabs - : 7.26-7.33 against 7.09-7.11 ms; not kept either.)
+// al: the inner rows inside the cutoff (ActList; round 5).  Column c of the launch is list entry c; rows outside the cutoff are not
+// touched at all - their q is exactly zero in the reference and nobody reads it (the node stage walks the same list).  The grid is
+// sized for A (the host does not know n_act); workgroups behind the list end return at once.
 template <class D, int WAVES, bool TRAIN>
 __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const float* __restrict__ stream,
                                                              const float* __restrict__ dp0b,
                                                              const float* __restrict__ ew, const float* __restrict__ rbuf,
                                                              float* __restrict__ qbuf, float* __restrict__ zd1,
-                                                             float* __restrict__ cdbuf) {
+                                                             float* __restrict__ cdbuf, ActList al) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = EquiStream<D>;
     constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT, G1 = S::G1, G2 = S::G2;
@@ -596,9 +599,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_edge_v1(TopoDev tp, const f
     };
     auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
 
+    const long long n_cols = al.n != nullptr ? (long long)*al.n : tp.A;
+    if ((long long)blockIdx.x * WAVES * 16 >= n_cols) return;                  // (workgroup-uniform: before the first barrier)
     const long long c = ((long long)blockIdx.x * WAVES + wave) * 16 + (lane & 15);
-    const size_t a = (size_t)(c < tp.A ? c : tp.A);           // padding columns use the spare entry A
-    const float* erow = ew + (c < tp.A ? a : (size_t)tp.E) * D::WP + 4 * g;     // inner entry a == physical row a
+    const bool live = c < n_cols;
+    const size_t a = (size_t)(live ? (al.rows != nullptr ? (long long)al.rows[c] : c) : tp.A);    // padding columns use the spare entry A
+    const float* erow = ew + (live ? a : (size_t)tp.E) * D::WP + 4 * g;         // inner entry a == physical row a
     f4 d1[D1T];
 #pragma unroll
     for (int t = 0; t < D1T; ++t) d1[t] = ld_vec(dp0b, t, lane);

@@ -87,6 +87,7 @@ int g_wgrad_wgs = 512;       // workgroups per weight-gradient GEMM (row chunks 
 int g_gcl_persist = 1;      // the fp32 GCL throughput shape as a persistent workgroup (oard_edge_p.h); 0: one 128-edge tile per workgroup
 int g_gcl_grid = 0;         // workgroups per launch of the persistent kernel: 0 = auto (one per CU when the launch has the chip to itself,
                             //    half of them when sub-batches run concurrently), > 0 = that many
+int g_equi_skip = 1;        // EquiMessage runs the inner edges inside the cutoff only (ActList; exact: it is zero on the others).  0: every inner row
 int g_gcl_skip = 1;         // skip S1 (first layer) / S3 (last layer) on inter-object edges
 int g_node_variant = 1;     // 0: one wave per 16 nodes, 1: 8 waves per 16 nodes with LDS-resident activations
 // Arithmetic of the two MFMA edge stages: oard_config::precision (OARD_PREC_* bits, include/oard.h) - a property of the CALL, read
@@ -327,6 +328,7 @@ static WsOff make_ws(const oard_config* c, const TopoDev& td) {
     w.dpos = take(N * 3 * 4); w.hout = take(N * 16 * 4);
     // scratch of the stage-split latency edge kernels: only topologies small enough to ever take that path (the launch-shape
     // thresholds are run-time options, so the launch re-checks that the buffers exist)
+    w.al_rows = take(A * 4); w.al_src = take(A * 4); w.al_pre = take(A * 4); w.al_cnt = take((size_t)cdiv((long long)td.A, 256) * 4 + 4); w.al_n = take(4);
     w.d1s = take((size_t)cdiv((long long)td.A, 128) * 8 * d.D1T * 1024);
     w.small_a = w.small_b = 0;
     if (E <= (size_t)OARD_SMALL_MAX_EDGES) {
@@ -455,10 +457,12 @@ int launch_gcl_v1(int prec, int variant, int conc, const TopoDev& tp, const floa
 }
 #define EQUI_CASE(id, WV_) case id: { \
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, WV_, false>), cdiv(tp.A, 16 * WV_), WV_ * 64, (EquiStream<D>::LDS_BYTES), st, \
-                   tp, stream, dp0b, ew, rbuf, qbuf, nullptr, nullptr); return OARD_OK; }
+                   tp, stream, dp0b, ew, rbuf, qbuf, nullptr, nullptr, al); return OARD_OK; }
 template <class D>
 int launch_equi_v1(int prec, int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* dp0b, const float* ew,
-                   const float* rbuf, float* qbuf, float* zd1, float* cd, hipStream_t st, float* d1s = nullptr) {
+                   const float* rbuf, float* qbuf, float* zd1, float* cd, hipStream_t st, float* d1s = nullptr, ActList al = ActList{}) {
+    // (the split-precision and the latency kernels run every inner row: their q is zero on the rows outside the cutoff, which the
+    // node stage does not read when it walks the list)
     if (zd1 && (prec & OARD_PREC_TRAIN_BF16X3) && d1s) {      // training-mode forward in split precision (optional)
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_b3<D, true>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiB3Stream<D>::LDS_BYTES), st, tp, wb + lo.equi_b3,
                    dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s, zd1, cd);
@@ -466,7 +470,7 @@ int launch_equi_v1(int prec, int variant, int conc, const TopoDev& tp, const flo
     }
     if (zd1) {                   // training-mode forward
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_v1<D, 8, true>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiStream<D>::LDS_BYTES), st,
-                   tp, stream, dp0b, ew, rbuf, qbuf, zd1, cd);
+                   tp, stream, dp0b, ew, rbuf, qbuf, zd1, cd, ActList{});
         return OARD_OK;
     }
     if (variant == 2 && cdiv(tp.A, 16) * conc <= 512LL * g_auto_small) variant = 1;
@@ -575,6 +579,12 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     const int node_variant = train ? 1 : g_node_variant;
     const bool gcl_skip = train || g_gcl_skip;
     const int stop_after = train ? 0 : g_stop_after;
+    // the inner rows inside the cutoff, compacted per call: EquiMessage (edge kernel and node-side gather) runs those only.  Inference with
+    // the streamed edge kernels and the v1 node stages; the training-mode forward tapes every row for its backward pass.
+    const bool use_al = !train && g_equi_skip && A > 0 && equi_variant != 0 && node_variant == 1;
+    int* al_cnt = (int*)(ws + w.al_cnt);
+    const ActList al = use_al ? ActList{(const int*)(ws + w.al_rows), (const int*)(ws + w.al_src), (const int*)(ws + w.al_pre), (const int*)(ws + w.al_n)}
+                              : ActList{nullptr, nullptr, nullptr, nullptr};
     LAUNCH(F_OTHER, k_prep, cdiv(N, 128), 128, st, tp, op, wb, pos, hin, t, t_scalar, cond,
            c->condition_nf > 0 ? c->condition_nf : 0, c->condition_time, emb);
     LAUNCH(F_INIT, k_geom, tp.n_groups, 64, st, tp, (const float*)pos, cutoff, pf64, pf32, x1, pp0, labels);
@@ -584,7 +594,8 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
         LAUNCH(F_INIT, k_fill_edges, std::min<long long>(cdiv((E - A + 1) * (D::WP / 4), 256), 8192), 256, st,
                wb + po.c0row, ew + (size_t)A * D::WP, E - A + 1, D::WP);
     if (A > 0) {
-        LAUNCH(F_INIT, k_edge_geo, cdiv(A, 256), 256, st, tp, (const float*)pos, (const double*)pf64, cutoff, geo, d64);
+        LAUNCH(F_INIT, k_edge_geo, cdiv(A, 256), 256, st, tp, (const float*)pos, (const double*)pf64, cutoff, geo, d64, use_al ? al_cnt : nullptr);
+        if (use_al) LAUNCH(F_INIT, k_active_list, cdiv(A, 256), 256, st, tp, (const float*)geo, (const int*)al_cnt, (int*)al.rows, (int*)al.src, (int*)al.pre, (int*)al.n);
         LAUNCH(F_INIT, k_rbf, cdiv(A * D::RP, 256), 256, st, tp, (const double*)d64, (const float*)geo,
                wb + po.rbf_means, wb + po.rbf_betas, cutoff, rbuf, ew, D::R, D::RP, D::H, D::WP);
     }
@@ -651,12 +662,12 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
             if (A > 0) {
                 int rc = launch_equi_v1<D>(c->precision, equi_variant, topo->conc, tp, wb, lo, wb + lo.equi_stream, wb + lo.dp0b, ew_out, rbuf, vmsg,
                                            train ? (float*)(tape + to.zd1[l]) : nullptr, train ? (float*)(tape + to.cd[l]) : nullptr, st,
-                                           (float*)(ws + w.d1s));
+                                           (float*)(ws + w.d1s), al);
                 if (rc != OARD_OK) return rc;
             }
 #define EQUI_NODE_V1(ROWS_, XC_) LAUNCH(F_NODE, (k_equi_node_v1<D, NW, ROWS_, XC_>), gN16, NW * 64, st, tp, wb, lo, (const float*)vmsg, \
                        (const float*)xq, (const float*)geo, (const float*)x1, (const float*)s_mid_at(l), s_at(l + 1), (const float*)vcur, vnext, \
-                       train ? (float*)(tape + to.s_a[l]) : nullptr, train ? (float*)(tape + to.vec_a[l]) : nullptr)
+                       train ? (float*)(tape + to.s_a[l]) : nullptr, train ? (float*)(tape + to.vec_a[l]) : nullptr, al)
             if (nv1 && rows) {
                 if (lo.xcross) EQUI_NODE_V1(true, true); else EQUI_NODE_V1(true, false);
             } else if (nv1) {
@@ -1394,6 +1405,26 @@ static size_t ws_total(const oard_config* c, const oard_topology* tp) {
 size_t oard_workspace_bytes(const oard_config* c, const oard_topology* tp) {
     if (!config_ok(c) || !tp) return 0;
     return ws_total(c, tp);
+}
+
+int oard_active_inner_edges(const oard_config* c, const oard_topology* topo, const void* ws, size_t ws_bytes, int64_t* n_active,
+                            oard_stream_t stream) {
+    if (!config_ok(c) || !topo || !ws || !n_active) return OARD_EINVAL;
+    if (ws_bytes < ws_total(c, topo)) return OARD_ENOMEM;
+    if (!g_equi_skip || g_equi_variant == 0 || g_node_variant != 1) { *n_active = -1; return OARD_OK; }
+    hipStream_t st = (hipStream_t)stream;
+    long long total = 0;
+    for (int p = 0; p < topo->n_parts; ++p) {
+        if (topo->parts[p].d.A <= 0) continue;
+        int n = 0;
+        const WsOff w = make_ws(c, topo->parts[p].d);
+        HIP_TRY(hipMemcpyAsync(&n, (const char*)ws + topo->parts[p].ws_off + w.al_n, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (n < 0 || n > topo->parts[p].d.A) { *n_active = -1; return OARD_OK; }      // no list was built by the last call on this workspace
+        total += n;
+    }
+    *n_active = total;
+    return OARD_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2209,6 +2240,7 @@ int oard_debug_option(const char* name, int value) {
     if (strcmp(name, "node_variant") == 0) { g_node_variant = value; return OARD_OK; }
     if (strcmp(name, "experiments") == 0) return kV0 ? OARD_OK : OARD_EINVAL;      // query: is this an experiment build?
     if (strcmp(name, "gcl_skip") == 0) { g_gcl_skip = value; return OARD_OK; }
+    if (strcmp(name, "equi_skip") == 0) { g_equi_skip = value; return OARD_OK; }
     if (strcmp(name, "gcl_persist") == 0) { g_gcl_persist = value; return OARD_OK; }
     if (strcmp(name, "gcl_grid") == 0) { g_gcl_grid = value; return OARD_OK; }
     if (strcmp(name, "skip_families") == 0) { g_skip_families = value; return OARD_OK; }

@@ -415,9 +415,21 @@ __global__ void k_geom(TopoDev tp, const float* __restrict__ pos, double cutoff,
 
 // one thread per inner (same-object) edge: cutoff mask from raw positions (:747-753), edge frame from
 // pos_frame (:693-705), masked (:768-771), envelope (:785)
-__global__ void k_edge_geo(TopoDev tp, const float* __restrict__ pos, const double* __restrict__ pf64,
-                           double cutoff, float* __restrict__ geo, double* __restrict__ d64) {
+// blk_cnt (optional): [gridDim.x] number of inner edges of this block (256 rows) inside the cutoff - first pass of k_active_list
+__global__ __launch_bounds__(256) void k_edge_geo(TopoDev tp, const float* __restrict__ pos, const double* __restrict__ pf64,
+                           double cutoff, float* __restrict__ geo, double* __restrict__ d64, int* __restrict__ blk_cnt) {
     const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk_cnt != nullptr) {                    // (before the early exit: every thread of the block takes part)
+        int in = 0;
+        if (a < tp.A) {
+            const int i = tp.act_src[a], j = tp.act_tgt[a];
+            const double rx = (double)pos[i * 3] - (double)pos[j * 3], ry = (double)pos[i * 3 + 1] - (double)pos[j * 3 + 1],
+                         rz = (double)pos[i * 3 + 2] - (double)pos[j * 3 + 2];
+            in = sqrt(rx * rx + ry * ry + rz * rz) < cutoff ? 1 : 0;
+        }
+        const int cnt = __syncthreads_count(in);
+        if (threadIdx.x == 0) blk_cnt[blockIdx.x] = cnt;
+    }
     if (a >= tp.A) return;
     const int i = tp.act_src[a], j = tp.act_tgt[a];
     const double rx = (double)pos[i * 3] - (double)pos[j * 3], ry = (double)pos[i * 3 + 1] - (double)pos[j * 3 + 1],
@@ -446,6 +458,34 @@ __global__ void k_edge_geo(TopoDev tp, const float* __restrict__ pos, const doub
 
 // radial basis (:63-69, 781-782) in float64; one thread per (inner edge, k); writes the RBF buffer that
 // EquiMessage re-reads every layer and the rbf section of the initial edge state
+// Compaction of the inner rows inside the cutoff (ActList, oard_layout.h): block b (256 rows, the blocks of k_edge_geo) adds the
+// counts of the blocks in front of it, scans its own 256 flags and writes pre[a] for every row, (row, source) for the active ones.
+__global__ __launch_bounds__(256) void k_active_list(TopoDev tp, const float* __restrict__ geo, const int* __restrict__ blk_cnt,
+                                                     int* __restrict__ rows, int* __restrict__ src, int* __restrict__ pre, int* __restrict__ n_act) {
+    __shared__ int red[256];
+    __shared__ int wsum[4];
+    int base = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) base += blk_cnt[b];
+    red[threadIdx.x] = base;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    base = red[0];
+    const long long a = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool on = a < tp.A && geo[a * GEO_STRIDE + 11] > 0.f;
+    const unsigned long long bal = __ballot(on);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base + in_wave;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (a < tp.A) pre[a] = off;
+    if (on) { rows[off] = (int)a; src[off] = tp.act_src[a]; }
+    if (a == tp.A - 1) { const int tot = off + (on ? 1 : 0); pre[tp.A] = tot; *n_act = tot; }
+}
 __global__ void k_rbf(TopoDev tp, const double* __restrict__ d64, const float* __restrict__ geo,
                       const float* __restrict__ means, const float* __restrict__ betas, double cutoff,
                       float* __restrict__ rbuf, float* __restrict__ ew, int R, int RP, int H, int WP) {

@@ -76,6 +76,17 @@ struct TopoDev {
     const long long *ref_edge_ptr;            // [N] first reference-order edge of internal node n
 };
 
+// Inner (same-object) edges whose distance is inside the cutoff, compacted once per forward call (k_active_list): EquiMessage is
+// exactly zero on the others (model/leftnet.py:748-753, 768-771: rbf * mask = 0 -> rbf_proj = 0), so k_equi_edge_v1 runs the
+// listed rows only and the node stage walks the list.  Target-sorted like the rows themselves: every per-node sum keeps its order.
+// All pointers NULL = every inner row is active (training-mode forward; first-generation kernels).
+struct ActList {
+    const int* rows;   // [n_act] physical row (== inner entry) of the k-th active edge, ascending
+    const int* src;    // [n_act] its source node (act_src[rows[k]])
+    const int* pre;    // [A + 1] number of active rows in front of row a  (node n owns list entries [pre[act_ptr[n]], pre[act_ptr[n + 1]]))
+    const int* n;      // [1]     n_act
+};
+
 // A topology is split into up to OARD_MAX_PARTS independent sub-batches (contiguous ranges of samples):
 // oard_forward runs them concurrently on internal streams so that the low-occupancy node stages and the
 // tail of one part's edge kernels overlap with the other parts' edge kernels.  Reactions never interact,
@@ -122,6 +133,7 @@ struct oard_topology {
 struct WsOff {
     size_t pos, pf64, pf32, x1, pp0, labels, hin, zemb, nb, s, s1, ne1, xh, P, Q, xq, vec, vec2, v2buf, sc0, vdot,
         geo, d64, rbuf, ew, mbuf, xmsg, vmsg, dpos, hout, total;   // xmsg..vmsg double as qbuf [A][3][HP] (v1)
+    size_t al_rows, al_src, al_pre, al_cnt, al_n;   // ActList of this call + the per-block counts it is built from
     size_t d1s;                    // split-precision EquiMessage kernel: SiLU(d1) in wave-tile order, [ceil(A / 128) * 8][D1T][256] floats
     size_t small_a, small_b;       // stage-split EquiMessage latency path: d1 [A+1][D1P]; 0 = not allocated (large topologies)
 };

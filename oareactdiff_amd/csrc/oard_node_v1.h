@@ -482,7 +482,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                                                              const float* __restrict__ geo, const float* __restrict__ x1,
                                                              const float* s, float* s_out, const float* __restrict__ vec_in,
                                                              float* __restrict__ vec_out,
-                                                             float* __restrict__ sa_out, float* __restrict__ va_out /* training tape: state after the aggregation, or NULL */) {
+                                                             float* __restrict__ sa_out, float* __restrict__ va_out /* training tape: state after the aggregation, or NULL */,
+                                                             ActList al /* inner rows inside the cutoff: the gather walks this list (NULL: every row) */) {
     // s: scalar state entering the stage (s_mid), s_out: the state leaving it - the same buffer in inference (every element is read and
     // later written by the same lane), the tape slots s_mid[l] / s_in[l + 1] in training
     constexpr int HT = D::HT;
@@ -498,8 +499,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
     float* in = sm + 3 * HT * 256;         // [2 HT]: s_mid | scal
     float* hx = sm + 5 * HT * 256;         // [HT]
     const NodeBlk nb = node_blk(tp.N, tp.npb);
-    const int n = nb.n, a0 = tp.act_ptr[n], cnt = nb.valid ? tp.act_ptr[n + 1] - a0 : 0;
+    // list entries [a0, a0 + cnt) belong to node n: with an ActList the entries are (row, source) pairs of the edges inside the cutoff, in
+    // row order; without, entry k IS row k
+    // (while nothing is masked - n_act == A, the usual case - the list is the identity: one uniform test, and the gather keeps the
+    // direct addressing it had before the list existed; the extra level of indexing cost 2 % of the node stages)
+    const int n = nb.n;
+    const bool listed = al.pre != nullptr && (long long)__builtin_amdgcn_readfirstlane(*al.n) != tp.A;
+    const int a0 = listed ? al.pre[tp.act_ptr[n]] : tp.act_ptr[n];
+    const int cnt = nb.valid ? (listed ? al.pre[tp.act_ptr[n + 1]] : tp.act_ptr[n + 1]) - a0 : 0;
     const int mx = wave_max(cnt);
+    auto row_of = [&](long long k) -> size_t { return (size_t)(listed ? al.rows[k] : (int)k); };
+    auto src_of = [&](long long k) -> int { return listed ? al.src[k] : tp.act_src[k]; };
     const float inv_sqrt2 = 0.70710678118654752f, inv_sqrt3 = 0.57735026918962576f,
                 inv_sqrt_h = 1.0f / sqrtf((float)D::H);
 
@@ -512,14 +522,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         if (ROWS) {                                             // small batches: the wave's columns walk the edges (row_lanes)
             const RowLanes rl = row_lanes(tp.N, tp.npb, nb.lane);
             const int nn = min(blockIdx.x * tp.npb + rl.node, tp.N - 1);
-            const int b0 = tp.act_ptr[nn], cnt2 = rl.live ? tp.act_ptr[nn + 1] - b0 : 0;
+            const int b0 = listed ? al.pre[tp.act_ptr[nn]] : tp.act_ptr[nn];
+            const int cnt2 = rl.live ? (listed ? al.pre[tp.act_ptr[nn + 1]] : tp.act_ptr[nn + 1]) - b0 : 0;
             const int mx2 = wave_max(cnt2);
             const f4 zn0 = ld_blk(xq, nn, 3 * D::HP, t, nb.lane), zn1 = ld_blk(xq, nn, 3 * D::HP, HT + t, nb.lane),
                      zn2 = ld_blk(xq, nn, 3 * D::HP, 2 * HT + t, nb.lane);
             for (int k = 0; k < mx2; k += rl.L) {
                 const int kk = k + rl.slot;
-                const size_t a = (size_t)min((long long)b0 + min(kk, max(cnt2 - 1, 0)), a_hi);
-                const int m = tp.act_src[a];
+                const long long ke = min((long long)b0 + min(kk, max(cnt2 - 1, 0)), a_hi);      // list entry (clamped: discarded when kk >= cnt2)
+                const size_t a = cnt2 > 0 ? row_of(ke) : 0;
+                const int m = cnt2 > 0 ? src_of(ke) : 0;
                 const float* gp = geo + a * GEO_STRIDE;
                 const float gx = gp[2], gy = gp[3], gz = gp[4];
                 const float cx = XC ? gp[5] : 0.f, cy = XC ? gp[6] : 0.f, cz = XC ? gp[7] : 0.f;
@@ -543,19 +555,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
             v1 = rows_total4(v1, rl, nb.lane); v2 = rows_total4(v2, rl, nb.lane);
         }
         // two edges in flight per step, branch-free (out-of-range slots re-read a valid edge and are discarded)
-        int mnext[2];
+        int mnext[2], rnext[2];                  // (source, row) of the next step's two edges; a node without edges reads nothing
+        auto entry = [&](int kk, int& m, int& r) {
+            const long long ke = min((long long)a0 + min(kk, max(cnt - 1, 0)), a_hi);
+            m = cnt > 0 ? src_of(ke) : 0;
+            r = cnt > 0 ? (int)row_of(ke) : 0;
+        };
 #pragma unroll
-        for (int i = 0; i < 2; ++i) mnext[i] = tp.act_src[(size_t)min((long long)a0 + min(i, max(cnt - 1, 0)), a_hi)];
+        for (int i = 0; i < 2; ++i) entry(i, mnext[i], rnext[i]);
         for (int k = 0; !ROWS && k < mx; k += 2) {
             f4 q0[2], q1[2], q2[2], y0[2], y1[2], y2[2], w0[2], w1[2], w2[2];
             float gx[2], gy[2], gz[2], cx[2], cy[2], cz[2];
-            const int mc[2] = {mnext[0], mnext[1]};
+            const int mc[2] = {mnext[0], mnext[1]}, rc[2] = {rnext[0], rnext[1]};
 #pragma unroll
-            for (int i = 0; i < 2; ++i)          // source nodes of the NEXT step: their latency hides behind this step's gathers
-                mnext[i] = tp.act_src[(size_t)min((long long)a0 + min(k + 2 + i, max(cnt - 1, 0)), a_hi)];
+            for (int i = 0; i < 2; ++i)          // entries of the NEXT step: their latency hides behind this step's gathers
+                entry(k + 2 + i, mnext[i], rnext[i]);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const size_t a = (size_t)min((long long)a0 + min(k + i, max(cnt - 1, 0)), a_hi);
+                const size_t a = (size_t)rc[i];
                 const int m = mc[i];
                 const float* g = geo + a * GEO_STRIDE;
                 gx[i] = g[2]; gy[i] = g[3]; gz[i] = g[4];

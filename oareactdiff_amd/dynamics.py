@@ -520,6 +520,20 @@ class EGNNDynamics(nn.Module):
                         "oard_tap")
         return dst
 
+    @torch.no_grad()
+    def active_inner_edges(self) -> int:
+        """Same-object edges that were inside the cutoff in the last inference call - the rows EquiMessage ran (the others carry an
+        exactly-zero message, model/leftnet.py:748-753, and are skipped); -1 if that call built no list.  Synchronises: a measurement aid."""
+        topo = self._last_topo
+        assert topo is not None and self._ws is not None
+        cfg = self._config()
+        out = C.c_int64(0)
+        with torch.cuda.device(self._ws.device):
+            stream = torch.cuda.current_stream(self._ws.device).cuda_stream
+            _capi.check(_capi.lib().oard_active_inner_edges(C.byref(cfg), topo.handle, self._ws.data_ptr(), self._ws.numel(),
+                                                            C.byref(out), stream), "oard_active_inner_edges")
+        return int(out.value)
+
     @staticmethod
     def compute_frag_index(n_frag_switch: Tensor):
         """egnn_dynamics.py:177-182."""

@@ -162,12 +162,15 @@ class DiffusionSampler:
     @torch.no_grad()
     def sample(self, n_samples: int, fragments_nodes: List[Tensor], conditions: Optional[Tensor] = None,
                return_frames: int = 1, timesteps: Optional[int] = None, h0: Optional[List[Tensor]] = None,
-               noise_fn: Optional[Callable[[int], List[Tensor]]] = None, graph: Optional[bool] = None) -> Tuple[list, List[Tensor]]:
+               noise_fn: Optional[Callable[[int], List[Tensor]]] = None, graph: Optional[bool] = None,
+               step_callback: Optional[Callable[[int], None]] = None) -> Tuple[list, List[Tensor]]:
         """`noise_fn(i)` (tests) supplies the i-th set of raw N(0,1) draws, one [n_k, node_nf_k] tensor per
         object (i = 0 initial state, 1..T the steps, T+1 the final draw); default: torch.randn on the device.
         `graph`: replay the step as a captured hipGraph (`_graphed_steps`; bit-identical to the eager loop, noise drawn in
         blocks of at most `self.noise_block_bytes`); None = automatically for launch-bound batches (n_samples <= 8, one returned
-        frame) unless the caller's stream is itself being captured (then the eager loop runs, which is capturable)."""
+        frame) unless the caller's stream is itself being captured (then the eager loop runs, which is capturable).
+        `step_callback(i)`: called on the host after the i-th network call of the eager loop has been enqueued (i = 1 ... T; progress
+        bars, timing events - it must not synchronise if the loop is to stay free of host waits)."""
         timesteps = self.T if timesteps is None else timesteps
         assert 0 < return_frames <= timesteps and timesteps % return_frames == 0       # en_diffusion.py:473-475
         assert h0 is not None if self.pos_only else True
@@ -214,6 +217,8 @@ class DiffusionSampler:
                     eps_hat, _ = dyn(za, edge_index, t_table[s + 1: s + 2], conditions, n_frag_switch, combined_mask)
                     self._step_kernel(topo, 0, za, eps_hat, draw(call), h0d if self.pos_only else None,
                                       co.alpha_ts, co.c_eps, co.sigma, zb, stream)
+                    if step_callback is not None:
+                        step_callback(call)
                     call += 1
                     za, zb = zb, za
                     if (s * return_frames) % timesteps == 0 and return_frames > 1:

@@ -17,7 +17,7 @@ def pytest_configure(config):
 # that the small golden cases exercise the throughput kernels (the ones bench.py measures); the tests of the
 # heuristics / latency kernels switch them on explicitly (tests/_cases.py: debug_options(**LIB_AUTO))
 SUITE_OPTIONS = dict(gcl_variant=2, equi_variant=2, node_variant=1, gcl_skip=1, parts=0,
-                     auto_small=0, auto_tiny=0, npb=16, poison=1, gcl_persist=1, gcl_grid=0)
+                     auto_small=0, auto_tiny=0, npb=16, poison=1, gcl_persist=1, gcl_grid=0, equi_skip=1)
 # OARD_GCL_B3=1 / OARD_EQUI_B3=1 / OARD_TRAIN_B3=1 run the whole suite on the split-precision edge kernels: the environment is the
 # default of `EGNNDynamics.edge_precision = None` (resolved per call into oard_config.precision; the library has no such global)
 LIB_DEFAULTS = dict(SUITE_OPTIONS, auto_small=4, auto_tiny=8, npb=0, poison=0)

@@ -198,6 +198,47 @@ def test_ragged_production_dims_vs_oracle(sizes, pos_scale, shapes):
     assert rel(v, rv) <= TOL and rel(h, rh) <= TOL, (rel(v, rv), rel(h, rh))
 
 
+@pytest.mark.parametrize("sizes,pos_scale", [([9, 30, 5], 2.5), ([40, 3, 17], 4.0), ([23] * 6, 1.0), ([23, 11], 60.0)])
+@pytest.mark.parametrize("parts", [1, 2])
+def test_skipping_the_inner_edges_outside_the_cutoff_changes_no_bit(sizes, pos_scale, parts):
+    """EquiMessage is exactly zero on same-object edges beyond the cutoff (model/leftnet.py:748-753, 768-771: rbf * mask = 0 feeds
+    rbf_proj, a Linear without bias).  The edge kernel therefore runs the compacted list of the edges inside the cutoff
+    (k_active_list, per call) and the node stage walks the same list, in row order: the sums see the same terms in the same order
+    minus exact zeros.  Bit-identical to running every inner row (debug option equi_skip = 0) - with a ragged active set, with
+    nothing masked, and with EVERYTHING masked (positions x 60: no active edge at all)."""
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    cfg = dict(PRODUCTION_LEFTNET_CONFIG, num_layers=3)
+    sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg, seed=7)
+    xh, ei, t, cond, nfs, cm = _random_case(sizes, pos_scale, 5, cfg)
+    outs, n_act = [], []
+    for skip in (1, 0):
+        with debug_options(equi_skip=skip, parts=parts), torch.no_grad():
+            dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0,
+                               condition_nf=1, device=dev)
+            dyn.load_state_dict(sd, strict=True)
+            out, _ = dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+            torch.cuda.synchronize()
+            n_act.append(dyn.active_inner_edges())
+            outs.append([o.clone() for o in out])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    A = sum(3 * n * (n - 1) for n in sizes)
+    # the count the library reports is the reference's own: distance < cutoff on same-object pairs
+    want = 0
+    for k in range(3):
+        pos = xh[k][:, :3].double()
+        m = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+        d = (pos[:, None] - pos[None]).norm(dim=-1)
+        want += int(((d < cfg["cutoff"]) & (m[:, None] == m[None])).sum()) - pos.shape[0]
+    assert n_act[1] == -1 and n_act[0] == want and 0 <= want <= A, (n_act, want, A)
+    if pos_scale >= 60:
+        assert want == 0
+    if pos_scale == 1.0:
+        assert want == A
+
+
 @pytest.mark.parametrize("pos_scale", [1.0, 3.0])
 def test_config5_large_reactions(pos_scale):
     """BASELINE.json configs[4] (SURVEY.md section 8d "config 5"): 128 atoms per object = 384-node reactions with
