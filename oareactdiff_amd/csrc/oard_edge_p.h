@@ -21,12 +21,13 @@
 #pragma once
 #include "oard_edge_v1.h"
 
-template <class D, bool DO_S1, bool DO_S3>
+// TRAIN: as k_gcl_edge_v1's training mode - the new state goes to a different buffer, the pre-activations z1 / z2 / att / z3 are taped.
+template <class D, bool DO_S1, bool DO_S3, bool TRAIN = false>
 __global__ __launch_bounds__(512, 2) void k_gcl_edge_p(TopoDev tp, const float* __restrict__ stream,
                                                        const float* __restrict__ P, const float* __restrict__ Q,
                                                        const float* __restrict__ u0, const float* __restrict__ c0,
                                                        long long r0, long long r1, const float* ew_in, float* ew_out,
-                                                       float* __restrict__ mbuf) {
+                                                       float* __restrict__ mbuf, GclTape tape) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WAVES = 8, GP = 2, RING = 3, DIST = RING - 1;
     using S = GclStream<D, GP>;
@@ -188,6 +189,10 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_p(TopoDev tp, const float* 
 #pragma unroll
             for (int t = 0; t < HT; ++t) h1[t] += hp[t] + hq[t];
         }
+        if (TRAIN) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t) st_blk(tape.z1, e, D::HP, t, lane, h1[t]);
+        }
 #pragma unroll
         for (int t = 0; t < HT; ++t) h1[t] = silu4(h1[t]);
         const float h1_tail = TAIL1 ? tail_compact(h1[HT - 1], lane) : 0.f;
@@ -195,10 +200,16 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_p(TopoDev tp, const float* 
         // ---- S2: m = SiLU(W2 h1 + b2); gate = SiLU(watt . m + batt) --------------------------------------------------
         f4 m[HT];
         f4 on[GP];
+        f4 pz2[TRAIN ? GP : 1];                     // TRAIN: z2 tiles of the previous phase, stored behind the next barrier
         float m_tail = 0.f;
 #pragma unroll
         for (int p2 = 0; p2 < S::NP2; ++p2) {
             auto post = [&]() {
+                if (TRAIN && p2 > 0) {
+#pragma unroll
+                    for (int gg = 0; gg < GP; ++gg)
+                        if ((p2 - 1) * GP + gg < HT) st_blk(tape.z2, e, D::HP, (p2 - 1) * GP + gg, lane, pz2[gg]);
+                }
                 pf_ahead(lp);
                 if (DO_S3 && p2 == S::NP2 - 1) {
 #pragma unroll
@@ -223,10 +234,12 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_p(TopoDev tp, const float* 
                                       : chain_tile<HT, TAIL1>(SL(), gg * G2 + 1, m, bias, m_tail, hook);
                     }
                     if (tg < HT) {
+                        if (TRAIN) pz2[gg] = acc;
                         m[tg] = silu4(acc);
                         if (TAIL1 && tg == HT - 1) m_tail = tail_compact(m[HT - 1], lane);
                     } else {
                         const float a = ROWS4 ? acc.x : __shfl(acc.x, lane & 15, 64);
+                        if (TRAIN && g == 0) tape.att[e] = a;
                         const float gate = silu1(a);
 #pragma unroll
                         for (int t = 0; t < HT; ++t) m[t] *= gate;
@@ -239,12 +252,17 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_p(TopoDev tp, const float* 
             ++gp; ++lp;
         }
 
+        if (TRAIN) {                                // z2 tiles of the last S2 phase
+#pragma unroll
+            for (int gg = 0; gg < GP; ++gg)
+                if ((S::NP2 - 1) * GP + gg < HT) st_blk(tape.z2, e, D::HP, (S::NP2 - 1) * GP + gg, lane, pz2[gg]);
+        }
         if (!DO_S3) {
 #pragma unroll
             for (int t = 0; t < HT; ++t) st_blk(mbuf, eid, D::HP, t, lane, m[t]);
         } else {
             // ---- S3: ew += SiLU(W3 m + b3); the next round's columns are fetched behind its barriers -------------------
-            f4 pend[GP];
+            f4 pend[GP], pendz[TRAIN ? GP : 1];
             f4 om[GP];
             auto s3_phase = [&](int p3, const f4 (&o)[GP], f4 (&onext)[GP], auto last_tag) {
                 constexpr bool LAST = decltype(last_tag)::value;   // the last S3 phase (peeled): its post() fetches the next round's first edge-state blocks
@@ -254,7 +272,10 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_p(TopoDev tp, const float* 
                         for (int t = 0; t < HT; ++t) st_blk(mbuf, eid, D::HP, t, lane, m[t]);
                     } else {
 #pragma unroll
-                        for (int gg = 0; gg < GP; ++gg) st_f4(orow + 16 * ((p3 - 1) * GP + gg), pend[gg]);
+                        for (int gg = 0; gg < GP; ++gg) {
+                            st_f4(orow + 16 * ((p3 - 1) * GP + gg), pend[gg]);
+                            if (TRAIN) st_f4(tape.z3 + e * D::WP + 4 * g + 16 * ((p3 - 1) * GP + gg), pendz[gg]);
+                        }
                     }
                     pf_ahead(lp);
                     if (p3 + 1 < S::NP3) {
@@ -279,6 +300,7 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_p(TopoDev tp, const float* 
                     const int t = p3 * GP + gg;
                     if (t < WB) {
                         const f4 z = chain_tile<HT, TAIL1>(SL(), gg * G2 + 1, m, A(gg * G2), m_tail, hook);
+                        if (TRAIN) pendz[gg] = z;
                         pend[gg] = o[gg] + silu4(z);
                     }
                 }
@@ -295,7 +317,10 @@ __global__ __launch_bounds__(512, 2) void k_gcl_edge_p(TopoDev tp, const float* 
 #pragma unroll
             for (int gg = 0; gg < GP; ++gg) {
                 const int t = (S::NP3 - 1) * GP + gg;
-                if (t < WB) st_f4(orow + 16 * t, pend[gg]);
+                if (t < WB) {
+                    st_f4(orow + 16 * t, pend[gg]);
+                    if (TRAIN) st_f4(tape.z3 + e * D::WP + 4 * g + 16 * t, pendz[gg]);
+                }
             }
         }
 

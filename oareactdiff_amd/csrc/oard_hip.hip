@@ -390,6 +390,13 @@ int launch_gcl_v1s(int prec, int variant, int conc, const TopoDev& tp, const flo
             return OARD_OK;
         }
 #endif
+        if (g_gcl_persist) {     // the training-mode forward is one sub-batch: persistent workgroups, balanced last round (oard_edge_p.h)
+            const long long nhalf = cdiv(cdiv(r1 - r0, 16), 4);
+            const long long want = g_gcl_grid > 0 ? g_gcl_grid : (g_gcl_grid < 0 ? cdiv(nhalf, 2LL * -g_gcl_grid) : device_cus());
+            LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_p<D, S1, S3, true>), std::min(nhalf, want), 8 * 64, (GclStream<D, 2>::LDS_BYTES / 2 * 3), st,
+                       tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, *tape);
+            return OARD_OK;
+        }
         GCL_RING3(true, *tape);
     }
     if (variant == 2 && cdiv(r1 - r0, 16) * conc <= 1024LL * g_auto_small) variant = 3;
@@ -415,7 +422,7 @@ int launch_gcl_v1s(int prec, int variant, int conc, const TopoDev& tp, const flo
                 // gcl_grid < 0: -k = k rounds (128-row tiles) per workgroup
                 const long long want = g_gcl_grid > 0 ? g_gcl_grid : (g_gcl_grid < 0 ? cdiv(nhalf, 2LL * -g_gcl_grid) : (conc > 1 ? std::max(1, device_cus() / 2) : device_cus()));
                 LAUNCH_LDS(F_GCL_EDGE, (k_gcl_edge_p<D, S1, S3>), std::min(nhalf, want), 8 * 64, (GclStream<D, 2>::LDS_BYTES / 2 * 3), st,
-                           tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf);
+                           tp, stream, P, Q, u0, c0, r0, r1, ew_in, ew_out, mbuf, GclTape{});
                 return OARD_OK;
             }
             GCL_RING3(false, GclTape{});
@@ -685,6 +692,28 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
         if (stop_after == 100 + 10 * l + 2) { topo->vec_final = (size_t)((char*)vcur - ws); return OARD_OK; }
     }
     if (!train) topo->vec_final = (size_t)((char*)vcur - ws);
+    if (train) {
+        // The backward edge kernels run 128-row tiles whose padding columns read the SPARE row (index E / A) of every taped array and take
+        // part in sums over a wave's columns with a zero cotangent: 0 x finite = 0, but 0 x NaN is not.  The forward's own padding columns
+        // write those rows only when a launch HAS padding columns, with whatever the spare row of its input held (the tape is grow-only,
+        // uninitialised memory) - finite so far by the accident of the layer-0 launch over the inter-object rows, and not at all once the
+        // persistent kernel deals 64-row half-tiles (E % 128 == 64: poisoned-tape test, round 5).  So the spare rows are zeroed here, behind
+        // every kernel that may have written them.
+        ZeroRows z;
+        z.count = 0;
+        auto add = [&](size_t off, size_t row, int ld) {
+            if (z.count == 64) { LAUNCH(F_OTHER, k_zero_rows, 64, 256, st, z); z.count = 0; }
+            z.p[z.count] = (float*)(tape + off) + row * (size_t)ld; z.n[z.count] = ld; ++z.count;
+        };
+        for (int l = 0; l <= c->num_layers; ++l) {
+            add(to.ew[l], (size_t)E, D::WP);
+            if (l == c->num_layers) break;
+            add(to.z1[l], (size_t)E, D::HP); add(to.z2[l], (size_t)E, D::HP); add(to.att[l], (size_t)E, 1); add(to.z3[l], (size_t)E, D::WP);
+            add(to.zd1[l], (size_t)A, D::D1P); add(to.cd[l], (size_t)A, 3 * D::HP);
+        }
+        add(to.geo, (size_t)A, GEO_STRIDE); add(to.rbuf, (size_t)A, D::RP);
+        if (z.count > 0) LAUNCH(F_OTHER, k_zero_rows, z.count, 256, st, z);
+    }
     if (node_variant >= 1)
         LAUNCH(F_NODE, (k_out_v1<D, NW>), gNb, NW * 64, st, tp, wb, po, (const float*)s_at(c->num_layers), (const float*)vcur, dpos, hout, status);
     else if constexpr (kV0)

@@ -458,6 +458,13 @@ __global__ __launch_bounds__(256) void k_edge_geo(TopoDev tp, const float* __res
 
 // radial basis (:63-69, 781-782) in float64; one thread per (inner edge, k); writes the RBF buffer that
 // EquiMessage re-reads every layer and the rbf section of the initial edge state
+// Zeroes up to 64 short rows in one launch (the spare rows of the training tape, oard_hip.hip: forward_impl)
+struct ZeroRows { float* p[64]; int n[64]; int count; };
+__global__ __launch_bounds__(256) void k_zero_rows(ZeroRows z) {
+    if ((int)blockIdx.x >= z.count) return;
+    float* p = z.p[blockIdx.x];
+    for (int i = threadIdx.x; i < z.n[blockIdx.x]; i += 256) p[i] = 0.f;
+}
 // Compaction of the inner rows inside the cutoff (ActList, oard_layout.h): block b (256 rows, the blocks of k_edge_geo) adds the
 // counts of the blocks in front of it, scans its own 256 flags and writes pre[a] for every row, (row, source) for the active ones.
 __global__ __launch_bounds__(256) void k_active_list(TopoDev tp, const float* __restrict__ geo, const int* __restrict__ blk_cnt,
