@@ -438,8 +438,10 @@ def sampler_run(dyn, wl, T_run, dev):
             "inner_edges": edge_counts(B, nf)[1], "active_inner_edges_in_the_last_call": tail_active, "head_and_tail": head,
             "reactions_per_sec_measured" if T_run == 1000 else "reactions_per_sec_T1000_projected":
                 B / dts if T_run == 1000 else B / (1001 * per_call),
-            "note": "with untrained weights the trajectory leaves the 10 A cutoff after a few hundred steps, so the "
-                    "tail of this run is cheaper than the fixed-distribution steps of the headline value (SURVEY 8d)"}
+            "note": "synthetic (untrained) weights: the trajectory leaves the 10 A cutoff within the first steps, EquiMessage is then "
+                    "exactly zero on every same-object edge and is skipped (active_inner_edges_in_the_last_call), so this run is cheaper "
+                    "per call than the fixed-distribution steps of the headline `value`, where nothing is masked (SURVEY 8d); a trained "
+                    "model keeps its molecules inside the cutoff and pays the headline's cost per call"}
 
 
 def second_line(dev, B, nf, steps, warmup, quick):

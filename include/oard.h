@@ -135,6 +135,12 @@ int oard_forward(const oard_config* cfg, const oard_topology* topo, const void* 
 int oard_active_inner_edges(const oard_config* cfg, const oard_topology* topo, const void* workspace_dev, size_t workspace_bytes,
                             int64_t* n_active_host, oard_stream_t stream);
 
+/* EquiUpdate's frame-scalar MLP (model/leftnet.py:333, lin3: 3 -> 48 -> 8 -> 1 on (x, 0, 0)) is evaluated from a table that
+ * oard_pack_weights builds and CHECKS per layer (csrc/oard_layout.h: L3T_*): this copies layer `layer`'s table - OARD_L3T_FLOATS floats:
+ * (f, f' h) at the 1025 grid points of [-16, 16], then [flag, worst midpoint deviation, range of f, -] - to out_dev (tests). */
+#define OARD_L3T_FLOATS 2054
+int oard_debug_lin3u_table(const oard_config* cfg, const void* packed_dev, int layer, float* out_dev, oard_stream_t stream);
+
 /* ---- sampler step (next row N1) ----------------------------------------------------------------
  * Replaces the element-wise part of EnVariationalDiffusion.sample_p_zs_given_zt / sample_normal /
  * sample_p_xh_given_z0 (oa_reactdiff/diffusion/en_diffusion.py:562-702) and the CoM-free noise of

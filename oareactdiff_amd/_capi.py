@@ -19,7 +19,7 @@ TAP_S, TAP_VEC, TAP_EDGE, TAP_POS_FRAME, TAP_DPOS, TAP_HOUT, TAP_LABELS, TAP_NE1
 EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_bytes", "oard_pack_weights",
            "oard_topology_create", "oard_topology_destroy", "oard_topology_num_nodes", "oard_topology_num_edges",
            "oard_topology_num_inner_edges", "oard_topology_num_samples", "oard_topology_check_edge_index",
-           "oard_workspace_bytes", "oard_forward", "oard_active_inner_edges", "oard_sampler_step", "oard_sampler_step_dev", "oard_tap", "oard_debug_stop_after", "oard_debug_option", "oard_timing_enable", "oard_timing_reset",
+           "oard_workspace_bytes", "oard_forward", "oard_active_inner_edges", "oard_debug_lin3u_table", "oard_sampler_step", "oard_sampler_step_dev", "oard_tap", "oard_debug_stop_after", "oard_debug_option", "oard_timing_enable", "oard_timing_reset",
            "oard_timing_get",
            "oard_topology_create_parts", "oard_topology_export", "oard_tape_bytes", "oard_tape_entry", "oard_forward_train",
            "oard_packed_bwd_bytes", "oard_pack_weights_bwd", "oard_gcl_backward_dx", "oard_edge_node_sums",
@@ -88,6 +88,7 @@ def lib() -> C.CDLL:
     L.oard_workspace_bytes.argtypes = [cfgp, vp]; L.oard_workspace_bytes.restype = sz
     L.oard_forward.argtypes = [cfgp, vp, vp, C.POINTER(vp), vp, C.c_int, vp, C.POINTER(vp), vp, sz, vp, vp]
     L.oard_forward.restype = C.c_int
+    L.oard_debug_lin3u_table.argtypes = [cfgp, vp, C.c_int, vp, vp]; L.oard_debug_lin3u_table.restype = C.c_int
     L.oard_active_inner_edges.argtypes = [cfgp, vp, vp, sz, C.POINTER(i64), vp]; L.oard_active_inner_edges.restype = C.c_int
     L.oard_sampler_step.argtypes = [cfgp, vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                     C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(vp), vp]

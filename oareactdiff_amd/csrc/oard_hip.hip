@@ -194,6 +194,7 @@ PackOff make_layout(const oard_config* c) {
         lo.xv0 = mat(d.HT, 2 * d.HT);
         lo.xv2 = mat(3 * d.HT, d.HT);
         lo.l3u = take(593);
+        lo.l3t = take(L3T_FLOATS);
         lo.gcl_stream = take((size_t)(d.WB * d.HT + (d.HT + 1) * (d.HT + 1) + d.WB * (d.HT + 1)) * 256);
         lo.equi_stream = take((size_t)(d.WB * d.D1T + 3 * d.HT * (1 + d.D1T + d.RB)) * 256);
         {   // GclB3Stream<D>::CHUNKS
@@ -975,6 +976,13 @@ int oard_pack_weights(const oard_config* c, const float* const* params, size_t n
         }
     }
     { int rcf = pk.flush(); if (rcf != OARD_OK) return rcf; }
+    {   // EquiUpdate's frame-scalar MLP as a checked table (oard_layout.h: L3T_*), from the raw block packed above
+        L3tJobs lj;
+        memset(&lj, 0, sizeof(lj));
+        for (int l = 0; l < c->num_layers; ++l) { lj.l3u[l] = po.layer[l].l3u; lj.l3t[l] = po.layer[l].l3t; }
+        hipLaunchKernelGGL(k_lin3u_table_fill, dim3(L3T_N / 256, (unsigned)c->num_layers), dim3(256), 0, st, (float*)packed, lj);
+        hipLaunchKernelGGL(k_lin3u_table_check, dim3(L3T_N / 256, (unsigned)c->num_layers), dim3(256), 0, st, (float*)packed, lj);
+    }
     hipLaunchKernelGGL(k_c0row, dim3((unsigned)cdiv(d.WP, 256)), dim3(256), 0, st, params[pi.lin30_b], params[pi.lin32_w],
                        params[pi.lin32_b], params[pi.rl0_b], params[pi.rl2_w], params[pi.rl2_b],
                        (float*)packed + po.c0row, H, d.H4, d.WP);
@@ -1434,6 +1442,15 @@ static size_t ws_total(const oard_config* c, const oard_topology* tp) {
 size_t oard_workspace_bytes(const oard_config* c, const oard_topology* tp) {
     if (!config_ok(c) || !tp) return 0;
     return ws_total(c, tp);
+}
+
+int oard_debug_lin3u_table(const oard_config* c, const void* packed, int layer, float* out, oard_stream_t stream) {
+    static_assert(OARD_L3T_FLOATS == L3T_FLOATS, "include/oard.h and csrc/oard_layout.h disagree on the table size");
+    if (!config_ok(c) || !packed || !out || layer < 0 || layer >= c->num_layers) return OARD_EINVAL;
+    const PackOff po = make_layout(c);
+    HIP_TRY(hipMemcpyAsync(out, (const float*)packed + po.layer[layer].l3t, (size_t)L3T_FLOATS * sizeof(float), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return OARD_OK;
 }
 
 int oard_active_inner_edges(const oard_config* c, const oard_topology* topo, const void* ws, size_t ws_bytes, int64_t* n_active,

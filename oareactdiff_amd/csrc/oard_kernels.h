@@ -458,6 +458,75 @@ __global__ __launch_bounds__(256) void k_edge_geo(TopoDev tp, const float* __res
 
 // radial basis (:63-69, 781-782) in float64; one thread per (inner edge, k); writes the RBF buffer that
 // EquiMessage re-reads every layer and the rbf section of the initial edge state
+// ---- the frame-scalar MLP as a table (see L3T_* in oard_layout.h) --------------------------------------------------------------------
+// p: raw parameter block w0[48][3] b0[48] w2[8][48] b2[8] w4[8] b4[1] (LayerOff::l3u); f(x) = lin3((x, 0, 0)) and f'(x), float64
+__device__ inline void lin3u_f64(const float* __restrict__ p, double x, double& f, double& df) {
+    double h[48], dh[48];
+    for (int k = 0; k < 48; ++k) {
+        const double w = (double)p[3 * k], z = w * x + (double)p[144 + k], s = 1.0 / (1.0 + exp(-z));
+        h[k] = z * s; dh[k] = w * s * (1.0 + z * (1.0 - s));
+    }
+    f = (double)p[592]; df = 0.0;
+    for (int j = 0; j < 8; ++j) {
+        double z = (double)p[576 + j], dz = 0.0;
+        for (int k = 0; k < 48; ++k) { const double w = (double)p[192 + j * 48 + k]; z += w * h[k]; dz += w * dh[k]; }
+        const double s = 1.0 / (1.0 + exp(-z));
+        f += (double)p[584 + j] * z * s; df += (double)p[584 + j] * dz * s * (1.0 + z * (1.0 - s));
+    }
+}
+// Hermite evaluation exactly as the node kernel does it (float32)
+OARD_DEV float lin3u_table_eval(const float* __restrict__ tab, float x) {
+    const float u = x * (1.0f / L3T_H), fl = floorf(u), t = u - fl;
+    const int i = (int)fl + L3T_N / 2;
+    const float f0 = tab[2 * i], d0 = tab[2 * i + 1], f1 = tab[2 * i + 2], d1 = tab[2 * i + 3];
+    const float t2 = t * t, t3 = t2 * t;
+    return (2.f * t3 - 3.f * t2 + 1.f) * f0 + (t3 - 2.f * t2 + t) * d0 + (3.f * t2 - 2.f * t3) * f1 + (t3 - t2) * d1;
+}
+// Two launches over (L3T_N / 256 blocks, layers): fill the points, then check every interval at its midpoint against the float64
+// function and set the flag (the last block of a layer to finish decides; tab[flag + 1 .. 3] = worst deviation, range, block counter).
+// ~30 us per weight update (a training step repacks every step), spread over 4 CUs per layer.
+struct L3tJobs { size_t l3u[OARD_MAX_LAYERS], l3t[OARD_MAX_LAYERS]; };
+__global__ __launch_bounds__(256) void k_lin3u_table_fill(float* __restrict__ blob, L3tJobs j) {
+    const float* p = blob + j.l3u[blockIdx.y];
+    float* tab = blob + j.l3t[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double f, df;
+    lin3u_f64(p, ((double)i - L3T_N / 2) * (double)L3T_H, f, df);
+    tab[2 * i] = (float)f; tab[2 * i + 1] = (float)(df * (double)L3T_H);
+    if (i == 0) {
+        lin3u_f64(p, (double)L3T_X, f, df);
+        tab[2 * L3T_N] = (float)f; tab[2 * L3T_N + 1] = (float)(df * (double)L3T_H);
+        tab[2 * (L3T_N + 1)] = 0.f; tab[2 * (L3T_N + 1) + 1] = 0.f; tab[2 * (L3T_N + 1) + 2] = 0.f; tab[2 * (L3T_N + 1) + 3] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void k_lin3u_table_check(float* __restrict__ blob, L3tJobs j) {
+    __shared__ float red_e[256], red_f[256];
+    const float* p = blob + j.l3u[blockIdx.y];
+    float* tab = blob + j.l3t[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x, t = threadIdx.x;
+    const double x = ((double)i - L3T_N / 2 + 0.5) * (double)L3T_H;
+    double f, df;
+    lin3u_f64(p, x, f, df);
+    red_e[t] = fabsf(lin3u_table_eval(tab, (float)x) - (float)f);
+    red_f[t] = fmaxf(fabsf(tab[2 * i]), fabsf((float)f));
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (t < d) { red_e[t] = fmaxf(red_e[t], red_e[t + d]); red_f[t] = fmaxf(red_f[t], red_f[t + d]); }
+        __syncthreads();
+    }
+    if (t == 0) {
+        // non-negative floats order like their bit patterns; a NaN pattern is larger than every finite one and fails the test below
+        unsigned* u = reinterpret_cast<unsigned*>(tab + 2 * (L3T_N + 1));
+        atomicMax(u + 1, __float_as_uint(red_e[0]));
+        atomicMax(u + 2, __float_as_uint(red_f[0]));
+        __threadfence();
+        if (atomicAdd(u + 3, 1u) == gridDim.x - 1) {
+            __threadfence();
+            const float e = __uint_as_float(atomicMax(u + 1, 0u)), fm = __uint_as_float(atomicMax(u + 2, 0u));
+            tab[2 * (L3T_N + 1)] = (e <= 2e-7f * fmaxf(fm, 1e-30f) && fm < 3e38f) ? 1.0f : 0.0f;
+        }
+    }
+}
 // Zeroes up to 64 short rows in one launch (the spare rows of the training tape, oard_hip.hip: forward_impl)
 struct ZeroRows { float* p[64]; int n[64]; int count; };
 __global__ __launch_bounds__(256) void k_zero_rows(ZeroRows z) {

@@ -31,6 +31,17 @@ struct RDims {  // the same numbers at run time
     }
 };
 
+// EquiUpdate's frame-scalar MLP (lin3: 3 -> 48 -> 8 -> 1, leftnet.py:333) sees (x, 0, 0) under the exact node frame: a smooth function
+// of ONE variable per layer, evaluated for every (node, channel).  Tabulated at pack time on [-L3T_X, L3T_X) in steps of L3T_H (a
+// power of two: index and fraction are exact in float32), values and derivatives from a float64 evaluation; cubic Hermite in the
+// kernel.  The table is CHECKED against the float64 function at three points per interval when it is built and carries a flag: the
+// kernel uses it only if the worst deviation is below 2e-7 of the function's range (float32 resolution of the direct evaluation),
+// and evaluates the MLP directly for arguments outside the table.
+#define L3T_X 16.0f
+#define L3T_H 0.03125f
+#define L3T_N 1024              // 2 L3T_X / L3T_H intervals
+#define L3T_FLOATS (2 * (L3T_N + 1) + 4)
+
 // ---- packed weight blob: offsets in floats -----------------------------------------------------
 struct LayerOff {
     // GCLMessage (leftnet.py:128-183)
@@ -39,6 +50,7 @@ struct LayerOff {
     size_t ln_q_w, ln_q_b, xp0, xp2, dp0, dp0b, dp2, dp2b, rbfp;
     // EquiUpdate (leftnet.py:292-346)
     size_t vp, xv0, xv2, l3u;   // l3u raw: w0[48*3] b0[48] w2[8*48] b2[8] w4[8] b4[1]
+    size_t l3t;                 // the frame-scalar MLP as a table (k_lin3u_table): [L3T_N + 1] x (f, f' h), then the "table is good" flag
     // LDS weight streams of the two hot edge kernels, chunks in consumption order (oard_edge_v1.h)
     size_t gcl_stream, equi_stream;
     size_t gcl_b3, equi_b3;     // split-precision streams of the two edge kernels (oard_edge_b3.h); built only when those kernels are enabled

@@ -488,8 +488,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
     // later written by the same lane), the tape slots s_mid[l] / s_in[l + 1] in training
     constexpr int HT = D::HT;
     constexpr int TPW = (HT + WAVES - 1) / WAVES;            // tiles owned per wave (upper bound)
-    __shared__ __attribute__((aligned(16))) float sm[6 * HT * 256 + 48 * 12];
+    __shared__ __attribute__((aligned(16))) float sm[6 * HT * 256 + 48 * 12 + L3T_FLOATS];
     float* l3s = sm + 6 * HT * 256;        // frame-scalar MLP weights (lin3u_stage)
+    float* l3t = l3s + 48 * 12;            // ... and its table (round 5: L3T_* in oard_layout.h; staged only when its flag is set)
+#ifdef OARD_NO_L3T                        // A/B build: always the MLP itself
+    const bool l3t_ok = false;
+#else
+    const bool l3t_ok = tp.npb > 4 && (wb + lo.l3t)[2 * (L3T_N + 1)] > 0.5f;          // uniform
+#endif
+    if (l3t_ok)
+        for (int i = threadIdx.x; i < 2 * (L3T_N + 1) / 4; i += WAVES * 64)
+            reinterpret_cast<f4*>(l3t)[i] = ld_f4(wb + lo.l3t + 4 * i);
+    if (l3t_ok && threadIdx.x < 2) l3t[2 * (L3T_N + 1) - 2 + threadIdx.x] = (wb + lo.l3t)[2 * (L3T_N + 1) - 2 + threadIdx.x];
 #ifdef OARD_TIMELINE
     const bool tl_on_ = blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0; int tl_n_ = 0;
 #endif
@@ -646,7 +656,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                 const float y = (c < tp.npb && 16 * t + f < D::H) ? lin3u1(l3s, l3, *cell) : 0.f;
                 *cell = y;                  // columns 4..15 of the block are padding and keep the raw projection
             } else {
-                sca = lin3u4(l3s, l3, sc);
+                // table where every argument of the wave lies inside it (|x| < L3T_X), the MLP itself otherwise
+                const bool in_tab = fabsf(sc.x) < L3T_X && fabsf(sc.y) < L3T_X && fabsf(sc.z) < L3T_X && fabsf(sc.w) < L3T_X;
+                if (l3t_ok && !__any(!in_tab))
+                    sca = (f4){lin3u_table_eval(l3t, sc.x), lin3u_table_eval(l3t, sc.y), lin3u_table_eval(l3t, sc.z), lin3u_table_eval(l3t, sc.w)};
+                else
+                    sca = lin3u4(l3s, l3, sc);
                 sca.x = f0 + 0 < D::H ? sca.x : 0.f; sca.y = f0 + 1 < D::H ? sca.y : 0.f;
                 sca.z = f0 + 2 < D::H ? sca.z : 0.f; sca.w = f0 + 3 < D::H ? sca.w : 0.f;
                 lds_st(in, HT + t, nb.lane, sca);

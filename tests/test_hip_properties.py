@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from _cases import Case, rel
+import leftnet_oracle as oracle  # noqa: E402
 from oareactdiff_amd.graph_tools import get_edges_index, get_mask_for_frag, get_n_frag_switch
 
 pytestmark = pytest.mark.gpu
@@ -206,3 +207,88 @@ def test_reflection_of_the_input(name, reflects):
         assert d_equiv <= 2e-5 and rel(h_m.cpu(), h.cpu()) <= 2e-5
     else:
         assert d_equiv > 1e-5
+
+
+def _lin3u_f64(sd, layer, x):
+    """EquiUpdate.lin3 (model/leftnet.py:310-316, 333) on (x, 0, 0) in float64."""
+    pre = f"model.update_layers.{layer}.lin3."
+    w0, b0, w2, b2, w4, b4 = (sd[pre + k].double() for k in ("0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias"))
+    h = torch.nn.functional.silu(x[:, None] * w0[:, 0][None] + b0[None])
+    return (torch.nn.functional.silu(h @ w2.t() + b2[None]) @ w4.t() + b4[None])[:, 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["synthetic", "steep"])
+def test_frame_scalar_table_is_checked_and_accurate(variant):
+    """The node stage evaluates EquiUpdate's frame-scalar MLP from a per-layer table (cubic Hermite on [-16, 16), built and verified
+    by oard_pack_weights).  With the synthetic production weights every layer's table must carry its "good" flag and reproduce the
+    float64 MLP to float32 resolution at random arguments; with a first layer scaled by 60 the function bends faster than the grid
+    resolves, the check must say so (flag off: the kernel then evaluates the MLP itself) - and the network output stays within the bar."""
+    import ctypes as C
+    from oareactdiff_amd import _capi
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    cfg = dict(PRODUCTION_LEFTNET_CONFIG, num_layers=2)
+    sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg, seed=3)
+    if variant == "steep":
+        sd["model.update_layers.1.lin3.0.weight"] = sd["model.update_layers.1.lin3.0.weight"] * 60.0
+    dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0, condition_nf=1, device=dev)
+    dyn.load_state_dict(sd, strict=True)
+    from test_hip_parity import _random_case
+    xh, ei, t, cond, nfs, cm = _random_case([12, 23, 7], 1.0, 3, cfg)
+    with torch.no_grad():
+        out, _ = dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+    ocfg = dyn._config()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    packed = dyn._get_packed(ocfg, stream)
+    flags = []
+    for layer in range(2):
+        tab = torch.empty(2054, device=dev)
+        _capi.check(_capi.lib().oard_debug_lin3u_table(C.byref(ocfg), packed.data_ptr(), layer, tab.data_ptr(), stream), "table")
+        tab = tab.cpu()
+        flags.append(float(tab[2050]))
+        g = torch.Generator().manual_seed(layer)
+        x = (torch.rand(4000, generator=g, dtype=torch.float64) * 2 - 1) * 15.9
+        x[:500] *= 1e-3                                            # the synthetic network's own arguments are small
+        xf = x.float()
+        u = xf * 32.0
+        fl = torch.floor(u)
+        tt, i = (u - fl), fl.long() + 512
+        f0, d0, f1, d1 = tab[2 * i], tab[2 * i + 1], tab[2 * i + 2], tab[2 * i + 3]
+        t2, t3 = tt * tt, tt * tt * tt
+        got = (2 * t3 - 3 * t2 + 1) * f0 + (t3 - 2 * t2 + tt) * d0 + (3 * t2 - 2 * t3) * f1 + (t3 - t2) * d1
+        ref = _lin3u_f64(sd, layer, xf.double())
+        err = float((got.double() - ref).abs().max() / ref.abs().max())
+        print(f"{variant} layer {layer}: flag {tab[2050]:.0f}, table's own check {tab[2051]:.2e} of range {tab[2052]:.2e}; Hermite vs float64 MLP {err:.2e}")
+        if flags[-1] > 0.5:
+            assert err <= 4e-7
+    assert flags == ([1.0, 1.0] if variant == "synthetic" else [1.0, 0.0])
+    ref = oracle.dynamics_forward({k: v.double() for k, v in sd.items()}, cfg, [x.double() for x in xh], ei, t.double(), cond.double(),
+                                  nfs, cm, 1, nodeframe="exact")
+    v = torch.cat([o[:, :3].cpu().double().reshape(-1) for o in out]); h = torch.cat([o[:, 3:].cpu().double().reshape(-1) for o in out])
+    rv = torch.cat([o[:, :3].reshape(-1) for o in ref]); rh = torch.cat([o[:, 3:].reshape(-1) for o in ref])
+    assert rel(v, rv) <= 1e-5 and rel(h, rh) <= 1e-5, (rel(v, rv), rel(h, rh))
+
+
+@pytest.mark.gpu
+def test_frame_scalar_arguments_outside_the_table_take_the_direct_path():
+    """vec_proj scaled so that the frame scalar leaves [-16, 16): the wave falls back to the MLP itself; still within the bar."""
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
+    from test_hip_parity import _random_case
+    dev = torch.device("cuda:0")
+    cfg = dict(PRODUCTION_LEFTNET_CONFIG, num_layers=2)
+    sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg, seed=3)
+    sd["model.update_layers.1.vec_proj.weight"] = sd["model.update_layers.1.vec_proj.weight"] * 3e5
+    dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0, condition_nf=1, device=dev)
+    dyn.load_state_dict(sd, strict=True)
+    xh, ei, t, cond, nfs, cm = _random_case([12, 23, 7], 1.0, 3, cfg)
+    with torch.no_grad():
+        out, _ = dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+    st = {}
+    ref = oracle.dynamics_forward({k: v.double() for k, v in sd.items()}, cfg, [x.double() for x in xh], ei, t.double(), cond.double(),
+                                  nfs, cm, 1, nodeframe="exact", stages=st)
+    v = torch.cat([o[:, :3].cpu().double().reshape(-1) for o in out]); h = torch.cat([o[:, 3:].cpu().double().reshape(-1) for o in out])
+    rv = torch.cat([o[:, :3].reshape(-1) for o in ref]); rh = torch.cat([o[:, 3:].reshape(-1) for o in ref])
+    assert rel(v, rv) <= 1e-5 and rel(h, rh) <= 1e-5, (rel(v, rv), rel(h, rh))

@@ -17,7 +17,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_ttrace13 -o t 
 python tools/prof_summary.py gpurun_out/${tag}_ttrace13/t_results.db > gpurun_out/${tag}_train_kernel_trace_summary_13steps.txt
 python tools/launch_diff.py gpurun_out/${tag}_train_kernel_trace_summary.txt gpurun_out/${tag}_train_kernel_trace_summary_13steps.txt 10 > gpurun_out/${tag}_train_launches_per_step.txt
 rm -rf gpurun_out/${tag}_ttrace gpurun_out/${tag}_ttrace13
-TK="k_wgrad k_gcl_edge_bwd k_equi_edge_bwd k_gcl_edge_v1 k_equi_edge_v1"
+TK="k_wgrad k_gcl_edge_bwd k_equi_edge_bwd k_gcl_edge_p k_gcl_edge_v1 k_equi_edge_v1"
 timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT -d gpurun_out/${tag}_tsq -o p -- $T --steps 3 > gpurun_out/${tag}_tsq.log 2>&1
 python tools/pmc_summary.py gpurun_out/${tag}_tsq/p_results.db --per-forward 1 $TK > gpurun_out/${tag}_train_pmc_sq.txt
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_tfetch -o p -- $T --steps 3 > gpurun_out/${tag}_tfetch.log 2>&1
