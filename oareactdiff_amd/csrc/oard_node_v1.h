@@ -518,8 +518,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
     const int a0 = listed ? al.pre[tp.act_ptr[n]] : tp.act_ptr[n];
     const int cnt = nb.valid ? (listed ? al.pre[tp.act_ptr[n + 1]] : tp.act_ptr[n + 1]) - a0 : 0;
     const int mx = wave_max(cnt);
-    auto row_of = [&](long long k) -> size_t { return (size_t)(listed ? al.rows[k] : (int)k); };
-    auto src_of = [&](long long k) -> int { return listed ? al.src[k] : tp.act_src[k]; };
+    auto row_of = [&](int k) -> int { return listed ? al.rows[k] : k; };
+    auto src_of = [&](int k) -> int { return listed ? al.src[k] : tp.act_src[k]; };
     const float inv_sqrt2 = 0.70710678118654752f, inv_sqrt3 = 0.57735026918962576f,
                 inv_sqrt_h = 1.0f / sqrtf((float)D::H);
 
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         f4 dx = f4zero(), v0 = f4zero(), v1 = f4zero(), v2 = f4zero();
         const f4 xn0 = ld_blk(xq, n, 3 * D::HP, t, nb.lane), xn1 = ld_blk(xq, n, 3 * D::HP, HT + t, nb.lane),
                  xn2 = ld_blk(xq, n, 3 * D::HP, 2 * HT + t, nb.lane);
-        const long long a_hi = max(tp.A - 1, 0LL);
+        const int a_hi = (int)max(tp.A - 1, 0LL);
         if (ROWS) {                                             // small batches: the wave's columns walk the edges (row_lanes)
             const RowLanes rl = row_lanes(tp.N, tp.npb, nb.lane);
             const int nn = min(blockIdx.x * tp.npb + rl.node, tp.N - 1);
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
                      zn2 = ld_blk(xq, nn, 3 * D::HP, 2 * HT + t, nb.lane);
             for (int k = 0; k < mx2; k += rl.L) {
                 const int kk = k + rl.slot;
-                const long long ke = min((long long)b0 + min(kk, max(cnt2 - 1, 0)), a_hi);      // list entry (clamped: discarded when kk >= cnt2)
-                const size_t a = cnt2 > 0 ? row_of(ke) : 0;
+                const int ke = min(b0 + min(kk, max(cnt2 - 1, 0)), a_hi);      // list entry (clamped: discarded when kk >= cnt2)
+                const size_t a = cnt2 > 0 ? (size_t)row_of(ke) : 0;
                 const int m = cnt2 > 0 ? src_of(ke) : 0;
                 const float* gp = geo + a * GEO_STRIDE;
                 const float gx = gp[2], gy = gp[3], gz = gp[4];
@@ -567,9 +567,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
         // two edges in flight per step, branch-free (out-of-range slots re-read a valid edge and are discarded)
         int mnext[2], rnext[2];                  // (source, row) of the next step's two edges; a node without edges reads nothing
         auto entry = [&](int kk, int& m, int& r) {
-            const long long ke = min((long long)a0 + min(kk, max(cnt - 1, 0)), a_hi);
+            const int ke = min(a0 + min(kk, max(cnt - 1, 0)), a_hi);
             m = cnt > 0 ? src_of(ke) : 0;
-            r = cnt > 0 ? (int)row_of(ke) : 0;
+            r = cnt > 0 ? row_of(ke) : 0;
         };
 #pragma unroll
         for (int i = 0; i < 2; ++i) entry(i, mnext[i], rnext[i]);
