@@ -95,3 +95,13 @@ def test_bench_launch_line_over_rccl_one_rank(mode):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    # the self-verifying part of the line, over RCCL on real hardware: the backend's own world size, the rank's device identity and clock
+    rk = d["ranks"]
+    assert rk["backend"] == "nccl" and rk["world_size"] == 1 and rk["distinct_devices"] == 1 and len(rk["per_rank"]) == 1
+    me = rk["per_rank"][0]
+    assert me["rank"] == 0 and me["device_index"] == 0 and me["device_name"] and me["pid"] > 0
+    assert me["pci_bus_id"] or me["uuid"], me                                  # something that tells two GPUs apart
+    assert abs(me["ms_per_step"] - d["ms_per_step"]) < 1e-6 and 0 < me["busy_ms_per_step"] <= me["ms_per_step"] + 1e-6
+    if mode == "train":                                                      # the bucket all-reduce's own device time and size
+        assert me["all_reduce_bytes"] == 4 * (d["train_step"]["trainable_parameters"] + 1) and me["all_reduce_ms_mean"] > 0
+        assert me["all_reduce_calls"] == 3

@@ -5,6 +5,9 @@
 tag=${1:-r3}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export OARD_PARTS=1
+# only fixed-distribution steps under the profiler: the (quick) sampling leg runs a diverging trajectory whose inner edges leave the cutoff -
+# EquiMessage then skips them, and its calls would pull the per-kernel averages of the trace down (round 5)
+export OARD_BENCH_SKIP=sampler
 B="python bench.py --precision bf16x3 --steps 4 --warmup 2 --no-cpu-baseline --quick"
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_b3trace -o t -- $B > gpurun_out/${tag}_b3trace.log 2>&1
 python tools/prof_summary.py gpurun_out/${tag}_b3trace/t_results.db > gpurun_out/${tag}_bf16x3_kernel_trace_summary.txt
