@@ -14,6 +14,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 #: demangled-name regex -> max scratch bytes per lane (the one known exception: the large-batch k_equi_node_v1)
 BUDGETS = {
     r"^void k_gcl_edge_v1<Dims<196, 96>, 8, 2, .*, 2, 3>": 0,
+    r"^void k_gcl_edge_p<Dims<196, 96>, ": 0,                 # persistent form (round 5): inference and training-mode instantiations
     r"^void k_equi_edge_v1<Dims<196, 96>, 8, ": 0,
     r"^void k_gcl_edge_bwd<": 0,
     r"^void k_equi_edge_bwd<": 0,
