@@ -58,13 +58,15 @@ OARD_DEV TileJob tile_job(const float* __restrict__ wp, int t, const float* in) 
 #ifndef OARD_NODE_SEQ_G
 #define OARD_NODE_SEQ_G 7       // chunks per pipeline step
 #endif
-// k_node_pre_v1 / k_gcl_node_v1 run at 84 / 94 registers of their 128: a longer step puts more weight chunks in flight per L2 round trip
-// (these stages wait for their weight fetches, ~1.7 us per step, not for their MFMAs) - round 5
+// k_node_pre_v1 / k_gcl_node_v1 have the registers for longer steps (84 / 94 of 128), but steps of 7 / 10 / 13 chunks measure the same
+// (node stages 2.46 / 2.465 / 2.478 ms, profiles/round5_notes.txt section 3), and the step length fixes which chunks land in dense_seq's
+// even / odd accumulators: 7 keeps the summation order the parity margins were measured with (config 1 under the default launch shapes:
+// worst of 51 calls 9.05e-6 with 7, 1.03e-5 with 10, tolerance 1e-5)
 #ifndef OARD_NODE_PRE_G
-#define OARD_NODE_PRE_G 10
+#define OARD_NODE_PRE_G 7
 #endif
 #ifndef OARD_GCL_NODE_G
-#define OARD_GCL_NODE_G 10
+#define OARD_GCL_NODE_G 7
 #endif
 // R = ring depth: the chunks of steps s+1 .. s+R-1 are in flight while step s issues its MFMAs ((R-1) x G x 4 VGPRs in flight,
 // R x G x 4 held).  R = 2 is the node kernels' shape (register budget of 13-wave workgroups); the latency edge kernels use R = 4:
@@ -102,8 +104,7 @@ OARD_DEV void dense_seq(const TileJob (&job)[N], int lane, f4 (&acc)[N]) {
 // vec1_proj): job[j].in is the first input, the others follow at STRIDE floats; acc[3 j + k] belongs to input k.  Every weight
 // chunk is fetched ONCE and feeds 3 x 4 MFMAs - as separate jobs the three components re-fetched the same chunks, and these stages
 // are bound by the L2 round trips of their weight fetches, not by their MFMAs (round 5: 78 -> 26 chunk fetches per wave in
-// k_equi_node_v1's vec_proj).  One accumulator per (tile, input): the K blocks are summed in order (dense_seq sums even and odd
-// blocks separately - a last-bit difference).
+// k_equi_node_v1's vec_proj).
 // The three B operands of a chunk are read by ONE volatile asm statement: written as plain LDS loads, hipcc moves the 3 x G reads of a
 // step - and, where two jobs share their inputs, the second job's as well - to the top of the block and spills them (660 bytes per lane in
 // k_equi_node_v1 at its 128-register cap; sched_barrier does not stop it, the motion happens before instruction scheduling).
@@ -126,10 +127,15 @@ OARD_DEV void mma_chunk_pinned(f4 a, f4 b, f4& acc) {
                  "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0"
                  : "+v"(acc) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
 }
-template <int KB, int N, int STRIDE, int G = OARD_NODE_SEQ_G, int R = 2>
+// SPLIT: even / odd chunks of a pipeline step on two accumulators per input, added at the end of the tile - dense_seq's summation order
+// (bit-identical to the three separate jobs this replaced); used where the registers allow it, the single chain elsewhere.
+template <int KB, int N, int STRIDE, int G = OARD_NODE_SEQ_G, bool SPLIT = false, int R = 2>
 OARD_DEV void dense_seq_xyz(const TileJob (&job)[N], int lane, f4 (&acc)[N * 3]) {
     constexpr int NG = (KB + G - 1) / G, S = N * NG;
     f4 a[R][G];
+    f4 c1[SPLIT ? 3 : 1];
+#pragma unroll
+    for (int k = 0; k < (SPLIT ? 3 : 1); ++k) c1[k] = f4zero();
     auto fetch = [&](int st) {
         const int j1 = st / NG, q1 = st % NG;
 #pragma unroll
@@ -149,10 +155,21 @@ OARD_DEV void dense_seq_xyz(const TileJob (&job)[N], int lane, f4 (&acc)[N * 3])
             if (q * G + i < KB) {
                 f4 x0, x1, x2;
                 lds_blk3<STRIDE>(job[j].in, q * G + i, lane, x0, x1, x2);
-                mma_chunk_pinned(a[st % R][i], x0, acc[3 * j + 0]);
-                mma_chunk_pinned(a[st % R][i], x1, acc[3 * j + 1]);
-                mma_chunk_pinned(a[st % R][i], x2, acc[3 * j + 2]);
+                if (SPLIT && (i & 1)) {
+                    mma_chunk_pinned(a[st % R][i], x0, c1[0]);
+                    mma_chunk_pinned(a[st % R][i], x1, c1[SPLIT ? 1 : 0]);
+                    mma_chunk_pinned(a[st % R][i], x2, c1[SPLIT ? 2 : 0]);
+                } else {
+                    mma_chunk_pinned(a[st % R][i], x0, acc[3 * j + 0]);
+                    mma_chunk_pinned(a[st % R][i], x1, acc[3 * j + 1]);
+                    mma_chunk_pinned(a[st % R][i], x2, acc[3 * j + 2]);
+                }
             }
+        if (SPLIT && q == NG - 1) {
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");       // (asm MFMA results are read by VALU: see below)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { acc[3 * j + k] += c1[k]; c1[k] = f4zero(); }
+        }
     }
     // the hazard recogniser does not look inside asm statements: cover the XDL-write -> VALU-read distance of the last MFMAs by hand
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
@@ -638,7 +655,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_equi_node_v1(TopoDev tp, const f
             f4 acc[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) acc[k] = f4zero();
-            dense_seq_xyz<HT, 2, HT * 256, (ROWS ? 5 : OARD_NODE_SEQ_G)>(job, nb.lane, acc);   // 5: no scratch in the small-batch instantiation
+            dense_seq_xyz<HT, 2, HT * 256, (ROWS ? 5 : OARD_NODE_SEQ_G), ROWS>(job, nb.lane, acc);    // (the small-batch instantiation has the registers for dense_seq's order)   // 5: no scratch in the small-batch instantiation
             const f4 v1[3] = {acc[0], acc[1], acc[2]}, v2[3] = {acc[3], acc[4], acc[5]};
 #pragma unroll
             for (int x = 0; x < 3; ++x) v2k[i][x] = v2[x];
@@ -868,7 +885,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_out_v1(TopoDev tp, const float* 
 #pragma unroll
             for (int x = 0; x < 3; ++x) acc[3 * i + x] = f4zero();
         }
-        dense_seq_xyz<HT, TPW, HT * 256>(job, nb.lane, acc);       // every chunk of vec1_proj feeds x, y and z
+        dense_seq_xyz<HT, TPW, HT * 256, OARD_NODE_SEQ_G, true>(job, nb.lane, acc);       // every chunk of vec1_proj feeds x, y and z
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
             if (nb.wave + i * WAVES < HT) {

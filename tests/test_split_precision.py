@@ -11,7 +11,7 @@ import os
 import pytest
 import torch
 
-from _cases import ALL_CASES, Case, debug_options, rel
+from _cases import ALL_CASES, THROUGHPUT, Case, debug_options, rel
 from test_hip_parity import _args, _dyn
 
 pytestmark = pytest.mark.gpu
@@ -22,7 +22,7 @@ TOL = 1e-5
 def test_split_precision_forward_matches_reference_f64(name):
     dev = torch.device("cuda:0")
     c = Case(name)
-    with torch.no_grad():
+    with debug_options(**THROUGHPUT), torch.no_grad():                   # (the split-precision forms exist for the throughput shapes)
         d32, d3 = _dyn(c, dev), _dyn(c, dev)
         d32.edge_precision, d3.edge_precision = "f32", "bf16x3"
         out32, _ = d32(*_args(c, dev))                                # the fp32 kernels
@@ -72,7 +72,7 @@ def test_edge_precision_attribute_switches_kernels_per_module():
     c = Case("g2_prod_b2_n23")
     a, b = _dyn(c, dev), _dyn(c, dev)
     a.edge_precision, b.edge_precision = "bf16x3", "f32"
-    with torch.no_grad():
+    with debug_options(**THROUGHPUT), torch.no_grad():
         oa1, _ = a(*_args(c, dev)); ob1, _ = b(*_args(c, dev)); oa2, _ = a(*_args(c, dev)); ob2, _ = b(*_args(c, dev))
         b.edge_precision = "bf16x3"
         ob3, _ = b(*_args(c, dev))
@@ -126,6 +126,10 @@ def test_two_precisions_on_two_threads_and_streams_are_bitwise_reproducible():
     mods = [_dyn(c, dev), _dyn(c, dev)]
     mods[0].edge_precision, mods[1].edge_precision = "f32", "bf16x3"
     args = [_args(c, dev), _args(c, dev)]
+    from oareactdiff_amd import _capi
+    from conftest import SUITE_OPTIONS
+    for k, v in THROUGHPUT.items():                    # (process-wide debug options, set for the whole test: the workers are threads)
+        assert _capi.lib().oard_debug_option(k.encode(), v) == 0
     with torch.no_grad():
         want = [[o.clone() for o in m(*a)[0]] for m, a in zip(mods, args)]
     torch.cuda.synchronize()
@@ -146,6 +150,8 @@ def test_two_precisions_on_two_threads_and_streams_are_bitwise_reproducible():
     th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
     [t.start() for t in th]
     [t.join() for t in th]
+    for k in THROUGHPUT:
+        _capi.lib().oard_debug_option(k.encode(), SUITE_OPTIONS[k])
     assert not errors, errors
     for i in range(2):
         for outs in got[i]:
