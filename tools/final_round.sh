@@ -11,6 +11,8 @@ bash tools/profile_cfg5.sh $tag > gpurun_out/profile_cfg5_$tag.log 2>&1
 bash tools/profile_wgrad.sh ${tag}_wgrad > gpurun_out/profile_wgrad_$tag.log 2>&1
 bash tools/timeline_train.sh $tag > /dev/null 2>&1
 cat gpurun_out/${tag}_source_stamp.txt
+# bench.py takes roofline.traffic from profiles/<tag>_*: the passes above ARE this round's (same sources, same box) - put them where it looks
+cp gpurun_out/${tag}_source_stamp.txt gpurun_out/${tag}*_pmc_*.txt profiles/
 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/bench_err.log
 python bench.py --mode train --steps 20 --warmup 3 > gpurun_out/${tag}_train_bench_line.json 2>/dev/null
 python bench.py --mode train --batch 14 --steps 20 --warmup 3 > gpurun_out/${tag}_train_b14.json 2>/dev/null
