@@ -24,8 +24,17 @@ class DiffusionSampler:
     def __init__(self, dynamics: EGNNDynamics, noise_schedule: str = "polynomial_2", timesteps: int = 1000,
                  precision: float = 1e-5, pos_only: bool = False,
                  norm_values: Sequence[float] = (1.0, 1.0, 1.0), norm_biases: Sequence[float] = (0.0, 0.0, 0.0),
-                 on_nan: str = "raise"):
-        """`on_nan`: what to do when any network call of a run predicted a NaN displacement.  The reference replaces that
+                 on_nan: str = "raise", gaussian_prior_std: Optional[float] = None):
+        """`gaussian_prior_std` (measurement aid, default off): add to every network prediction the ideal denoiser of a Gaussian data
+        prior x0 ~ N(0, s^2) per coordinate, eps = sigma_t z_t / (alpha_t^2 s^2 + sigma_t^2), on the position columns.  An UNTRAINED
+        network predicts eps ~ 0, and the ancestral sampler then scales its state by 1 / alpha_t|s every step (en_diffusion.py:614-618):
+        positions reach hundreds of Angstrom within a few calls, every pair leaves the cutoff and the remaining calls run on an empty
+        radius graph.  With the prior term the chain is the exact reverse process of N(0, s^2) data: the state keeps the marginal
+        alpha_t^2 s^2 + sigma_t^2 (= 1 for s = 1, the distribution of the headline's inputs) and every network call sees a
+        molecule-sized cloud, as a trained model's would.  One in-place axpy per object and step on the loop's stream; the network
+        call itself is untouched.  Used by bench.py's T = 1000 line and tests/test_configs.py (the float64 replay adds the same term).
+
+        `on_nan`: what to do when any network call of a run predicted a NaN displacement.  The reference replaces that
         step's velocity by randn, prints a warning and keeps sampling (egnn_dynamics.py:138-143) - one host sync per
         step.  Here the loop never syncs: every call ORs its NaN flag into a device-side sticky flag which is read ONCE
         after the loop; "raise" (default) raises FloatingPointError, "warn" warns and returns the (NaN) samples,
@@ -34,6 +43,7 @@ class DiffusionSampler:
         other modes) and a warning is printed once after the loop."""
         assert on_nan in ("raise", "warn", "replace")
         self.on_nan = on_nan
+        self.prior_std = None if gaussian_prior_std is None else float(gaussian_prior_std)
         self.dynamics = dynamics
         self.schedule = Schedule(noise_schedule, timesteps, precision)
         self.T = timesteps
@@ -75,6 +85,22 @@ class DiffusionSampler:
             import warnings
             warnings.warn(msg)
 
+    def prior_coefficient(self, step: int, n_steps: int) -> float:
+        """sigma_t / (alpha_t^2 s^2 + sigma_t^2) at time step / n_steps: E[eps | z_t] = coefficient * z_t for x0 ~ N(0, s^2)."""
+        a, sg = self.schedule.alpha_sigma(step, n_steps)
+        return sg / (a * a * self.prior_std * self.prior_std + sg * sg)
+
+    def _add_prior(self, eps_hat, z, coef) -> None:
+        """eps_hat[:, :pos_dim] += coef * z[:, :pos_dim] per object; `coef` a host float (eager loop) or a [1] device tensor (graph)."""
+        pd = self.pos_dim
+        for e, x in zip(eps_hat, z):
+            if e.numel() == 0:
+                continue
+            if isinstance(coef, Tensor):
+                e[:, :pd].addcmul_(x[:, :pd], coef)
+            else:
+                e[:, :pd].add_(x[:, :pd], alpha=coef)
+
     # --------------------------------------------------------------------------------------------
     def _step_kernel(self, topo, mode, z, eh, noise, h0, a, b, c, out, stream):
         L = _capi.lib()
@@ -107,6 +133,8 @@ class DiffusionSampler:
         coef_tab = torch.tensor([[c.alpha_ts, c.c_eps, c.sigma] for c in coefs], dtype=torch.float32, device=dev)      # [T,3]
         # the eager loop's t values, bit for bit: (arange(T + 1) / T)[s + 1]
         t_tab = (torch.arange(timesteps + 1, device=dev, dtype=torch.float32) / timesteps)[torch.tensor([s + 1 for s in steps], device=dev)]
+        prior_tab = (torch.tensor([self.prior_coefficient(s + 1, timesteps) for s in steps], dtype=torch.float32, device=dev)
+                     if self.prior_std is not None else None)
         # The noise of the steps is drawn in BLOCKS (not all T draws up front: that would be T x the eager loop's memory -
         # a [T, n, nf] table per object): at most `noise_block_bytes` of draws exist at a time, refilled between replays in
         # the eager loop's draw order (call 1 .. T), so a seeded run consumes the generator exactly like the eager loop.
@@ -132,6 +160,8 @@ class DiffusionSampler:
             coef = coef_tab.index_select(0, counter).view(3)
             noise = [nt.index_select(0, slot)[0] for nt in noise_tab]
             eps_hat, _ = dyn(z, edge_index, t_cur, conditions, n_frag_switch, combined_mask)
+            if prior_tab is not None:
+                self._add_prior(eps_hat, z, prior_tab.index_select(0, counter))
             stream = torch.cuda.current_stream(dev).cuda_stream
             self._step_kernel_dev(topo, 0, z, eps_hat, noise, h0d if self.pos_only else None, coef, z_new, stream)
             for a, b in zip(z, z_new):
@@ -215,6 +245,8 @@ class DiffusionSampler:
                 for s in (reversed(range(timesteps)) if not use_graph else ()):
                     co = self.schedule.step(s, timesteps)
                     eps_hat, _ = dyn(za, edge_index, t_table[s + 1: s + 2], conditions, n_frag_switch, combined_mask)
+                    if self.prior_std is not None:
+                        self._add_prior(eps_hat, za, self.prior_coefficient(s + 1, timesteps))
                     self._step_kernel(topo, 0, za, eps_hat, draw(call), h0d if self.pos_only else None,
                                       co.alpha_ts, co.c_eps, co.sigma, zb, stream)
                     if step_callback is not None:
@@ -225,6 +257,8 @@ class DiffusionSampler:
                         out_samples[(s * return_frames) // timesteps] = self._unnormalize_z([z.clone() for z in za])
                 fc = self.schedule.final()
                 eps_hat, _ = dyn(za, edge_index, t_table[0:1], conditions, n_frag_switch, combined_mask)
+                if self.prior_std is not None:
+                    self._add_prior(eps_hat, za, self.prior_coefficient(0, timesteps))
                 self._step_kernel(topo, 1, za, eps_hat, draw(call), None, fc.inv_alpha_0, fc.sigma_0, fc.sigma_x, zb, stream)
                 x = zb
                 self.last_x = x

@@ -85,7 +85,18 @@ def test_benched_launch_persistent_and_tile_gcl_kernels_agree():
 def test_config1_single_reaction_t50_sampler():
     """BASELINE configs[0]: B=1, 20 atoms per object, T=50 polynomial_2, production dims.  The device sampler follows a
     float64 replay of the same noise over the 51 network calls (accumulated tolerance 5e-5), and every single network
-    call, fed with the float64 trajectory's state, is within 1e-5 of the float64 oracle."""
+    call, fed with the float64 trajectory's state, is within 1e-5 of the float64 oracle ON IDENTICAL INPUTS.
+
+    Round 6, two changes to what this test measures (the arithmetic under test did not change):
+    * the trajectory.  With untrained weights eps_hat ~ 0 and the sampler multiplies its state by 1 / alpha_t|s per step: by the 4th
+      call every pair is beyond the 10 A cutoff (|pos| ~ 100 ... 700 A), 47 of the 51 calls predicted an exactly-zero velocity and
+      the worst call of the old test (9.05e-6 ... 1.03e-5) was the LAST one before that: 2 edges left inside the cutoff, |vel| ~ 2e-12.
+      `gaussian_prior_std=1` (sampler.py) adds the ideal denoiser of N(0, 1) data to both the device loop and the float64 replay:
+      every call now sees a molecule-sized cloud with all 1 140 same-object edges active;
+    * identical inputs.  The float64 oracle used to see the float64 state and the device its float32 rounding.  On that old worst
+      call the ROUNDING OF THE INPUTS ALONE moves the float64 oracle by 3.9e-5 (ulp(80 A) against 10 A - d in the cutoff envelope),
+      while float32 arithmetic on identical inputs is 1.3e-6 off (measured with the oracle on the CPU).  The oracle is now
+      evaluated on the float32-rounded state, which is what "identical inputs" means; the other figure is printed beside it."""
     from oareactdiff_amd import DiffusionSampler
     dev = torch.device("cuda:0")
     dyn, sd, cfg = _prod_dynamics(dev)
@@ -107,15 +118,20 @@ def test_config1_single_reaction_t50_sampler():
             g = torch.Generator().manual_seed(1000 + i)
             gens[i] = [torch.randn(nf, 9, generator=g) for _ in range(3)]
         return gens[i]
-    smp = DiffusionSampler(dyn, "polynomial_2", T, 1e-5, pos_only=True)
+    smp = DiffusionSampler(dyn, "polynomial_2", T, 1e-5, pos_only=True, gaussian_prior_std=1.0)
     smp.sample(B, frag, conditions=cond, h0=h0, noise_fn=noise)
     sd64 = {k: v.double() for k, v in sd.items()}
     calls = []
 
+    def net64(zt, t):
+        return oracle.dynamics_forward(sd64, cfg, zt, ei, t, cond.double(), nfs, cm, 1, nodeframe="exact")
+
     def dyn64(zt, t):
-        o = oracle.dynamics_forward(sd64, cfg, zt, ei, t, cond.double(), nfs, cm, 1, nodeframe="exact")
-        calls.append(([z.clone() for z in zt], t.clone(), o))
-        return o
+        st = {}
+        o = oracle.dynamics_forward(sd64, cfg, zt, ei, t, cond.double(), nfs, cm, 1, nodeframe="exact", stages=st)
+        calls.append(([z.clone() for z in zt], t.clone(), o, int(st["edge_mask"].sum())))
+        c = smp.prior_coefficient(int(round(float(t.reshape(-1)[0]) * T)), T)          # the device loop's coefficient
+        return [torch.cat([x[:, :3] + c * z[:, :3], x[:, 3:]], dim=1) for x, z in zip(o, zt)]
     torch.set_default_dtype(torch.float64)
     try:
         table = so.gamma_table("polynomial_2", T, 1e-5).double()
@@ -127,16 +143,22 @@ def test_config1_single_reaction_t50_sampler():
     want = torch.cat([x64[k][:, :3].reshape(-1) for k in range(3)])
     traj = rel(got, want)
     assert len(calls) == T + 1
-    per_call = []
-    for zt, t, o in calls:                               # teacher-forced: the HIP network on the float64 trajectory's inputs
+    inner = int((nfs[ei[0]] == nfs[ei[1]]).sum())
+    assert min(c[3] for c in calls) == inner, "the trajectory left the cutoff: the calls behind that point test nothing"
+    per_call, unrounded = [], []
+    for zt, t, o, _ in calls:                            # teacher-forced: the HIP network on the float64 trajectory's state
+        z32 = [z.float() for z in zt]
         with torch.no_grad():
-            out, _ = dyn([z.float().to(dev) for z in zt], ei.to(dev), t.float().to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+            out, _ = dyn([z.to(dev) for z in z32], ei.to(dev), t.float().to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
         v = torch.cat([x[:, :3].cpu().double().reshape(-1) for x in out])
-        rv = torch.cat([x[:, :3].reshape(-1) for x in o])
-        per_call.append(rel(v, rv))
-    print(f"config 1: trajectory error {traj:.2e} over {T + 1} calls; per network call max {max(per_call):.2e} "
-          f"median {sorted(per_call)[len(per_call) // 2]:.2e}")
-    assert max(per_call) <= TOL
+        o_same = net64([z.double() for z in z32], t.float().double())                  # the oracle on the SAME float32 numbers
+        per_call.append(rel(v, torch.cat([x[:, :3].reshape(-1) for x in o_same])))
+        unrounded.append(rel(v, torch.cat([x[:, :3].reshape(-1) for x in o])))
+    print(f"config 1: trajectory error {traj:.2e} over {T + 1} calls, {inner} of {inner} inner edges active in every call; per network "
+          f"call on identical inputs max {max(per_call):.2e} median {sorted(per_call)[len(per_call) // 2]:.2e} "
+          f"(against the oracle on the unrounded float64 state: max {max(unrounded):.2e})")
+    assert max(per_call) <= 5e-6                         # gate with margin: measured <= 3e-6 under both launch-shape settings
+    assert max(unrounded) <= TOL
     assert traj <= 5e-5
 
 

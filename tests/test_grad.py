@@ -7,7 +7,8 @@ float64 evaluations (reference vs oracle, different summation order) differ by u
 forward's "1e-5 of the largest entry, per tensor" cannot be a per-tensor gate for every gradient tensor in float32.
 Gates: (i) flat gradient |g - g64|_2 / |g64|_2 <= 2e-5; (ii) per tensor <= 1e-5 for every tensor whose reference
 float32-vs-float64 gap is below 1e-3 (the well-conditioned ones: all Linear weights of the edge / node MLPs), and
-<= a tenth of the reference's own float32 gap for the rest.  Printed per tensor beside the reference's gap."""
+<= a tenth of the reference's own float32 gap for the rest; one named exception (`ILL_CONDITIONED_SCALAR_SUMS`: the scalar gate's two
+sums over every edge, 2e-5 where the reference's gap is >= 1e-4).  Printed per tensor beside the reference's gap."""
 import pytest
 import torch
 
@@ -44,13 +45,25 @@ def test_oracle_autograd_matches_reference_gradients(name):
     assert flat_x <= 1e-7 and max(errs_x.values()) <= 1e-5, (flat_x, max(errs_x.items(), key=lambda kv: kv[1]))
 
 
-def grad_tol(ref_f32_gap: float) -> float:
-    """Per-tensor gate of a float32 gradient against the reference's float64 one: 1e-5 relative, but never tighter than a tenth of the
-    error the REFERENCE's own float32 run has on that tensor (recorded in the fixture).  The cancellation-heavy single scalars - the bias of
-    att_mlp: a sum over every edge of terms of both signs - sit at 1e-4 ... 8e-4 in the reference's float32 and at ~1e-5 here, where the last
-    bits depend on the launch shape (g9_grad_prod_n23, layer 5: 1.07e-5 with the latency kernels, reference float32 7.8e-4).  Continuous in
-    the gap: the earlier form switched from 1e-5 to gap / 10 at gap = 1e-3."""
-    return max(1e-5, 0.1 * ref_f32_gap)
+#: the named exception of `grad_tol`: the two gradients of a GCL layer's scalar gate (att_mlp: H -> 1).  Each is the signed sum over EVERY
+#: edge of `da_e` (times SiLU(z2_e) for the weight), condition ~ sqrt(E): on g9_grad_prod_n23, layer 5, the reference's own float32 run is
+#: off by 7.8e-4, plain torch float32 with our float64 geometry / exact node frame by 5.3e-6, the same with the whole gate (forward and
+#: backward, its sums included) evaluated in float64 by 6.1e-6 (round 6, oracle on the CPU) - the error arrives with the float32 cotangent,
+#: no accumulation order inside the gate removes it - and the HIP path by 0.9e-5 ... 1.07e-5 depending on the launch shape.
+ILL_CONDITIONED_SCALAR_SUMS = (".att_mlp.mlp.0.linear.bias", ".att_mlp.mlp.0.linear.weight")
+
+
+def grad_tol(ref_f32_gap: float, name: str = "") -> float:
+    """Per-tensor gate of a float32 gradient against the reference's float64 one (relative to the tensor's largest entry):
+      * 1e-5, flat, for every tensor on which the REFERENCE's own float32 run is within 1e-3 of its float64 run;
+      * 2e-5 for the named cancellation-heavy sums above, and only where the reference's float32 gap shows the cancellation (>= 1e-4);
+      * a tenth of the reference's float32 gap for the tensors it cannot evaluate itself (gap >= 1e-3: remainders of cancelling sums).
+    Round 5 had relaxed the first class to max(1e-5, gap / 10) - up to 1e-4 for any tensor - to admit ONE scalar at 1.07e-5."""
+    if ref_f32_gap >= 1e-3:
+        return 0.1 * ref_f32_gap
+    if ref_f32_gap >= 1e-4 and name.endswith(ILL_CONDITIONED_SCALAR_SUMS):
+        return 2e-5
+    return 1e-5
 
 
 @pytest.mark.gpu
@@ -75,7 +88,7 @@ def test_hip_training_step_gradients_match_reference_f64(name):
     print(f"\n{name}: loss {float(loss):.8f} (ref64 {ref_loss:.8f}); flat gradient error {flat:.2e}")
     bad = []
     for n in sorted(errs, key=lambda k: -errs[k]):
-        tol = grad_tol(gap[n])
+        tol = grad_tol(gap[n], n)
         flag = "" if errs[n] <= tol else "   <-- above tolerance"
         if flag:
             bad.append(n)
@@ -113,7 +126,7 @@ def test_benched_training_launch_reproduces_the_reference_gradients():
         sub.mean(0).backward()
         grads = {n: p.grad for n, p in dyn.named_parameters() if p.grad is not None}
         errs, flat = c.compare(grads)
-        bad = [n for n in errs if errs[n] > grad_tol(gap[n])]
+        bad = [n for n in errs if errs[n] > grad_tol(gap[n], n)]
         worst = max(errs, key=lambda k: errs[k])
         print(f"\nB=64 launch, fixture in slots {slots}: per-reaction nll error {e_nll:.2e}; flat gradient error {flat:.2e}; "
               f"worst tensor {worst} {errs[worst]:.2e} (reference f32: {gap[worst]:.2e})")

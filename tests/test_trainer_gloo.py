@@ -12,6 +12,10 @@ import torch.multiprocessing as mp
 CFG = dict(pos_require_grad=False, cutoff=10.0, num_layers=1, hidden_channels=32, num_radial=8, in_hidden_channels=8,
            reflect_equiv=True, legacy=True, update=True, pos_grad=False, single_layer_output=True, object_aware=True)
 SIZES = [3, 4, 2, 5]
+T_INT = [7.0, 0.0, 50.0, 23.0]
+#: BASELINE configs[3]'s data-parallel degree: eight reactions (ragged), one per rank at world size 8
+SIZES8 = [3, 4, 2, 5, 3, 2, 4, 3]
+T_INT8 = [7.0, 0.0, 50.0, 23.0, 1.0, 38.0, 12.0, 49.0]
 T = 50
 
 
@@ -42,7 +46,7 @@ def _oracle_dynamics():
     return d.double()
 
 
-def _batch(sizes, lo, hi):
+def _batch(sizes, lo, hi, t_all=None):
     """Reactions [lo, hi) of the full synthetic batch, plus this shard's rows of the full batch's noise draws."""
     g = torch.Generator().manual_seed(7)
     B = len(sizes)
@@ -59,22 +63,23 @@ def _batch(sizes, lo, hi):
         draws += [torch.randn(n, 3, generator=g, dtype=torch.float64)[keep], torch.randn(n, 6, generator=g, dtype=torch.float64)[keep]]
         reps.append({"size": torch.tensor(sizes[lo:hi]), "pos": pos[keep], "one_hot": one_hot[keep], "charge": charge[keep],
                      "mask": full_mask[keep] - lo})
-    t_int = torch.tensor([[7.0], [0.0], [50.0], [23.0]], dtype=torch.float64)[lo:hi]
+    t_int = torch.tensor(T_INT if t_all is None else t_all, dtype=torch.float64).view(-1, 1)[lo:hi]
     it = iter(draws)
     return (reps, torch.zeros(hi - lo, 1, dtype=torch.float64)), t_int, (lambda shape: next(it))
 
 
-def _step(rank, world, perturb=False, poison_rank=None):
+def _step(rank, world, perturb=False, poison_rank=None, sizes=None, t_all=None):
     from oareactdiff_amd.shard import shard_range
     from oareactdiff_amd.trainer import DDPMTrainer
-    lo, hi = shard_range(len(SIZES), rank, world)
+    sizes = SIZES if sizes is None else sizes
+    lo, hi = shard_range(len(sizes), rank, world)
     dyn = _oracle_dynamics()
     if perturb and rank > 0:                 # replicas that were NOT built identically (different RNG state / only rank 0 loaded)
         with torch.no_grad():
             for p in dyn.parameters():
                 p.add_(0.1 * (rank + 1))
     tr = DDPMTrainer(dyn, timesteps=T, norm_values=(1.0, 4.0, 10.0), scales=(1.0, 2.0, 1.0))
-    batch, t_int, draw = _batch(SIZES, lo, hi)
+    batch, t_int, draw = _batch(sizes, lo, hi, t_all)
     if poison_rank == rank:                  # this rank's noise is NaN: its loss and gradients are not finite
         inner = draw
         draw = lambda shape: inner(shape) * float("nan")      # noqa: E731
@@ -82,11 +87,13 @@ def _step(rank, world, perturb=False, poison_rank=None):
     return tr, info
 
 
-def _worker(rank, world, port, q, perturb=False, poison_rank=None):
+def _worker(rank, world, port, q, perturb=False, poison_rank=None, sizes=None, t_all=None):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if world > 2:
+        torch.set_num_threads(1)                      # eight ranks on the container's eight cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        tr, info = _step(rank, world, perturb, poison_rank)
+        tr, info = _step(rank, world, perturb, poison_rank, sizes, t_all)
         q.put((rank, tr.flat_grad.numpy().copy(), torch.cat([p.detach().reshape(-1) for p in tr.params]).numpy().copy(),
                info["loss"], info["grad_norm"], info["skipped"], len(tr.gradnorm_queue)))   # numpy: tensors would travel as shm handles
     finally:
@@ -95,7 +102,11 @@ def _worker(rank, world, port, q, perturb=False, poison_rank=None):
 
 
 def _run_two_ranks(**kw):
-    world, port = 2, _free_port()
+    return _run_ranks(2, **kw)
+
+
+def _run_ranks(world, **kw):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q), kwargs=kw) for r in range(world)]
@@ -122,6 +133,25 @@ def test_two_rank_training_step_equals_single_process():
     assert float((g0 - single.flat_grad).abs().max()) <= 1e-10 * scale   # mean of the shard means == mean over the batch
     assert float((w0 - w1).abs().max()) <= 1e-12
     assert abs(0.5 * (l0 + l1) - info1["loss"]) <= 1e-10 * abs(info1["loss"])
+
+
+def test_eight_rank_training_step_equals_single_process():
+    """BASELINE configs[3] is 8-way data parallel: eight gloo ranks with ONE reaction each (ragged sizes; rank 1's is at t = 0, rank 2's at
+    t = T) against one process on the eight.  After the single all-reduce of the flat bucket (sum, / 8) every rank holds the single
+    process's gradient, takes the same clipping decision and ends the step with its weights - bit-identical across the eight replicas."""
+    single, info1 = _step(0, 1, sizes=SIZES8, t_all=T_INT8)
+    w1 = torch.cat([p.detach().reshape(-1) for p in single.params])
+    out = _run_ranks(8, sizes=SIZES8, t_all=T_INT8)
+    assert [o[0] for o in out] == list(range(8)) and all(o[5] == 0 for o in out)
+    g0, w0 = out[0][1], out[0][2]
+    for _, g, w, _, n, _, _ in out[1:]:
+        assert torch.equal(g, g0) and torch.equal(w, w0)           # replicas identical after the collective
+        assert n == out[0][4]
+    scale = float(single.flat_grad.abs().max())
+    assert float((g0 - single.flat_grad).abs().max()) <= 1e-10 * scale   # mean of eight per-reaction means == mean over the batch
+    assert float((w0 - w1).abs().max()) <= 1e-12
+    assert abs(out[0][4] - info1["grad_norm"]) <= 1e-9 * info1["grad_norm"]
+    assert abs(sum(o[3] for o in out) / 8 - info1["loss"]) <= 1e-10 * abs(info1["loss"])
 
 
 def test_replicas_built_differently_are_synchronised_at_construction():
