@@ -127,6 +127,28 @@ OARD_DEV void mma_chunk_pinned(f4 a, f4 b, f4& acc) {
                  "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0"
                  : "+v"(acc) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
 }
+// The LAST chunk of a group of three chains: the z chain's four MFMAs, then - INSIDE the string, where neither the scheduler nor the
+// register allocator can put anything - the wait states that an XDL result needs before anything but an accumulating MFMA may touch it
+// (hipcc's hazard recogniser does not look inside asm statements, so nothing else would insert them).  The x and y accumulators are "+v"
+// operands of this statement too: it is ordered behind their last MFMAs by data dependence, and every later reader of any of the three
+// - VALU, a store, a spill - is ordered behind IT, hence behind the wait states.  (Round 5 had the s_nops in a separate statement that
+// named no accumulator: hipcc was free to schedule a dependent add, copy or spill store in front of it.)
+OARD_DEV void mma_chunk_pinned_last(f4 a, f4 b, f4& acc, f4& other0, f4& other1) {
+    asm volatile("s_nop 1\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %7, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %9, %0\n\t"
+                 "v_mfma_f32_16x16x4_f32 %0, %6, %10, %0\n\t"
+                 "s_nop 7\n\ts_nop 7\n\ts_nop 3"
+                 : "+v"(acc), "+v"(other0), "+v"(other1)
+                 : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+}
+constexpr int last_chunk_at(int kb, int g, int parity) {         // last chunk of a job whose position inside its pipeline step has this parity
+    int r = -1;
+    for (int ch = 0; ch < kb; ++ch)
+        if (((ch % g) & 1) == parity) r = ch;
+    return r;
+}
 // SPLIT: even / odd chunks of a pipeline step on two accumulators per input, added at the end of the tile - dense_seq's summation order
 // (bit-identical to the three separate jobs this replaced); used where the registers allow it, the single chain elsewhere.
 template <int KB, int N, int STRIDE, int G = OARD_NODE_SEQ_G, bool SPLIT = false, int R = 2>
@@ -145,6 +167,11 @@ OARD_DEV void dense_seq_xyz(const TileJob (&job)[N], int lane, f4 (&acc)[N * 3])
 #pragma unroll
     for (int st = 0; st < R - 1; ++st)
         if (st < S) fetch(st);
+    // The chunk that ends a job's chains carries the wait states (mma_chunk_pinned_last).  With SPLIT a job has two groups of chains, on
+    // acc (even positions of a pipeline step) and on c1 (odd positions): each group's last chunk is marked, so both are settled when
+    // `acc += c1` reads them.
+    constexpr int LAST_EVEN = SPLIT ? last_chunk_at(KB, G, 0) : KB - 1;
+    constexpr int LAST_ODD = SPLIT ? last_chunk_at(KB, G, 1) : -1;
 #pragma unroll
     for (int st = 0; st < S; ++st) {
         const int j = st / NG, q = st % NG;
@@ -153,26 +180,27 @@ OARD_DEV void dense_seq_xyz(const TileJob (&job)[N], int lane, f4 (&acc)[N * 3])
 #pragma unroll
         for (int i = 0; i < G; ++i)
             if (q * G + i < KB) {
+                const int ch = q * G + i;
+                const bool last = ch == LAST_EVEN || ch == LAST_ODD;
                 f4 x0, x1, x2;
-                lds_blk3<STRIDE>(job[j].in, q * G + i, lane, x0, x1, x2);
+                lds_blk3<STRIDE>(job[j].in, ch, lane, x0, x1, x2);
                 if (SPLIT && (i & 1)) {
                     mma_chunk_pinned(a[st % R][i], x0, c1[0]);
                     mma_chunk_pinned(a[st % R][i], x1, c1[SPLIT ? 1 : 0]);
-                    mma_chunk_pinned(a[st % R][i], x2, c1[SPLIT ? 2 : 0]);
+                    if (last) mma_chunk_pinned_last(a[st % R][i], x2, c1[SPLIT ? 2 : 0], c1[0], c1[SPLIT ? 1 : 0]);
+                    else mma_chunk_pinned(a[st % R][i], x2, c1[SPLIT ? 2 : 0]);
                 } else {
                     mma_chunk_pinned(a[st % R][i], x0, acc[3 * j + 0]);
                     mma_chunk_pinned(a[st % R][i], x1, acc[3 * j + 1]);
-                    mma_chunk_pinned(a[st % R][i], x2, acc[3 * j + 2]);
+                    if (last) mma_chunk_pinned_last(a[st % R][i], x2, acc[3 * j + 2], acc[3 * j + 0], acc[3 * j + 1]);
+                    else mma_chunk_pinned(a[st % R][i], x2, acc[3 * j + 2]);
                 }
             }
         if (SPLIT && q == NG - 1) {
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");       // (asm MFMA results are read by VALU: see below)
 #pragma unroll
             for (int k = 0; k < 3; ++k) { acc[3 * j + k] += c1[k]; c1[k] = f4zero(); }
         }
     }
-    // the hazard recogniser does not look inside asm statements: cover the XDL-write -> VALU-read distance of the last MFMAs by hand
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
 }
 // LayerNorm statistics of an LDS vector (every wave computes them redundantly)
 template <int HT, int H>
