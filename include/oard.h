@@ -425,6 +425,33 @@ int oard_adamw_step_dev(float* param_dev, const float* grad_dev, float* exp_avg_
                         double* clip_state_dev, int capacity, const float* grad_norm_dev, const float* flag_dev, float* out4_dev,
                         oard_stream_t stream);
 
+/* ---- general edge lists (round 6) --------------------------------------------------------------------------------------------
+ * Replaces: EGNNDynamics.forward on an edge_index that is NOT the complete graph per sample.  The reference accepts any edge list
+ * (dynamics/egnn_dynamics.py:63-72), builds incomplete ones with get_edges_index(..., edge_cutoff=) (utils/_graph_tools.py:31-33, plumbed
+ * through trainer/pl_trainer.py:68,94 and dynamics/_base.py:59), and its model tests run disconnected and cut graphs
+ * (tests/model/test_equiv.py:177-230, tests/model/test_subgraphs.py:285-339).  Production never leaves the complete graph
+ * (trainer/train_ts1x.py:106), so this path is built for parity, not throughput (csrc/oard_general.h): explicit edge list, CSR gathers in
+ * edge order, the reference's literal node frame (leftnet.py:812-834) on float64 geometry, float64 accumulation, raw (unpacked) parameters.
+ * Inference only.
+ *
+ * oard_graph_create: host arrays in (combined_mask / n_frag_switch as for oard_topology_create; edge_index [2, E] row-major, reference
+ * node ids; self loops, duplicates and edges across samples are taken as given, as the reference does), device tables out.
+ * oard_graph_is_complete: 1 iff the edge SET is get_edges_index(combined_mask, remove_self_edge=True) in any order - the caller may then
+ * use oard_forward instead.  oard_graph_forward: as oard_forward, with the canonical parameter pointers (oard_pack_weights' order) in
+ * place of the packed blob; asynchronous on `stream`; the workspace is the caller's and carries everything the call needs. */
+typedef struct oard_graph oard_graph;
+int oard_graph_create(const oard_config* cfg, const int64_t* combined_mask_host, const int64_t* n_frag_switch_host, int64_t n_nodes,
+                      const int64_t* edge_index_host, int64_t n_edges, oard_graph** out);
+void oard_graph_destroy(oard_graph* graph);
+int64_t oard_graph_num_nodes(const oard_graph* graph);
+int64_t oard_graph_num_edges(const oard_graph* graph);
+int64_t oard_graph_object_rows(const oard_graph* graph, int object);   /* rows of xh[object] */
+int oard_graph_is_complete(const oard_graph* graph);
+size_t oard_graph_workspace_bytes(const oard_config* cfg, const oard_graph* graph);
+int oard_graph_forward(const oard_config* cfg, const oard_graph* graph, const float* const* params_dev, size_t n_params,
+                       const float* const* xh_dev, const float* t_dev, int t_is_scalar, const float* conditions_dev,
+                       float* const* out_dev, void* workspace_dev, size_t workspace_bytes, int32_t* status_dev, oard_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,9 @@ EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_by
            "oard_equi_backward_dx", "oard_scalarize_backward", "oard_equi_msg_backward", "oard_lin3u_forward", "oard_lin3u_backward", "oard_wgrad_scratch_bytes", "oard_wgrad",
            "oard_train_scratch_bytes", "oard_train_scratch_poison", "oard_train_scratch_entry", "oard_train_tail_backward",
            "oard_train_layer_backward", "oard_train_init_backward", "oard_train_stage_backward",
-           "oard_loss_prepare", "oard_loss_terms", "oard_adamw_step", "oard_adamw_step_dev", "oard_nan_replace"]
+           "oard_loss_prepare", "oard_loss_terms", "oard_adamw_step", "oard_adamw_step_dev", "oard_nan_replace",
+           "oard_graph_create", "oard_graph_destroy", "oard_graph_num_nodes", "oard_graph_num_edges", "oard_graph_object_rows",
+           "oard_graph_is_complete", "oard_graph_workspace_bytes", "oard_graph_forward"]
 STAGE_RECOMPUTE, STAGE_UPDATE, STAGE_MESSAGE, STAGE_GCL_NODE, STAGE_NODE_PRE, STAGE_GCL_EDGE, STAGE_EQUI_EDGE = range(7)
 SCRATCH_XH, SCRATCH_XQ, SCRATCH_CR, SCRATCH_DCD, SCRATCH_DCR = range(1, 6)
 
@@ -132,6 +134,15 @@ def lib() -> C.CDLL:
     cd = C.c_double
     L.oard_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, cd, cd, cd, cd, cd, i64, ci, cd, vp]; L.oard_adamw_step.restype = ci
     L.oard_adamw_step_dev.argtypes = [vp, vp, vp, vp, vp, i64, cd, cd, cd, cd, cd, ci, ci, vp, ci, vp, vp, vp, vp]; L.oard_adamw_step_dev.restype = ci
+    # general edge lists (csrc/oard_general.hip)
+    L.oard_graph_create.argtypes = [cfgp, vp, vp, i64, vp, i64, pvp]; L.oard_graph_create.restype = ci
+    L.oard_graph_destroy.argtypes = [vp]; L.oard_graph_destroy.restype = None
+    L.oard_graph_num_nodes.argtypes = [vp]; L.oard_graph_num_nodes.restype = i64
+    L.oard_graph_num_edges.argtypes = [vp]; L.oard_graph_num_edges.restype = i64
+    L.oard_graph_object_rows.argtypes = [vp, ci]; L.oard_graph_object_rows.restype = i64
+    L.oard_graph_is_complete.argtypes = [vp]; L.oard_graph_is_complete.restype = ci
+    L.oard_graph_workspace_bytes.argtypes = [cfgp, vp]; L.oard_graph_workspace_bytes.restype = sz
+    L.oard_graph_forward.argtypes = [cfgp, vp, pvp, sz, pvp, vp, ci, vp, pvp, vp, sz, vp, vp]; L.oard_graph_forward.restype = ci
     L.oard_debug_stop_after.argtypes = [C.c_int]; L.oard_debug_stop_after.restype = C.c_int
     L.oard_debug_option.argtypes = [C.c_char_p, C.c_int]; L.oard_debug_option.restype = C.c_int
     L.oard_timing_enable.argtypes = [C.c_int]; L.oard_timing_enable.restype = C.c_int

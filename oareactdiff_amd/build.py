@@ -7,19 +7,38 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.environ.get("OARD_LIB") or os.path.join(CSRC, "liboard_hip.so")
-SOURCES = ["oard_hip.hip"]
+# translation units -> the headers each one includes (None = every header of csrc/ except the ones another unit owns).  Units are compiled
+# to objects side by side and linked; an edit recompiles only the units that include the edited file.
+SOURCES = {"oard_hip.hip": None, "oard_general.hip": ["oard_general.h"]}
+_OWNED = {h for deps in SOURCES.values() if deps for h in deps}
+_PUBLIC = os.path.join("..", "..", "include", "oard.h")
 
 
-def _headers():
-    """Every header the translation unit can include: a stale library must never survive an edit."""
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "oard.h")]
+def _deps(src):
+    """Every file whose edit makes `src`'s object stale: a stale library must never survive an edit."""
+    own = SOURCES[src]
+    hdrs = sorted(f for f in os.listdir(CSRC) if f.endswith(".h") and f not in _OWNED) if own is None else list(own)
+    return [src] + hdrs + [_PUBLIC]
+
+
+def _objdir():
+    """Objects are kept per output library: an OARD_LIB build with other widths / flags must not share objects with the default one."""
+    return os.path.join(os.path.dirname(os.path.abspath(LIB)), "build", os.path.basename(LIB))
+
+
+def _obj(src):
+    return os.path.join(_objdir(), os.path.splitext(src)[0] + ".o")
+
+
+def _newer(paths, than):
+    if not os.path.exists(than):
+        return True
+    t = os.path.getmtime(than)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in paths)
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + _headers())
+    return any(_newer(_deps(src), LIB) for src in SOURCES)
 
 
 DEFAULT_DIMS = "196x96,32x8,32x32"
@@ -65,8 +84,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-result", dims_define(dims)] + SOURCES + ["-o", LIB]
+    os.makedirs(_objdir(), exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", dims_define(dims)]
+    extra = os.environ.get("OARD_CXXFLAGS", "").split()          # experiment / ablation builds (-DOARD_EXPERIMENTS ...): always with OARD_LIB
+    tag = os.path.join(_objdir(), "flags.txt")
+    flag_line = " ".join(flags + extra)
+    try:
+        same_flags = open(tag).read() == flag_line
+    except OSError:
+        same_flags = False
+    todo = [src for src in SOURCES if force or not same_flags or _newer(_deps(src), _obj(src))]
+
+    def compile_one(src):
+        cmd = [hipcc] + flags + extra + ["-c", src, "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, cwd=CSRC, check=True)
+    if todo:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(todo)) as pool:
+            list(pool.map(compile_one, todo))
+        with open(tag, "w") as f:
+            f.write(flag_line)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(src) for src in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, cwd=CSRC, check=True)

@@ -11,6 +11,7 @@
 // (the product), tests/general_host/harness.cpp runs the same functors and the same orchestration in host loops (a CPU test of the
 // formulas against the oracle - test infrastructure, never a fallback: the product entry points exist in the HIP library only).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>

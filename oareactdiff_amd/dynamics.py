@@ -162,6 +162,9 @@ class EGNNDynamics(nn.Module):
         self._train_topo_cache: "OrderedDict[tuple, object]" = OrderedDict()
         self._ws: Optional[Tensor] = None
         self._last_topo: Optional["_Topology"] = None
+        #: "auto": the complete graph per sample runs the production kernels, any other edge list the general path (csrc/oard_general.h);
+        #: "general": every inference call runs the general path (tests: two independent implementations of the same network)
+        self.edge_list_path = "auto"
 
     # ------------------------------------------------------------------------------------------
     def _config(self) -> _capi.OardConfig:
@@ -288,14 +291,15 @@ class EGNNDynamics(nn.Module):
 
     def _get_topology(self, cfg, edge_index: Tensor, n_frag_switch: Tensor, combined_mask: Tensor,
                       stream: int) -> "_Topology":
+        force_general = self.edge_list_path == "general"
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
                n_frag_switch.data_ptr(), n_frag_switch._version, combined_mask.data_ptr(), combined_mask._version,
-               combined_mask.numel())
+               combined_mask.numel(), force_general)
         topo = self._topo_cache.get(key)
         if topo is not None:
             self._topo_cache.move_to_end(key)
             return topo
-        topo = _Topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+        topo = _Topology(cfg, edge_index, n_frag_switch, combined_mask, stream, force_general=force_general)
         # the key is made of addresses and versions: the entry keeps the three tensors alive so that the caching
         # allocator cannot hand their storage to a different layout of the same size while the entry exists
         topo.key_tensors = (edge_index, n_frag_switch, combined_mask)
@@ -349,16 +353,30 @@ class EGNNDynamics(nn.Module):
                 cond = conditions.detach().to(device=dev, dtype=torch.float32).contiguous()
                 if cond.shape[0] <= topo.max_sample_id or cond.shape[1] != self.condition_nf:
                     raise _capi.OardError("conditions has the wrong shape")
-            need = L.oard_workspace_bytes(C.byref(cfg), topo.handle)
+            general = topo.graph is not None
+            need = L.oard_graph_workspace_bytes(C.byref(cfg), topo.graph) if general else L.oard_workspace_bytes(C.byref(cfg), topo.handle)
             if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
             status = torch.zeros(2, dtype=torch.int32, device=dev)
             xp = (C.c_void_p * n_obj)(*[x.data_ptr() for x in xs])
             op = (C.c_void_p * n_obj)(*[o.data_ptr() for o in outs])
-            rc = L.oard_forward(C.byref(cfg), topo.handle, packed.data_ptr(), xp, tt.data_ptr(), t_scalar,
-                                cond.data_ptr() if cond is not None else None, op, self._ws.data_ptr(),
-                                self._ws.numel(), status.data_ptr(), stream)
-            _capi.check(rc, "oard_forward")
+            if general:
+                if self.nan_check == "replace":
+                    raise _capi.OardError("nan_check='replace' is implemented for the complete-graph topology only")
+                tensors = self._ordered_tensors()                 # the general path reads the raw parameters (no packed blob)
+                for tns in tensors:
+                    if tns is not None and (tns.dtype != torch.float32 or not tns.is_contiguous() or tns.device != dev):
+                        raise _capi.OardError("the general-edge-list path needs contiguous float32 parameters on the call's device")
+                pp = (C.c_void_p * len(tensors))(*[tns.data_ptr() if tns is not None else None for tns in tensors])
+                rc = L.oard_graph_forward(C.byref(cfg), topo.graph, pp, len(tensors), xp, tt.data_ptr(), t_scalar,
+                                          cond.data_ptr() if cond is not None else None, op, self._ws.data_ptr(), self._ws.numel(),
+                                          status.data_ptr(), stream)
+                _capi.check(rc, "oard_graph_forward")
+            else:
+                rc = L.oard_forward(C.byref(cfg), topo.handle, packed.data_ptr(), xp, tt.data_ptr(), t_scalar,
+                                    cond.data_ptr() if cond is not None else None, op, self._ws.data_ptr(),
+                                    self._ws.numel(), status.data_ptr(), stream)
+                _capi.check(rc, "oard_forward")
             self._last_topo = topo
             self.last_status = status
             if self.nan_check != "sync":
@@ -506,6 +524,8 @@ class EGNNDynamics(nn.Module):
         """Intermediate tensor of the last forward (reference node/edge order); tests only."""
         topo = self._last_topo
         assert topo is not None and self._ws is not None
+        if topo.handle is None:
+            raise _capi.OardError("stage taps exist on the complete-graph path only (the last call ran the general-edge-list path)")
         H, R, L_, Cc = self._dims
         cfg = self._config()
         shape = {
@@ -526,6 +546,8 @@ class EGNNDynamics(nn.Module):
         exactly-zero message, model/leftnet.py:748-753, and are skipped); -1 if that call built no list.  Synchronises: a measurement aid."""
         topo = self._last_topo
         assert topo is not None and self._ws is not None
+        if topo.handle is None:
+            return -1                                            # general-edge-list path: no active list
         cfg = self._config()
         out = C.c_int64(0)
         with torch.cuda.device(self._ws.device):
@@ -553,7 +575,7 @@ class EGNNDynamics(nn.Module):
 class _Topology:
     """Device index tables for one (combined_mask, n_frag_switch, edge_index) triple."""
 
-    def __init__(self, cfg, edge_index: Tensor, n_frag_switch: Tensor, combined_mask: Tensor, stream: int):
+    def __init__(self, cfg, edge_index: Tensor, n_frag_switch: Tensor, combined_mask: Tensor, stream: int, force_general: bool = False):
         L = _capi.lib()
         cm = combined_mask.detach().to("cpu", torch.int64).contiguous()          # one-off host copy
         nfs = n_frag_switch.detach().to("cpu", torch.int64).contiguous()
@@ -585,16 +607,26 @@ class _Topology:
         ok = torch.zeros(1, dtype=torch.int32, device=dev)
         _capi.check(L.oard_topology_check_edge_index(h, ei.data_ptr(), ei.shape[1], ok.data_ptr(), stream),
                     "oard_topology_check_edge_index")
-        if int(ok.item()) != 1:
+        self.graph = None
+        if int(ok.item()) != 1 or force_general:
+            # not the complete graph per sample (edge_cutoff graphs, disconnected components, arbitrary lists: egnn_dynamics.py:63-72
+            # accepts them all): the general-edge-list path (csrc/oard_general.h) takes the call.  One host copy of the edge list per
+            # topology, like the two masks above.
             L.oard_topology_destroy(h)
             self.handle = None
-            raise _capi.OardError(
-                "edge_index is not (a permutation of) get_edges_index(combined_mask, remove_self_edge=True): the MI355X backend "
-                "implements the complete-graph-per-sample topology the diffusion sampler/trainer uses")
+            ei_host = ei.to("cpu").contiguous()
+            g = C.c_void_p()
+            rc = L.oard_graph_create(C.byref(cfg), cm.data_ptr(), nfs.data_ptr(), cm.numel(), ei_host.data_ptr(), ei_host.shape[1], C.byref(g))
+            _capi.check(rc, "oard_graph_create (node ids out of range, or n_frag_switch not object-major)")
+            self.graph = g
+            self.n_edges = int(L.oard_graph_num_edges(g))
+            self.n_inner = int((nfs[ei_host[0]] == nfs[ei_host[1]]).sum())
 
     def __del__(self):
         try:
             if getattr(self, "handle", None):
                 self._lib.oard_topology_destroy(self.handle)
+            if getattr(self, "graph", None):
+                self._lib.oard_graph_destroy(self.graph)
         except Exception:
             pass

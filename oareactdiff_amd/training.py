@@ -96,7 +96,9 @@ class TrainTopology:
             _capi.check(L.oard_topology_check_edge_index(h, ei.data_ptr(), ei.shape[1], ok.data_ptr(), stream),
                         "oard_topology_check_edge_index")
             if int(ok.item()) != 1:
-                raise _capi.OardError("edge_index is not get_edges_index(combined_mask, remove_self_edge=True)")
+                raise _capi.OardError("edge_index is not get_edges_index(combined_mask, remove_self_edge=True): the training path (tape, "
+                                      "hand-written backward) is built on the complete graph per sample; general edge lists are served "
+                                      "in inference only (csrc/oard_general.h)")
 
     def __del__(self):
         try:

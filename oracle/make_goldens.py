@@ -83,6 +83,21 @@ def make_inputs(case: dict):
         t = torch.tensor([0.314])
     else:
         t = torch.from_numpy(hash_uniform(case["name"] + ".t", B, 1234).reshape(B, 1)).float()
+    # general edge lists (round 6): what EGNNDynamics.forward accepts besides the complete graph (egnn_dynamics.py:63-72)
+    mode = case.get("edges")
+    if mode == "edge_cutoff":                                  # the reference's own builder, utils/_graph_tools.py:31-33
+        pos_all = torch.cat([x[:, :3] for x in xh], dim=0)
+        edge_index = get_edges_index(combined_mask, pos=pos_all, edge_cutoff=case["edge_cutoff"], remove_self_edge=True)
+    elif mode == "random_subset":                              # an arbitrary DIRECTED subset: pins which end every aggregation uses
+        keep = torch.from_numpy(hash_uniform(case["name"] + ".keep", edge_index.size(1), 99) < case["keep"])
+        edge_index = edge_index[:, keep]
+        perm = torch.from_numpy(np.argsort(hash_uniform(case["name"] + ".order", edge_index.size(1), 98)))
+        edge_index = edge_index[:, perm]                       # ... in an arbitrary order
+    elif mode == "components":                                 # two components per sample: nodes with even / odd row index never meet
+        a, b = edge_index
+        edge_index = edge_index[:, (a % 2) == (b % 2)]
+    else:
+        assert mode is None
     return xh, edge_index, t, conditions, n_frag_switch, combined_mask
 
 
@@ -123,13 +138,15 @@ def run_case(case: dict) -> None:
     o_lit = oracle.dynamics_forward(sd64, cfg, xh64, edge_index, t.double(), conditions.double(),
                                     n_frag_switch, combined_mask, cnf, nodeframe="literal",
                                     stages=st_lit, direct_vel=False)
+    # (the exact-arithmetic node frame is a property of the COMPLETE graph per sample: the general-edge-list cases keep the literal frame)
+    nf_hip = "literal" if case.get("edges") else "exact"
     o_ex = oracle.dynamics_forward(sd64, cfg, xh64, edge_index, t.double(), conditions.double(),
-                                   n_frag_switch, combined_mask, cnf, nodeframe="exact", stages=st_ex)
+                                   n_frag_switch, combined_mask, cnf, nodeframe=nf_hip, stages=st_ex)
     torch.set_default_dtype(torch.float32)
     # oracle, float32 network on float64 geometry, exact node frame: the arithmetic model of
     # the HIP path, in plain torch
     o_ex32 = oracle.dynamics_forward(sd32, cfg, xh, edge_index, t, conditions, n_frag_switch,
-                                     combined_mask, cnf, nodeframe="exact", geom64=True)
+                                     combined_mask, cnf, nodeframe=nf_hip, geom64=True)
 
     nz = [k for k in range(len(xh)) if xh[k].size(0)]
     pd = 3
@@ -211,6 +228,18 @@ CASES = [
          condition_nf=1, fragments_nodes=[[5, 7, 3]] * 3, t_1d=False, pos_scale=3.0, onehot=True),
     dict(name="g10p_noreflect_prod", model_config=dict(PROD, num_layers=2, reflect_equiv=False), node_nfs=[9, 9, 9],
          condition_nf=1, fragments_nodes=[[9, 6]] * 3, t_1d=False, onehot=True),
+    # G11: general edge lists - the only other thing EGNNDynamics.forward accepts (egnn_dynamics.py:63-72).  edge_cutoff graphs from the
+    # reference's own builder (test dims with ragged samples; production dims), an arbitrary directed subset in arbitrary order (28 % of the
+    # ordered pairs missing: in- and out-degrees differ, some nodes have no incoming edge), and two disconnected components per sample
+    # (tests/model/test_equiv.py:177-230).  Run by the general path (csrc/oard_general.h), literal node frame.
+    dict(name="g11_edge_cutoff_h32", model_config=dict(TEST_CFG, num_layers=3), node_nfs=[9, 9, 9], condition_nf=1,
+         fragments_nodes=[[5, 7, 3]] * 3, t_1d=False, pos_scale=2.0, onehot=True, edges="edge_cutoff", edge_cutoff=3.5),
+    dict(name="g11p_edge_cutoff_prod", model_config=dict(PROD, num_layers=2), node_nfs=[9, 9, 9], condition_nf=1,
+         fragments_nodes=[[9, 6]] * 3, t_1d=False, pos_scale=2.0, onehot=True, edges="edge_cutoff", edge_cutoff=4.0),
+    dict(name="g11_random_subset", model_config=dict(TEST_CFG, num_layers=2), node_nfs=[4, 5, 6], condition_nf=3,
+         fragments_nodes=[[2, 3], [2, 3], [1, 2]], t_1d=True, edges="random_subset", keep=0.72),
+    dict(name="g11_components_noreflect", model_config=dict(TEST_CFG, num_layers=2, reflect_equiv=False), node_nfs=[9, 9, 9],
+         condition_nf=1, fragments_nodes=[[6, 4]] * 3, t_1d=False, onehot=True, edges="components"),
 ]
 
 if __name__ == "__main__":

@@ -62,9 +62,14 @@ def test_library_built_with_other_widths_is_stale(tmp_path, monkeypatch):
     lib = os.path.join(tmp_path, "liboard_x.so")
     calls = []
 
-    def fake_run(cmd, **kw):
-        calls.append(cmd)
-        open(lib, "w").close()
+    def fake_run(cmd, **kw):                                 # a build = one compile per translation unit, then ONE link: count the links
+        if "-shared" in cmd:
+            calls.append(cmd)
+            open(lib, "w").close()
+        else:
+            compiles.append(cmd)
+            open(cmd[cmd.index("-o") + 1], "w").close()
+    compiles = []
     monkeypatch.setattr(B, "LIB", lib)
     monkeypatch.setattr(B.subprocess, "run", fake_run)
     monkeypatch.setenv("OARD_DIMS", "64x16")
@@ -74,7 +79,8 @@ def test_library_built_with_other_widths_is_stale(tmp_path, monkeypatch):
     assert len(calls) == 1                                   # same widths, library newer than the sources: kept
     monkeypatch.delenv("OARD_DIMS")
     B.build()
-    assert len(calls) == 2 and B._built_dims() == B.DEFAULT_DIMS and any("X(196,96)" in a for a in calls[1])
+    assert len(calls) == 2 and B._built_dims() == B.DEFAULT_DIMS and any("X(196,96)" in a for a in compiles[-1])
+    assert len(compiles) == 2 * len(B.SOURCES)               # other widths = other flags: every unit recompiled
     os.remove(lib + ".dims")
     B.build()
     assert len(calls) == 3                                   # unknown widths: rebuilt

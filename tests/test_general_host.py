@@ -1,0 +1,69 @@
+"""The general-edge-list path's formulas on the CPU (csrc/oard_general.h).  The stage functors and the orchestration of that path are
+written once for two executors; here tests/general_host/harness.cpp runs them in host loops (compiled with g++ by this test) against the
+REFERENCE's float64 outputs (tests/golden/*.npz, oracle/make_goldens.py): the eight complete-graph fixtures - where the literal node
+frame this path evaluates agrees with the exact-arithmetic one - and the four general graphs of round 6 (edge_cutoff graphs from the
+reference's own builder, an arbitrary directed subset in arbitrary order, disconnected components with reflect_equiv=False).
+On the GPU the same functors run as HIP kernels (tests/test_general_edges.py, -m gpu).  Nothing in the product path loads this harness."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+import torch
+
+from _cases import ALL_CASES, Case, rel
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GENERAL_CASES = ["g11_edge_cutoff_h32", "g11p_edge_cutoff_prod", "g11_random_subset", "g11_components_noreflect"]
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("general_host") / "libgeneral_host.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "general_host", "harness.cpp")], check=True)
+    return C.CDLL(so)
+
+
+def run_host(harness, c: Case, edge_index=None):
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=[f"o{k}" for k in range(c.n_obj)], node_nfs=c.node_nfs, edge_nf=0,
+                       condition_nf=c.cnf, device=torch.device("cpu"))
+    dyn.load_state_dict(c.state_dict(), strict=True)
+    cfg = dyn._config()
+    tensors = [t.detach().float().contiguous() if t is not None else None for t in dyn._ordered_tensors()]
+    vp = C.c_void_p
+    params = (vp * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+    xh = [x.float().contiguous() for x in c.xh]
+    out = [torch.full_like(x, float("nan")) for x in xh]
+    ei = (c.edge_index if edge_index is None else edge_index).long().contiguous()
+    cm, nfs = c.combined_mask.long().contiguous(), c.n_frag_switch.long().contiguous()
+    t, cond = c.t.float().contiguous(), c.conditions.float().contiguous()
+    status = torch.zeros(1, dtype=torch.int32)
+    arr = lambda ts: (vp * len(ts))(*[x.data_ptr() for x in ts])                # noqa: E731
+    rc = harness.oard_general_forward_host(C.byref(cfg), vp(cm.data_ptr()), vp(nfs.data_ptr()), C.c_int64(cm.numel()), vp(ei.data_ptr()),
+                                           C.c_int64(ei.shape[1]), params, C.c_size_t(len(tensors)), arr(xh), vp(t.data_ptr()),
+                                           1 if t.dim() == 1 else 0, vp(cond.data_ptr()), arr(out), vp(status.data_ptr()))
+    assert rc == 0, rc
+    assert int(status[0]) == 0
+    return out
+
+
+@pytest.mark.parametrize("name", ALL_CASES + GENERAL_CASES)
+def test_general_path_formulas_match_the_reference_f64(harness, name):
+    c = Case(name)
+    out = run_host(harness, c)
+    v, h = c.split(out)
+    rv, rh = c.split(c.ref64)
+    print(f"{name}: N {c.combined_mask.numel()} E {c.edge_index.shape[1]}  vel {rel(v, rv):.2e}  h {rel(h, rh):.2e}")
+    assert all(bool(torch.isfinite(o).all()) for o in out)
+    assert rel(v, rv) <= 1e-5 and rel(h, rh) <= 1e-5
+
+
+def test_general_path_is_invariant_under_edge_order(harness):
+    """Per-node outputs; every aggregation runs in edge order, so a permutation moves the float64 sums' last bits only."""
+    c = Case("g11_edge_cutoff_h32")
+    g = torch.Generator().manual_seed(3)
+    perm = torch.randperm(c.edge_index.shape[1], generator=g)
+    a, b = run_host(harness, c), run_host(harness, c, c.edge_index[:, perm])
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max())

@@ -96,23 +96,30 @@ def test_stages_match_oracle(name):
     assert rel(dyn.debug_tap(_capi.TAP_HOUT).cpu(), st["h_out"]) <= TOL
 
 
-def test_rejects_non_complete_topology():
-    from oareactdiff_amd._capi import OardError
+def test_non_complete_topology_runs_the_general_path():
+    """Rounds 1-5 refused every edge list but the complete graph per sample; since round 6 such a call runs the general-edge-list path
+    (csrc/oard_general.h; tests/test_general_edges.py) and matches the float64 oracle with the reference's literal node frame."""
     dev = torch.device("cuda:0")
     c = Case("g1_wrapper_small")
     dyn = _dyn(c, dev)
     a = list(_args(c, dev))
     a[1] = a[1][:, :-2]                    # drop two edges
-    with pytest.raises(OardError):
-        with torch.no_grad():
-            dyn(*a)
+    with torch.no_grad():
+        out, _ = dyn(*a)
+    assert dyn._last_topo.graph is not None
+    ref = oracle.dynamics_forward(c.state_dict(torch.float64), c.cfg, [x.double() for x in c.xh], c.edge_index[:, :-2], c.t.double(),
+                                  c.conditions.double(), c.n_frag_switch, c.combined_mask, c.cnf, nodeframe="literal")
+    v, h = c.split([o.cpu() for o in out])
+    rv, rh = c.split(ref)
+    assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
 
 
 @pytest.mark.parametrize("name", ["g1_wrapper_small", "g3_cutoff_ragged"])
 def test_any_ordering_of_the_complete_edge_set_is_accepted(name):
     """`EGNNDynamics.forward` takes any `edge_index` (egnn_dynamics.py:63-72); outputs are per node, so a PERMUTATION of the edge
     list `get_edges_index` builds (utils/_graph_tools.py:30-36) is the same computation: bit-identical outputs.  A duplicated, a
-    missing, a self or a cross-sample edge is still refused."""
+    missing, a self or a cross-sample edge is a DIFFERENT graph: it runs the general path (round 6) and matches the float64 oracle on
+    that edge list, as the reference would; a node id out of range is refused."""
     from oareactdiff_amd._capi import OardError
     dev = torch.device("cuda:0")
     c = Case(name)
@@ -137,13 +144,23 @@ def test_any_ordering_of_the_complete_edge_set_is_accepted(name):
     other = int((cm != cm[int(a[1][0, 0])]).nonzero()[0]) if len(torch.unique(cm)) > 1 else None
     if other is not None:
         crs = a[1].clone(); crs[1, 0] = other; bad.append(crs)                      # an edge between two samples
-    oob = a[1].clone(); oob[1, 0] = cm.numel(); bad.append(oob)                     # node id out of range
     for ei in bad:
         b = list(a)
         b[1] = ei
-        with pytest.raises(OardError):
-            with torch.no_grad():
-                dyn(*b)
+        with torch.no_grad():
+            got, _ = dyn(*b)
+        assert dyn._last_topo.graph is not None
+        ref = oracle.dynamics_forward(c.state_dict(torch.float64), c.cfg, [x.double() for x in c.xh], ei.cpu(), c.t.double(),
+                                      c.conditions.double(), c.n_frag_switch, c.combined_mask, c.cnf, nodeframe="literal")
+        v, h = c.split([o.cpu() for o in got])
+        rv, rh = c.split(ref)
+        assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
+    oob = a[1].clone(); oob[1, 0] = cm.numel()                                     # node id out of range
+    b = list(a)
+    b[1] = oob
+    with pytest.raises(OardError):
+        with torch.no_grad():
+            dyn(*b)
 
 
 def _random_case(sizes, pos_scale, seed, cfg):
