@@ -593,6 +593,9 @@ static int forward_impl(const oard_config* c, const TopoPart* topo, const float*
     int* al_cnt = (int*)(ws + w.al_cnt);
     const ActList al = use_al ? ActList{(const int*)(ws + w.al_rows), (const int*)(ws + w.al_src), (const int*)(ws + w.al_pre), (const int*)(ws + w.al_n)}
                               : ActList{nullptr, nullptr, nullptr, nullptr};
+    // a call that builds no list says so in the workspace: oard_active_inner_edges reports what the LAST call on it did, not what an
+    // earlier inference call left behind (0xff bytes = -1)
+    if (!use_al) HIP_TRY(hipMemsetAsync(ws + w.al_n, 0xff, sizeof(int), st));
     LAUNCH(F_OTHER, k_prep, cdiv(N, 128), 128, st, tp, op, wb, pos, hin, t, t_scalar, cond,
            c->condition_nf > 0 ? c->condition_nf : 0, c->condition_time, emb);
     LAUNCH(F_INIT, k_geom, tp.n_groups, 64, st, tp, (const float*)pos, cutoff, pf64, pf32, x1, pp0, labels);
@@ -1457,8 +1460,7 @@ int oard_active_inner_edges(const oard_config* c, const oard_topology* topo, con
                             oard_stream_t stream) {
     if (!config_ok(c) || !topo || !ws || !n_active) return OARD_EINVAL;
     if (ws_bytes < ws_total(c, topo)) return OARD_ENOMEM;
-    if (!g_equi_skip || g_equi_variant == 0 || g_node_variant != 1) { *n_active = -1; return OARD_OK; }
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = (hipStream_t)stream;       // (decided by what the last call WROTE, not by the current debug options)
     long long total = 0;
     for (int p = 0; p < topo->n_parts; ++p) {
         if (topo->parts[p].d.A <= 0) continue;
@@ -1886,11 +1888,22 @@ static int wgq_flush() {
     int slot = 0;
     {
         std::lock_guard<std::mutex> lk(rg.mu);
-        if (!rg.host) {
-            const size_t bytes = (size_t)WGQ_SLOTS * WGQ_MAX_JOBS * sizeof(WgqJob);
-            HIP_TRY(hipHostMalloc((void**)&rg.host, bytes, hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void**)&rg.dev, bytes));
-            for (int i = 0; i < WGQ_SLOTS; ++i) HIP_TRY(hipEventCreateWithFlags(&rg.ev[i], hipEventDisableTiming));
+        if (!rg.host) {                          // allocate into locals, publish only when everything exists (a half-built ring would
+            const size_t bytes = (size_t)WGQ_SLOTS * WGQ_MAX_JOBS * sizeof(WgqJob);        // be taken for a complete one by the next flush)
+            WgqJob *h0 = nullptr, *d0 = nullptr;
+            hipEvent_t ev0[WGQ_SLOTS] = {};
+            int made = 0;
+            bool ok = hipHostMalloc((void**)&h0, bytes, hipHostMallocDefault) == hipSuccess && hipMalloc((void**)&d0, bytes) == hipSuccess;
+            for (; ok && made < WGQ_SLOTS; ++made) ok = hipEventCreateWithFlags(&ev0[made], hipEventDisableTiming) == hipSuccess;
+            if (!ok) {
+                for (int i = 0; i < made; ++i) if (ev0[i]) (void)hipEventDestroy(ev0[i]);
+                if (d0) (void)hipFree(d0);
+                if (h0) (void)hipHostFree(h0);
+                return OARD_EHIP;
+            }
+            for (int i = 0; i < WGQ_SLOTS; ++i) rg.ev[i] = ev0[i];
+            rg.dev = d0;
+            rg.host = h0;
         }
         slot = rg.next;
         rg.next = (rg.next + 1) % WGQ_SLOTS;

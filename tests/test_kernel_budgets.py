@@ -53,3 +53,31 @@ def test_production_kernels_stay_inside_their_register_budgets(tmp_path):
                     bad.append(f"{dem[:140]}: {scratch} bytes of scratch per lane (budget {limit}), {vgpr} VGPRs")
     assert not bad, "\n".join(bad)
     assert all(v > 0 for v in seen.values()), [k for k, v in seen.items() if v == 0]
+    # ---- wait states behind MFMA results, in the ISA of the same object (round 6, advisor finding) ---------------------------------------
+    # Some kernels issue their MFMAs as `asm volatile` (dense_seq_xyz of csrc/oard_node_v1.h, k_wgrad_t16): hipcc's hazard recogniser does
+    # not look inside asm statements, and one of those kernels (k_equi_node_v1) is allowed 36 bytes of scratch - a spill store of an
+    # accumulator right behind its last MFMA would read a result that is not there yet.  tools/mfma_hazard_check.py walks the disassembly
+    # of EVERY kernel: no instruction but an accumulating MFMA touches an MFMA's destination inside its window.
+    co = os.path.join(tmp_path, "res.co")
+    subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + os.path.join(tmp_path, "res.o"),
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(CSRC), "..", "tools"))
+    import mfma_hazard_check as hz
+    viol, n_mfma, n_fn = hz.check(co)
+    assert n_mfma > 10000 and n_fn > 100, (n_mfma, n_fn)        # the scan saw the library
+    assert not viol, "\n".join(viol[:20])
+
+
+def test_the_hazard_scan_flags_what_it_should():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(CSRC), "..", "tools"))
+    import mfma_hazard_check as hz
+    mf = "v_mfma_f32_16x16x4_f32 v[0:3], v4, v5, v[0:3]"
+    assert hz.scan([mf, "v_mfma_f32_16x16x4_f32 v[0:3], v6, v7, v[0:3]", "s_nop 7", "s_nop 1", "v_add_f32 v8, v0, v1"])[0] == []      # chain, 10 states
+    assert hz.scan([mf, "s_nop 7", "s_nop 0", "v_add_f32 v8, v0, v1"])[0]                       # VALU read after 9 states
+    assert hz.scan([mf, "scratch_store_dwordx4 off, v[0:3], s0 offset:16"])[0]                   # a spill store right behind the MFMA
+    assert hz.scan([mf, "v_mov_b32 v2, 0"])[0]                                                   # a write into the destination
+    assert hz.scan([mf, "v_mfma_f32_16x16x4_f32 v[8:11], v0, v5, v[8:11]"])[0]                   # the result as SrcA of the next MFMA
+    assert hz.scan([mf, "v_mfma_f32_16x16x4_f32 v[8:11], v6, v5, v[0:3]"])[0] == []              # ... taken whole as SrcC: the chain
+    assert hz.scan(["v_mfma_f32_4x4x1_16b_f32 v[0:3], v4, v5, v[0:3]", "s_nop 3", "v_add_f32 v8, v0, v1"])[0] == []      # 2 passes: 4 states
