@@ -9,8 +9,18 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.environ.get("OARD_LIB") or os.path.join(CSRC, "liboard_hip.so")
 # translation units -> the headers each one includes (None = every header of csrc/ except the ones another unit owns).  Units are compiled
 # to objects side by side and linked; an edit recompiles only the units that include the edited file.
-SOURCES = {"oard_hip.hip": None, "oard_general.hip": ["oard_general.h"]}
-_OWNED = {h for deps in SOURCES.values() if deps for h in deps}
+_EDGE = ["oard_engine.h", "oard_layout.h", "oard_kernels.h", "oard_edge_v1.h", "oard_inst.h"]
+SOURCES = {
+    "oard_hip.hip": None,                                                        # host code + every kernel not listed below
+    "oard_general.hip": ["oard_general.h"],                                       # general-edge-list path
+    # explicit instantiations of the heavy kernel families (csrc/oard_inst.h)
+    "oard_inst_gcl_p.hip": _EDGE + ["oard_edge_p.h"],
+    "oard_inst_gcl_v1.hip": _EDGE + ["oard_node_v1.h", "oard_edge_small.h"],
+    "oard_inst_b3.hip": _EDGE + ["oard_edge_b3.h"],
+    "oard_inst_equi.hip": _EDGE + ["oard_node_v1.h", "oard_edge_bwd.h"],
+    "oard_inst_wgrad.hip": _EDGE + ["oard_edge_bwd.h", "oard_wgrad_t16.h"],
+}
+_OWNED = {"oard_general.h"}                     # headers no other unit includes
 _PUBLIC = os.path.join("..", "..", "include", "oard.h")
 
 

@@ -458,7 +458,7 @@ struct B3Job {
     size_t tstride, kstride;
 };
 struct B3Jobs { B3Job j[4]; };
-__global__ __launch_bounds__(256) void k_pack_b3(B3Jobs jobs, float* __restrict__ blob) {
+OARD_KERNEL __global__ __launch_bounds__(256) void k_pack_b3(B3Jobs jobs, float* __restrict__ blob) {
     const B3Job j = jobs.j[blockIdx.y];
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)j.MT * j.NB * 64) return;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void k_pack_b3(B3Jobs jobs, float* __restrict_
     *reinterpret_cast<bf8*>(d + 512) = l;
 }
 // fp32 bias chunks: copies of the fp32 stream's (same C-layout chunk)
-__global__ __launch_bounds__(256) void k_copy_chunks(float* __restrict__ blob, size_t src, size_t sstride, size_t dst, size_t dstride, int n) {
+OARD_KERNEL __global__ __launch_bounds__(256) void k_copy_chunks(float* __restrict__ blob, size_t src, size_t sstride, size_t dst, size_t dstride, int n) {
     const int c = blockIdx.x;
     if (c < n) blob[dst + (size_t)c * dstride + threadIdx.x] = blob[src + (size_t)c * sstride + threadIdx.x];
 }

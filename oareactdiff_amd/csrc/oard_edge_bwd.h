@@ -106,7 +106,7 @@ struct GclBwdArgs {
 OARD_DEV void gb_barrier() {
     if (OARD_GB_ABL == 1) __syncthreads(); else phase_barrier();
 }
-__device__ int g_gb_never = 0;            // always 0: "stores" of the no-store ablations stay in the code (nothing is dead) but never execute
+OARD_DEVVAR __device__ int g_gb_never = 0;            // always 0: "stores" of the no-store ablations stay in the code (nothing is dead) but never execute
 OARD_DEV void gb_st(float* p, f4 v) { if ((OARD_GB_ABL != 2 && OARD_GB_ABL != 4) || g_gb_never) st_f4(p, v); }
 OARD_DEV f4 gb_ld(const float* p) { return (OARD_GB_ABL == 3 || OARD_GB_ABL == 4) ? (f4){0.25f, -0.5f, 0.125f, 1.0f} : ld_f4(p); }
 template <class D, int WAVES, int GP, bool HAS_S3>
@@ -389,7 +389,7 @@ OARD_DEV int xcd_run32(int b, int nblk) {
 // partial sums are added in wave order (fixed summation order).  Round 4: was one wave per node walking both lists
 // (index load -> row load, 2 (ns - 1) dependent round trips): 118 -> see profiles us per layer at B = 64.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_edge_node_sums(TopoDev tp, const float* __restrict__ dz1, int HP,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_edge_node_sums(TopoDev tp, const float* __restrict__ dz1, int HP,
                                                         float* __restrict__ dP, float* __restrict__ dQ) {
     __shared__ f4 part[3][2][64];
     const int n = OARD_XCD_RUNS ? xcd_run32(blockIdx.x, gridDim.x) : (int)blockIdx.x, lane = threadIdx.x & 63, f = lane * 4;
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_lds(const float* __restrict__ 
 // kernel above would run 128 x 256 tiles that are almost all padding and is latency-bound there.  Here a workgroup stages 64
 // rows of both operands in LDS and every thread owns up to four outputs (o, i); column i == MI is the bias (X = 1).
 // partial layout: [chunk][MO][MI + 1].
-__global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ dY, int ldY, int MO, const float* __restrict__ X, int ldX,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_wgrad_small(const float* __restrict__ dY, int ldY, int MO, const float* __restrict__ X, int ldX,
                                                      int MI, int x_silu, long long rows, long long rows_per_chunk,
                                                      float* __restrict__ partial) {
     __shared__ float sy[64 * 65], sx[64 * 65];
@@ -823,7 +823,7 @@ OARD_DEV float chunk_sum_wave(const float* __restrict__ p, size_t stride, int n_
 }
 // dW [MO][MI] and db [MO] from the small kernel's partials: one wave per output
 // ldW: row stride of the destination (a column slice of a wider nn.Linear weight); acc: add to the destination instead of overwriting
-__global__ __launch_bounds__(256) void k_wgrad_small_reduce(const float* __restrict__ partial, int n_chunks, int MO, int MI,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_wgrad_small_reduce(const float* __restrict__ partial, int n_chunks, int MO, int MI,
                                                             float* __restrict__ dW, int ldW, float* __restrict__ db, int acc) {
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), nout = MO * (MI + 1);
     if (idx >= nout) return;
@@ -862,7 +862,7 @@ OARD_DEV void wgrad_reduce_body(float (*red)[33], const float* __restrict__ part
         *dst = acc ? *dst + t : t;
     }
 }
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int PP, int QP, int transposed, int o_len, int o_pad,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int n_chunks, int PP, int QP, int transposed, int o_len, int o_pad,
                                int MO, int i_len, int i_pad, int MI, float* __restrict__ out, int ldW, int acc) {
     __shared__ float red[8][33];
     wgrad_reduce_body(red, partial, n_chunks, PP, QP, transposed, o_len, o_pad, MO, i_len, i_pad, MI, out, ldW, acc, blockIdx.x);
@@ -875,12 +875,12 @@ OARD_DEV void bgrad_reduce_body(const float* __restrict__ bpartial, int n_chunks
     const float s = chunk_sum_wave(bpartial + op, (size_t)stride, n_chunks, threadIdx.x & 63);
     if ((threadIdx.x & 63) == 0) out[o] = acc ? out[o] + s : s;
 }
-__global__ __launch_bounds__(256) void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int stride, int o_len, int o_pad,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_bgrad_reduce(const float* __restrict__ bpartial, int n_chunks, int stride, int o_len, int o_pad,
                                                       int MO, float* __restrict__ out, int acc) {
     bgrad_reduce_body(bpartial, n_chunks, stride, o_len, o_pad, MO, out, acc, blockIdx.x);
 }
 // the reduce passes of a job table in one launch: per job rblk_w blocks of the dW reduce, then rblk_b blocks of the bias reduce
-__global__ __launch_bounds__(256) void k_wgrad_reduce_q(const WgqJob* __restrict__ jobs, int n_jobs) {
+OARD_KERNEL __global__ __launch_bounds__(256) void k_wgrad_reduce_q(const WgqJob* __restrict__ jobs, int n_jobs) {
     __shared__ float red[8][33];
     const WgqJob& J = jobs[wgq_find(jobs, n_jobs, blockIdx.x, true)];
     const unsigned lb = blockIdx.x - J.rblk0;

@@ -18,7 +18,7 @@
 #pragma once
 #include "oard_edge_v1.h"
 
-__device__ unsigned int g_fp_timeouts;
+OARD_DEVVAR __device__ unsigned int g_fp_timeouts;
 #define FP_SPIN_MAX (1 << 16)
 #ifndef FP_GATE_EVERY
 #define FP_GATE_EVERY 4

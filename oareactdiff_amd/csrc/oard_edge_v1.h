@@ -47,7 +47,7 @@ OARD_DEV void phase_barrier() {
 // the phase barrier (own DMA pieces / loads / stores not landed), the barrier itself (waiting for the other waves), the issue of
 // one LDS-DMA piece.  Sums over all waves in g_phase_probe (oard_debug_probe_read).
 #ifdef OARD_PHASE_PROBE
-__device__ unsigned long long g_phase_probe[8];
+OARD_DEVVAR __device__ unsigned long long g_phase_probe[8];
 #define PROBE_DECL long long pr_t0_ = clock64(), pr_wait_ = 0, pr_bar_ = 0, pr_n_ = 0;
 #define PHASE_BARRIER() do { const long long a_ = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long b_ = clock64(); \
         __syncthreads(); const long long c_ = clock64(); pr_wait_ += b_ - a_; pr_bar_ += c_ - b_; ++pr_n_; } while (0)
@@ -65,7 +65,7 @@ __device__ unsigned long long g_phase_probe[8];
 // (tools/wave_timeline.py): code 1 = after the phase barrier, 2 = chain starts, 3 = chain done, 4 = phase work done
 #ifdef OARD_TIMELINE
 #define TL_MAX 1024
-__device__ long long g_timeline[16][TL_MAX];
+OARD_DEVVAR __device__ long long g_timeline[16][TL_MAX];
 #define TL_DECL const bool tl_on_ = DO_S1 && DO_S3 && blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0; int tl_n_ = 0;
 #define TL(code) do { if (tl_on_ && tl_n_ < TL_MAX) g_timeline[threadIdx.x >> 6][tl_n_++] = (clock64() << 3) | (code); } while (0)
 #define TL_END() do { if (tl_on_ && tl_n_ < TL_MAX) g_timeline[threadIdx.x >> 6][tl_n_] = 0; } while (0)

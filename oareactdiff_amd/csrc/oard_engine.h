@@ -23,6 +23,19 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define OARD_DEV __device__ __forceinline__
+// The library is several translation units (oareactdiff_amd/build.py): oard_hip.hip holds the host code and launches every kernel; the
+// heavy kernel families are explicitly instantiated in oard_inst_*.hip (declared `extern template` in oard_hip.hip, oard_inst.h), so that
+// an edit to one family recompiles one unit.  A kernel that is NOT a template, and every __device__ variable, must exist in one unit only:
+// in an instantiation unit such a kernel becomes a template that nothing instantiates (a `static` kernel would still be emitted), a
+// __device__ variable a static of that unit.  -DOARD_SINGLE_TU (probe / timeline builds that read __device__
+// variables back): everything in oard_hip.hip, as before round 6.
+#ifdef OARD_INST_TU
+#define OARD_KERNEL template <int OARD_NEVER_INSTANTIATED_>
+#define OARD_DEVVAR static __attribute__((unused))
+#else
+#define OARD_KERNEL
+#define OARD_DEVVAR
+#endif
 
 OARD_DEV f4 f4zero() { return (f4){0.f, 0.f, 0.f, 0.f}; }
 

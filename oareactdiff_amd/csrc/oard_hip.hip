@@ -23,6 +23,7 @@
 #include "oard_edge_small.h"
 #include "oard_edge_bwd.h"
 #include "oard_node_bwd.h"
+#include "oard_inst.h"        // the heavy kernel families are instantiated in their own translation units: `extern template` here
 
 #define OARD_VERSION 2030
 // The first-generation kernels (weights straight from L2, one wave per 16 nodes: gcl_variant / equi_variant / node_variant 0) are the

@@ -1,0 +1,8 @@
+// Explicit instantiations of one kernel family (oard_inst.h): its own translation unit, so that an edit to the family recompiles this unit only.
+#define OARD_INST_TU
+#define OARD_INST_DEFINE
+#define OARD_INST_UNIT_EQUI
+#include "oard_edge_v1.h"
+#include "oard_node_v1.h"
+#include "oard_edge_bwd.h"
+#include "oard_inst.h"

@@ -58,7 +58,7 @@ struct PackJob {
 };
 
 // matrix -> MFMA chunks: dst[((t*KB + b)*64 + lane)*4 + c] = W[row(16t + (lane&15))][col(16b + 4(lane>>4) + c)]
-__global__ void k_pack_matrix(PackJob j, float* __restrict__ blob) {
+OARD_KERNEL __global__ void k_pack_matrix(PackJob j, float* __restrict__ blob) {
     const size_t total = (size_t)j.MT * j.KB * 256;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i & 3), lane = (int)((i >> 2) & 63);
@@ -79,7 +79,7 @@ __global__ void k_pack_matrix(PackJob j, float* __restrict__ blob) {
 }
 // per-feature vector as "bias chunks" for the LDS weight stream: chunk of tile t holds, for lane (g, o),
 // the float4 vec[16t + 4g .. +3] (i.e. ld_vec's layout, replicated over o); same sectioning as k_pack_vector
-__global__ void k_pack_bias_chunks(const float* __restrict__ src, float* __restrict__ dst, int sect_len, int sect_pad,
+OARD_KERNEL __global__ void k_pack_bias_chunks(const float* __restrict__ src, float* __restrict__ dst, int sect_len, int sect_pad,
                                    int sects, int n_tiles, size_t tstride, int perm_ht) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tiles * 256) return;
@@ -90,14 +90,14 @@ __global__ void k_pack_bias_chunks(const float* __restrict__ src, float* __restr
     dst[(size_t)slot * tstride + (i & 255)] = (src != nullptr && s < sects && w < sect_len) ? src[s * sect_len + w] : 0.f;
 }
 // vector with the same row sectioning, padded with zeros; n_dst = msects * msect_pad (or MT*16)
-__global__ void k_pack_vector(const float* __restrict__ src, float* __restrict__ dst, int sect_len, int sect_pad,
+OARD_KERNEL __global__ void k_pack_vector(const float* __restrict__ src, float* __restrict__ dst, int sect_len, int sect_pad,
                               int sects, int n_dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_dst) return;
     const int s = i / sect_pad, w = i % sect_pad;
     dst[i] = (src != nullptr && s < sects && w < sect_len) ? src[s * sect_len + w] : 0.f;
 }
-__global__ void k_copy_raw(const float* __restrict__ src, float* __restrict__ dst, int n) {
+OARD_KERNEL __global__ void k_copy_raw(const float* __restrict__ src, float* __restrict__ dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
 }
@@ -116,7 +116,7 @@ struct GenJob {
     int perm_ht;
     long long block0;          // first block of this job
 };
-__global__ __launch_bounds__(256) void k_pack_all(const GenJob* __restrict__ jobs, int n_jobs, float* __restrict__ blob) {
+OARD_KERNEL __global__ __launch_bounds__(256) void k_pack_all(const GenJob* __restrict__ jobs, int n_jobs, float* __restrict__ blob) {
     int lo = 0, hi = n_jobs - 1;
     const long long b = blockIdx.x;
     while (lo < hi) {                                     // last job with block0 <= b
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_pack_all(const GenJob* __restrict__ job
 
 // constant state of a masked edge (leftnet.py:768-809 with dist = 0, radial_emb = 0, frame = 0):
 //   [ lin3(0) x 2H | radial_lin(0) | 0 x R | pad ]
-__global__ void k_c0row(const float* __restrict__ lin3w0b /*b0*/, const float* __restrict__ lin3w2,
+OARD_KERNEL __global__ void k_c0row(const float* __restrict__ lin3w0b /*b0*/, const float* __restrict__ lin3w2,
                         const float* __restrict__ lin3b2, const float* __restrict__ rl0b,
                         const float* __restrict__ rl2w, const float* __restrict__ rl2b, float* __restrict__ c0,
                         int H, int H4, int WP) {
@@ -183,7 +183,7 @@ __global__ void k_c0row(const float* __restrict__ lin3w0b /*b0*/, const float* _
 
 // u0 = W1c(layer 0) . c0row (+ nothing else): what stage S1 of the first GCL layer yields on every
 // inter-object edge, whose initial state is the constant row
-__global__ void k_u0(const float* __restrict__ w_edge_mlp0 /*[H][2H+W]*/, const float* __restrict__ c0,
+OARD_KERNEL __global__ void k_u0(const float* __restrict__ w_edge_mlp0 /*[H][2H+W]*/, const float* __restrict__ c0,
                      float* __restrict__ u0, int H, int W, int HP) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= HP) return;
@@ -200,7 +200,7 @@ __global__ void k_u0(const float* __restrict__ w_edge_mlp0 /*[H][2H+W]*/, const 
 // =====================================================================================================
 // edge_index ([2, n_edges] int64, reference node ids) is a permutation of the complete per-sample edge set: see
 // oard_topology_check_edge_index.  One thread per given edge; a repeated id finds its bit already set.
-__global__ void k_check_edge_set(const int* __restrict__ ref_sample, const int* __restrict__ ref_rank, const long long* __restrict__ ref_ptr,
+OARD_KERNEL __global__ void k_check_edge_set(const int* __restrict__ ref_sample, const int* __restrict__ ref_rank, const long long* __restrict__ ref_ptr,
                                  int n_nodes, const long long* __restrict__ ei, long long n_edges, unsigned* bitmap, int* ok) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_edges) return;
@@ -224,7 +224,7 @@ struct ObjPtrs {
 
 OARD_DEV float silu_acc(float x) { return x / (1.0f + expf(-x)); }
 
-__global__ void k_prep(TopoDev tp, ObjPtrs op, const float* __restrict__ wb, float* __restrict__ pos,
+OARD_KERNEL __global__ void k_prep(TopoDev tp, ObjPtrs op, const float* __restrict__ wb, float* __restrict__ pos,
                        float* __restrict__ hin, const float* __restrict__ t, int t_scalar,
                        const float* __restrict__ cond, int cnf, int ctime, int emb) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,7 +255,7 @@ __global__ void k_prep(TopoDev tp, ObjPtrs op, const float* __restrict__ wb, flo
     for (; c < 16; ++c) h[c] = 0.f;
 }
 
-__global__ void k_post(TopoDev tp, ObjPtrs op, const float* __restrict__ wb, const float* __restrict__ dpos,
+OARD_KERNEL __global__ void k_post(TopoDev tp, ObjPtrs op, const float* __restrict__ wb, const float* __restrict__ dpos,
                        const float* __restrict__ hout, int emb) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= tp.N) return;
@@ -289,7 +289,7 @@ __global__ void k_post(TopoDev tp, ObjPtrs op, const float* __restrict__ wb, con
 // before the per-object CoM removal): when the call's status flag is set, EVERY object's velocity block is replaced by CoM-free
 // N(0,1) noise the caller drew beforehand; otherwise nothing is touched.  One thread per node.
 struct NanPtrs { const float* noise[OARD_MAX_OBJECTS]; float* out[OARD_MAX_OBJECTS]; int node_nf[OARD_MAX_OBJECTS]; };
-__global__ void k_nan_replace(TopoDev tp, NanPtrs np, const int* __restrict__ status) {
+OARD_KERNEL __global__ void k_nan_replace(TopoDev tp, NanPtrs np, const int* __restrict__ status) {
     if (status[0] == 0) return;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= tp.N) return;
@@ -318,7 +318,7 @@ struct SamplerPtrs {
 };
 // coef != NULL: the three schedule scalars come from device memory (a captured hipGraph replays the same launch for every
 // step; the host only advances a device-side step counter that selects the row of the coefficient table)
-__global__ void k_sampler_step(TopoDev tp, SamplerPtrs sp, int mode, float a, float b, float c, const float* __restrict__ coef,
+OARD_KERNEL __global__ void k_sampler_step(TopoDev tp, SamplerPtrs sp, int mode, float a, float b, float c, const float* __restrict__ coef,
                                int zero_h) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= tp.N) return;
@@ -364,7 +364,7 @@ __global__ void k_sampler_step(TopoDev tp, SamplerPtrs sp, int mode, float a, fl
 // =====================================================================================================
 // one 64-thread block per (sample, object) group: cutoff graph inside the group, the reference's
 // one-hop labelling with overwrites, label-mean removal; then the node frame in its exact form.
-__global__ void k_geom(TopoDev tp, const float* __restrict__ pos, double cutoff, double* __restrict__ pf64,
+OARD_KERNEL __global__ void k_geom(TopoDev tp, const float* __restrict__ pos, double cutoff, double* __restrict__ pf64,
                        float* __restrict__ pf32, float* __restrict__ x1, float* __restrict__ pp0,
                        int* __restrict__ labels) {
     __shared__ double sp[OARD_MAX_GROUP * 3];
@@ -416,7 +416,7 @@ __global__ void k_geom(TopoDev tp, const float* __restrict__ pos, double cutoff,
 // one thread per inner (same-object) edge: cutoff mask from raw positions (:747-753), edge frame from
 // pos_frame (:693-705), masked (:768-771), envelope (:785)
 // blk_cnt (optional): [gridDim.x] number of inner edges of this block (256 rows) inside the cutoff - first pass of k_active_list
-__global__ __launch_bounds__(256) void k_edge_geo(TopoDev tp, const float* __restrict__ pos, const double* __restrict__ pf64,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_edge_geo(TopoDev tp, const float* __restrict__ pos, const double* __restrict__ pf64,
                            double cutoff, float* __restrict__ geo, double* __restrict__ d64, int* __restrict__ blk_cnt) {
     const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (blk_cnt != nullptr) {                    // (before the early exit: every thread of the block takes part)
@@ -486,7 +486,7 @@ OARD_DEV float lin3u_table_eval(const float* __restrict__ tab, float x) {
 // function and set the flag (the last block of a layer to finish decides; tab[flag + 1 .. 3] = worst deviation, range, block counter).
 // ~30 us per weight update (a training step repacks every step), spread over 4 CUs per layer.
 struct L3tJobs { size_t l3u[OARD_MAX_LAYERS], l3t[OARD_MAX_LAYERS]; };
-__global__ __launch_bounds__(256) void k_lin3u_table_fill(float* __restrict__ blob, L3tJobs j) {
+OARD_KERNEL __global__ __launch_bounds__(256) void k_lin3u_table_fill(float* __restrict__ blob, L3tJobs j) {
     const float* p = blob + j.l3u[blockIdx.y];
     float* tab = blob + j.l3t[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void k_lin3u_table_fill(float* __restrict__ bl
         tab[2 * (L3T_N + 1)] = 0.f; tab[2 * (L3T_N + 1) + 1] = 0.f; tab[2 * (L3T_N + 1) + 2] = 0.f; tab[2 * (L3T_N + 1) + 3] = 0.f;
     }
 }
-__global__ __launch_bounds__(256) void k_lin3u_table_check(float* __restrict__ blob, L3tJobs j) {
+OARD_KERNEL __global__ __launch_bounds__(256) void k_lin3u_table_check(float* __restrict__ blob, L3tJobs j) {
     __shared__ float red_e[256], red_f[256];
     const float* p = blob + j.l3u[blockIdx.y];
     float* tab = blob + j.l3t[blockIdx.y];
@@ -529,14 +529,14 @@ __global__ __launch_bounds__(256) void k_lin3u_table_check(float* __restrict__ b
 }
 // Zeroes up to 64 short rows in one launch (the spare rows of the training tape, oard_hip.hip: forward_impl)
 struct ZeroRows { float* p[64]; int n[64]; int count; };
-__global__ __launch_bounds__(256) void k_zero_rows(ZeroRows z) {
+OARD_KERNEL __global__ __launch_bounds__(256) void k_zero_rows(ZeroRows z) {
     if ((int)blockIdx.x >= z.count) return;
     float* p = z.p[blockIdx.x];
     for (int i = threadIdx.x; i < z.n[blockIdx.x]; i += 256) p[i] = 0.f;
 }
 // Compaction of the inner rows inside the cutoff (ActList, oard_layout.h): block b (256 rows, the blocks of k_edge_geo) adds the
 // counts of the blocks in front of it, scans its own 256 flags and writes pre[a] for every row, (row, source) for the active ones.
-__global__ __launch_bounds__(256) void k_active_list(TopoDev tp, const float* __restrict__ geo, const int* __restrict__ blk_cnt,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_active_list(TopoDev tp, const float* __restrict__ geo, const int* __restrict__ blk_cnt,
                                                      int* __restrict__ rows, int* __restrict__ src, int* __restrict__ pre, int* __restrict__ n_act) {
     __shared__ int red[256];
     __shared__ int wsum[4];
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void k_active_list(TopoDev tp, const float* __
     if (on) { rows[off] = (int)a; src[off] = tp.act_src[a]; }
     if (a == tp.A - 1) { const int tot = off + (on ? 1 : 0); pre[tp.A] = tot; *n_act = tot; }
 }
-__global__ void k_rbf(TopoDev tp, const double* __restrict__ d64, const float* __restrict__ geo,
+OARD_KERNEL __global__ void k_rbf(TopoDev tp, const double* __restrict__ d64, const float* __restrict__ geo,
                       const float* __restrict__ means, const float* __restrict__ betas, double cutoff,
                       float* __restrict__ rbuf, float* __restrict__ ew, int R, int RP, int H, int WP) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -584,7 +584,7 @@ __global__ void k_rbf(TopoDev tp, const double* __restrict__ d64, const float* _
 }
 
 // every edge starts as the masked-edge constant row; inner edges are then overwritten
-__global__ void k_fill_edges(const float* __restrict__ c0, float* __restrict__ ew, long long E, int WP) {
+OARD_KERNEL __global__ void k_fill_edges(const float* __restrict__ c0, float* __restrict__ ew, long long E, int WP) {
     const int per = WP / 4;                    // E = number of rows to fill starting at `ew`
     const long long total = E * per;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void k_node_pre(TopoDev tp, const float* __res
     f4 v[D::HT];
 #pragma unroll
     for (int t = 0; t < D::HT; ++t)
-        v[t] = dense_tile<D::PB>(wb + po.pe1, t, hid, id.lane, ld_blk(s, n, D::HP, t, id.lane));
+        v[t] = ld_blk(s, n, D::HP, t, id.lane) + dense_tile<D::PB>(wb + po.pe1, t, hid, id.lane, f4zero());      // (summed on its own: see k_node_pre_v1)
     layer_norm<D::HT, D::H, true>(v, wb + lo.ln_g_w, wb + lo.ln_g_b, id.lane);
 #pragma unroll
     for (int t = 0; t < D::HT; ++t)
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_out(TopoDev tp, const float* __restrict
 // =====================================================================================================
 // taps (tests): copy internal buffers out in the reference's node / edge order
 // =====================================================================================================
-__global__ void k_tap_nodes(TopoDev tp, const float* __restrict__ src, int src_ld, int sections, int sect_pad,
+OARD_KERNEL __global__ void k_tap_nodes(TopoDev tp, const float* __restrict__ src, int src_ld, int sections, int sect_pad,
                             int sect_len, float* __restrict__ dst) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int cols = sections * sect_len;
@@ -1125,11 +1125,11 @@ __global__ void k_tap_nodes(TopoDev tp, const float* __restrict__ src, int src_l
     const int n = (int)(i / cols), c = (int)(i % cols);
     dst[(size_t)tp.node_ref[n] * cols + c] = src[(size_t)n * src_ld + (c / sect_len) * sect_pad + (c % sect_len)];
 }
-__global__ void k_tap_labels(TopoDev tp, const int* __restrict__ labels, float* __restrict__ dst) {
+OARD_KERNEL __global__ void k_tap_labels(TopoDev tp, const int* __restrict__ labels, float* __restrict__ dst) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n < tp.N) dst[tp.node_ref[n]] = (float)labels[n];
 }
-__global__ void k_tap_edges(TopoDev tp, const float* __restrict__ ew, int WP, int W, float* __restrict__ dst) {
+OARD_KERNEL __global__ void k_tap_edges(TopoDev tp, const float* __restrict__ ew, int WP, int W, float* __restrict__ dst) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= tp.E * W) return;
     const long long e = i / W;

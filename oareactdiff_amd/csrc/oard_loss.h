@@ -34,7 +34,7 @@ OARD_DEV float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 OARD_DEV float gauss_cdf(float x) { return 0.5f * (1.0f + erff(x * 0.70710678118654752f)); }
 
 // one thread per node: z_t, eps                                    en_diffusion.py:250-306 (noised_representation, sample_*_noise)
-__global__ void k_loss_prep(TopoDev tp, LossPtrs lp, LossCfg lc, const float* __restrict__ t_int, const float* __restrict__ gamma) {
+OARD_KERNEL __global__ void k_loss_prep(TopoDev tp, LossPtrs lp, LossCfg lc, const float* __restrict__ t_int, const float* __restrict__ gamma) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= tp.N) return;
     const int obj = tp.node_obj[n], row = tp.node_row[n], nf = lp.node_nf[obj];
@@ -75,7 +75,7 @@ __global__ void k_loss_prep(TopoDev tp, LossPtrs lp, LossCfg lc, const float* __
 // one 64-thread block per sample: error terms, t = 0 likelihood terms, nll, logged terms, d(mean nll)/d(net)
 //   terms [2 n_obj][B]: rows 0..n_obj-1 = normalised, scaled error per object (before the division by scales + 1e-4 of the log),
 //                       rows n_obj.. = un-normalised error per object                                      pl_trainer.py:268-277
-__global__ __launch_bounds__(64) void k_loss_terms(TopoDev tp, LossPtrs lp, LossCfg lc, const float* __restrict__ t_int,
+OARD_KERNEL __global__ __launch_bounds__(64) void k_loss_terms(TopoDev tp, LossPtrs lp, LossCfg lc, const float* __restrict__ t_int,
                                                    const float* __restrict__ gamma, int B, float* __restrict__ nll,
                                                    float* __restrict__ terms) {
     const int sb = blockIdx.x, lane = threadIdx.x;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void k_loss_terms(TopoDev tp, LossPtrs lp, Loss
 // (clip_grad_norm_'s factor; 1 = no clipping).  Every derived scalar comes from the host in double precision, rounded once, exactly
 // as torch passes its Python-float scalars to the element-wise kernels: decay = 1 - lr wd, w1 = 1 - beta1, w2 = 1 - beta2,
 // step_size = lr / (1 - beta1^t), inv_bc2s = 1 / sqrt(1 - beta2^t) (torch divides a tensor by a scalar as a product with its inverse).
-__global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+OARD_KERNEL __global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                         float* __restrict__ vmax, long long n, float decay, float w1, float beta2, float w2, float eps, float step_size,
                         float inv_bc2s, int amsgrad, float gscale) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,7 +188,7 @@ OARD_DEV double np_sum(const double* a, int n) {
 }
 
 // out: grad_norm, max_norm (NaN when not clipping or skipped), gscale, skipped
-__global__ void k_clip_decide(double* __restrict__ st, int cap, const float* __restrict__ norm, const float* __restrict__ flag, int clip_on,
+OARD_KERNEL __global__ void k_clip_decide(double* __restrict__ st, int cap, const float* __restrict__ norm, const float* __restrict__ flag, int clip_on,
                               double lr, double beta1, double beta2, double eps, double wd, float* __restrict__ out) {
 #pragma clang fp contract(off)          // the host evaluates these expressions without fused multiply-adds
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -227,7 +227,7 @@ __global__ void k_clip_decide(double* __restrict__ st, int cap, const float* __r
 }
 
 // k_adamw with the scalars of the step read from device memory; a skipped step touches nothing
-__global__ void k_adamw_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+OARD_KERNEL __global__ void k_adamw_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             float* __restrict__ vmax, long long n, int amsgrad, const AdamScal* __restrict__ sc) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || sc->skip) return;

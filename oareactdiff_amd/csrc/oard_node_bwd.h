@@ -352,13 +352,13 @@ __global__ __launch_bounds__(256) void k_equi_msg_bwd(TopoDev tp, const float* _
 // h2a = dout * (h2[8], 1, 0, 0, 0), whose column sums are the gradients of lin3.4's weight and bias.
 // p: raw parameter block  w0[48][3] b0[48] w2[8][48] b2[8] w4[8] b4[1]  (LayerOff::l3u)
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_lin3u_fwd(const float* __restrict__ p, const float* __restrict__ x, long long n,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_lin3u_fwd(const float* __restrict__ p, const float* __restrict__ x, long long n,
                                                    float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = lin3u(p, x[i]);
 }
 
-__global__ __launch_bounds__(256) void k_lin3u_bwd(const float* __restrict__ p, const float* __restrict__ x,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_lin3u_bwd(const float* __restrict__ p, const float* __restrict__ x,
                                                    const float* __restrict__ dout, long long n, float* __restrict__ dx,
                                                    float* __restrict__ xa, float* __restrict__ h1o, float* __restrict__ dz1o,
                                                    float* __restrict__ h2a, float* __restrict__ dz2o) {
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lin3u_bwd_fused(const float* __r
 // one wave per parameter-gradient entry: fixed-order sum over the per-wave partial blocks, ADDED to the destination
 //   entries: [0, 384) lin3.2.weight [8][48] | [384, 392) lin3.2.bias | [392, 400) lin3.4.weight | [400, 448) lin3.0.weight[:, 0]
 //            | [448, 496) lin3.0.bias | 496 lin3.4.bias
-__global__ __launch_bounds__(256) void k_lin3u_reduce(const float* __restrict__ partial, int n_waves, float* __restrict__ gw0,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_lin3u_reduce(const float* __restrict__ partial, int n_waves, float* __restrict__ gw0,
                                                       float* __restrict__ gb0, float* __restrict__ gw2, float* __restrict__ gb2,
                                                       float* __restrict__ gw4, float* __restrict__ gb4) {
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;

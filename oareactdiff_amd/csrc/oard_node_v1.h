@@ -308,12 +308,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_node_pre_v1(TopoDev tp, const fl
         for (int i = 0; i < TPW; ++i) {
             const int t = min(nb.wave + i * WAVES, D::HT - 1);
             job[i] = tile_job<D::PB>(wb + po.pe1, t, hid);
-            acc[i] = ld_blk(s, nb.n, D::HP, t, nb.lane);
+            acc[i] = f4zero();
         }
         dense_seq<D::PB, TPW, OARD_NODE_PRE_G>(job, nb.lane, acc);
+        // s + pos_expansion(.): the product is summed on its own and added to s ONCE, as `s = s + mlp(pos_prjt)` does (leftnet.py:840-841).
+        // Rounds 1-5 started the chain AT s: ~100 small terms, each rounded at the magnitude of s - the one stage of the forward whose
+        // error sat above plain torch float32's (tools/stage_error.py: 4.5e-7 against 1.6e-7 per layer; it is what made the node state's
+        // error grow to 1.3e-6 over the six layers and config 1's worst call read 5e-6 ... 9e-6)
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (nb.wave + i * WAVES < D::HT) lds_st(sv, nb.wave + i * WAVES, nb.lane, acc[i]);
+            if (nb.wave + i * WAVES < D::HT)
+                lds_st(sv, nb.wave + i * WAVES, nb.lane, ld_blk(s, nb.n, D::HP, nb.wave + i * WAVES, nb.lane) + acc[i]);
     }
     __syncthreads();
     float mean, rstd;

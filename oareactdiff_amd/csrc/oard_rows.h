@@ -157,7 +157,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_rows_dense_long(RowsDense a) {
 // ---- LayerNorm on rows (torch.nn.LayerNorm: biased variance, eps = 1e-5 inside the sqrt) ---------------------------------------
 // one wave per row; HP <= 256 (4 features per lane).  gamma / beta may be nullptr (no affine part).
 // Y = LN(X + (Xadd ? Xadd : 0)); Sum (optional) receives X + Xadd (the tensor the statistics are taken of)
-__global__ __launch_bounds__(256) void k_rows_ln_fwd(const float* __restrict__ X, const float* __restrict__ Xadd, int ld, int H, int HP,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_rows_ln_fwd(const float* __restrict__ X, const float* __restrict__ Xadd, int ld, int H, int HP,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ Y, float* __restrict__ Sum, long long rows) {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_rows_ln_fwd(const float* __restrict__ X
 // adjoint: given X (the normalised tensor's input) and dY:   dxhat = dY * gamma;
 //   dX = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));   G = dY * xhat (its column sums are d gamma; those of dY are d beta)
 // dX = (Dadd ? Dadd : 0) + that.
-__global__ __launch_bounds__(256) void k_rows_ln_bwd(const float* __restrict__ X, int ld, int H, int HP, const float* __restrict__ gamma,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_rows_ln_bwd(const float* __restrict__ X, int ld, int H, int HP, const float* __restrict__ gamma,
                                                      const float* __restrict__ dY, const float* __restrict__ Dadd,
                                                      float* __restrict__ dX, float* __restrict__ G, long long rows) {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_rows_ln_bwd(const float* __restrict__ X
 // chunks in a fixed order (chunk_sum_wave).  Deterministic, no atomics.  Optional per-row weight (a [rows] vector, e.g. the gate
 // adjoint) and SiLU applied to X on load (the att_mlp gradient: sum_e da_e SiLU(z2_e)).
 #define CS_ROWS 64
-__global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
                                                      const float* __restrict__ wrow, int x_silu, float* __restrict__ part) {
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= ncols) return;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ X
 // sums are a function of (rows, rows per block) only - still a fixed order)
 #define CSL_ROWS 512
 #define CSL_ROWS_SHORT 32
-__global__ __launch_bounds__(256) void k_colsum_long(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_colsum_long(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
                                                      const float* __restrict__ wrow, int x_silu, float* __restrict__ part, int rows_per_block) {
     // float64 accumulators (round 5): the att_mlp gradients are sums of a signed value over every edge whose terms largely cancel (condition
     // ~ sqrt(E)); with float32 running sums the bias gradient - one scalar - carried ~1e-5 of relative error.  The kernel is bound by its loads.
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_colsum_long(const float* __restrict__ X
 // of one per column - thread t of chunk q adds rows q CSN_ROWS + t, + 256, ... for all columns in registers, then the 256 thread
 // sums are combined by a fixed tree in LDS.  part[q][c] as above.
 #define CSN_ROWS 8192
-__global__ __launch_bounds__(256) void k_colsum_narrow(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_colsum_narrow(const float* __restrict__ X, int ld, long long r0, long long r1, int ncols,
                                                        const float* __restrict__ wrow, float* __restrict__ part) {
     __shared__ float red[256][17];
     const long long rb = r0 + (long long)blockIdx.x * CSN_ROWS, re = rb + CSN_ROWS < r1 ? rb + CSN_ROWS : r1;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_colsum_narrow(const float* __restrict__
     }
     if ((int)threadIdx.x < ncols) part[(size_t)blockIdx.x * ncols + threadIdx.x] = red[0][threadIdx.x];
 }
-__global__ __launch_bounds__(256) void k_colsum_fin(const float* __restrict__ part, int n_chunks, int ncols, float* __restrict__ out,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_colsum_fin(const float* __restrict__ part, int n_chunks, int ncols, float* __restrict__ out,
                                                     int accumulate, float scale) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= ncols) return;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_colsum_fin(const float* __restrict__ pa
 }
 
 // out[i][j] (+)= a[i] * b[j]   (the constant-row term of layer 0's edge_mlp.0 gradient: outer(sum_e dz1_e, c0row))
-__global__ void k_outer_acc(float* __restrict__ out, int ld, const float* __restrict__ a, int na, const float* __restrict__ b, int nb_,
+OARD_KERNEL __global__ void k_outer_acc(float* __restrict__ out, int ld, const float* __restrict__ a, int na, const float* __restrict__ b, int nb_,
                             int accumulate) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)na * nb_) return;
@@ -342,16 +342,16 @@ __global__ void k_outer_acc(float* __restrict__ out, int ld, const float* __rest
 }
 
 // out[i * stride] += a[i]   (a gradient that lands in one column of a wider parameter)
-__global__ void k_strided_acc(const float* __restrict__ a, int n, float* __restrict__ out, int stride) {
+OARD_KERNEL __global__ void k_strided_acc(const float* __restrict__ a, int n, float* __restrict__ out, int stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[(size_t)i * stride] += a[i];
 }
-__global__ void k_silu_rows(const float* __restrict__ z, long long n, float* __restrict__ out) {
+OARD_KERNEL __global__ void k_silu_rows(const float* __restrict__ z, long long n, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = silu1(z[i]);
 }
 // out = a * SiLU'(z)
-__global__ void k_mul_dsilu_rows(const float* __restrict__ a, const float* __restrict__ z, long long n, float* __restrict__ out) {
+OARD_KERNEL __global__ void k_mul_dsilu_rows(const float* __restrict__ a, const float* __restrict__ z, long long n, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float zz = z[i], s = __builtin_amdgcn_rcpf(1.0f + __expf(-zz));

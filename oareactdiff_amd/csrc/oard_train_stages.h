@@ -266,14 +266,14 @@ static int wg(const TrainCtx& x, const float* dY, int ldY, int ncY, int o_len, i
 
 // ---- element-wise pieces ---------------------------------------------------------------------------------------------------------------
 // pos_expansion hidden layer (leftnet.py:642-648 on pos_prjt = (pp0, 0, 0): only column 0 of mlp.0 takes part)
-__global__ void k_pe_hidden(const float* __restrict__ pe0, const float* __restrict__ pp0, int N, int H2, int PP, float* __restrict__ hid) {
+OARD_KERNEL __global__ void k_pe_hidden(const float* __restrict__ pe0, const float* __restrict__ pp0, int N, int H2, int PP, float* __restrict__ hid) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)N * PP) return;
     const int n = (int)(i / PP), k = (int)(i % PP);
     hid[i] = k < H2 ? silu1(pe0[k * 3] * pp0[n]) : 0.f;
 }
 // dzh = dhid * SiLU'(pe0[k] pp0[n])
-__global__ void k_pe_dz(const float* __restrict__ pe0, const float* __restrict__ pp0, int N, int H2, int PP, const float* __restrict__ dhid,
+OARD_KERNEL __global__ void k_pe_dz(const float* __restrict__ pe0, const float* __restrict__ pp0, int N, int H2, int PP, const float* __restrict__ dhid,
                         float* __restrict__ dzh) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)N * PP) return;
@@ -283,7 +283,7 @@ __global__ void k_pe_dz(const float* __restrict__ pe0, const float* __restrict__
     dzh[i] = v;
 }
 // EquiUpdate: sc = <vec1, x1> (the frame scalar before lin3), vdot = <vec1, vec2> / sqrt(H)       leftnet.py:329-335
-__global__ void k_upd_sc(const float* __restrict__ v12, const float* __restrict__ x1, int N, int HP, float inv_sqrt_h,
+OARD_KERNEL __global__ void k_upd_sc(const float* __restrict__ v12, const float* __restrict__ x1, int N, int HP, float inv_sqrt_h,
                          float* __restrict__ sc, float* __restrict__ vdot) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)N * HP) return;
@@ -299,7 +299,7 @@ __global__ void k_upd_sc(const float* __restrict__ v12, const float* __restrict_
 }
 // adjoint seeds of EquiUpdate's outputs:  s_out = s_a + (a + b + vdot)/sqrt2,  vec_out[x] = vec_a[x] + c vec2[x]
 //   dabc = [ds/sqrt2 | ds/sqrt2 | sum_x dvec[x] vec2[x]],  d vec2[x] = dvec[x] c + vec1[x] ds/sqrt2/sqrtH,  d vec1[x] = vec2[x] ds/sqrt2/sqrtH (+ dsc x1[x] later)
-__global__ void k_upd_seed(const float* __restrict__ ds, const float* __restrict__ dvec, const float* __restrict__ v12,
+OARD_KERNEL __global__ void k_upd_seed(const float* __restrict__ ds, const float* __restrict__ dvec, const float* __restrict__ v12,
                            const float* __restrict__ cvec, int N, int HP, float inv_sqrt_h, float* __restrict__ dabc,
                            float* __restrict__ dv12) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,7 +318,7 @@ __global__ void k_upd_seed(const float* __restrict__ ds, const float* __restrict
     float* o = dabc + (size_t)n * 3 * HP;
     o[ch] = dsq; o[HP + ch] = dsq; o[2 * HP + ch] = dc;
 }
-__global__ void k_upd_dv1(const float* __restrict__ dsc, const float* __restrict__ x1, int N, int HP, float* __restrict__ dv12) {
+OARD_KERNEL __global__ void k_upd_dv1(const float* __restrict__ dsc, const float* __restrict__ x1, int N, int HP, float* __restrict__ dv12) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)N * HP) return;
     const int n = (int)(i / HP), ch = (int)(i % HP);
@@ -326,7 +326,7 @@ __global__ void k_upd_dv1(const float* __restrict__ dsc, const float* __restrict
 #pragma unroll
     for (int k = 0; k < 3; ++k) dv12[((size_t)n * 3 + k) * 2 * HP + ch] += d * x1[n * 3 + k];
 }
-__global__ void k_scale_rows(const float* __restrict__ a, float scale, long long n, float* __restrict__ out) {
+OARD_KERNEL __global__ void k_scale_rows(const float* __restrict__ a, float scale, long long n, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] * scale;
 }
@@ -616,7 +616,7 @@ struct TailPtrs {
     size_t dec[OARD_MAX_OBJECTS], enc[OARD_MAX_OBJECTS];      // offsets of the raw MLP blocks in the packed blob
 };
 // v1 = |vec1_proj(vec)|_xyz per channel, v2s[n][x] = <vec[n][x], vec2_proj.weight>          one 64-thread block per node
-__global__ __launch_bounds__(64) void k_out_norms(const float* __restrict__ u, const float* __restrict__ vec, const float* __restrict__ v2p,
+OARD_KERNEL __global__ __launch_bounds__(64) void k_out_norms(const float* __restrict__ u, const float* __restrict__ vec, const float* __restrict__ v2p,
                                                   int HP, float* __restrict__ v1, float* __restrict__ v2s) {
     const int n = blockIdx.x;
     float p[3] = {0.f, 0.f, 0.f};
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(64) void k_out_norms(const float* __restrict__ u, c
 }
 // per node: cotangent of dpos through the CoM removal, decoder adjoint (operands of its weight gradients in REFERENCE row order:
 // objects are contiguous there), gate / vec2 adjoints.   dxg [N][16] = (0, dgate, 0 ...), dhout [N][16], dv2s [N][3]
-__global__ void k_post_bwd(TopoDev tp, TailPtrs tl, const float* __restrict__ wb, const float* __restrict__ hout,
+OARD_KERNEL __global__ void k_post_bwd(TopoDev tp, TailPtrs tl, const float* __restrict__ wb, const float* __restrict__ hout,
                            const float* __restrict__ xg, const float* __restrict__ v2s, int emb, float* __restrict__ dxg,
                            float* __restrict__ dhout, float* __restrict__ dv2s, float* __restrict__ dgate, float* __restrict__ dec_dy,
                            float* __restrict__ dec_hid, float* __restrict__ dec_dz, float* __restrict__ dec_x) {
@@ -695,7 +695,7 @@ __global__ void k_post_bwd(TopoDev tp, TailPtrs tl, const float* __restrict__ wb
     }
 }
 // du[x] = dv1 u[x] / v1 (zero subgradient at v1 = 0, as torch.norm);  zadd[x] = dv2s[x] vec2_proj.weight
-__global__ void k_out_du(const float* __restrict__ dv1, const float* __restrict__ v1, const float* __restrict__ u,
+OARD_KERNEL __global__ void k_out_du(const float* __restrict__ dv1, const float* __restrict__ v1, const float* __restrict__ u,
                          const float* __restrict__ dv2s, const float* __restrict__ v2p, int N, int HP, float* __restrict__ du,
                          float* __restrict__ zadd) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -795,7 +795,7 @@ static int tr_tail_bwd(const TrainCtx& x, const TrainTail& tw, const oard_topolo
 //   call's inputs (encoder gradients).
 // =====================================================================================================================================
 // sums of X over the nodes of every sample / (sample, object) group, fixed order            one block per sample
-__global__ __launch_bounds__(256) void k_seg_sums(TopoDev tp, const float* __restrict__ X, int HP, float* __restrict__ outS,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_seg_sums(TopoDev tp, const float* __restrict__ X, int HP, float* __restrict__ outS,
                                                   float* __restrict__ outG) {
     const int b = blockIdx.x, ch = threadIdx.x;
     if (ch >= HP) return;
@@ -871,14 +871,14 @@ __global__ __launch_bounds__(256) void k_nbr_bwd(TopoDev tp, const float* __rest
     ipro[i] = dsn * (segSn[(size_t)smp * D::HP + ch] - segGn[(size_t)q_grp * D::HP + ch]);
 }
 // dfr[a] = df[a] env[a]
-__global__ void k_scale_by_env(const float* __restrict__ df, const float* __restrict__ geo, long long A, int HP, float* __restrict__ out) {
+OARD_KERNEL __global__ void k_scale_by_env(const float* __restrict__ df, const float* __restrict__ geo, long long A, int HP, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A * HP) return;
     out[i] = df[i] * geo[(i / HP) * GEO_STRIDE + 1];
 }
 // the constant row of the inter-object edges, c0 = [lin3(0) x 2H | radial_lin(0) | 0 x R]  (k_c0row):  adjoint into the biases /
 // last layers it is made of.  dc0 [W] = sum of dew over the inter-object rows (+ the NeighborEmb share of the f section in dc0f_extra)
-__global__ __launch_bounds__(256) void k_c0_bwd(const float* __restrict__ dc0, const float* __restrict__ dc0f_extra, int H, int H4,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_c0_bwd(const float* __restrict__ dc0, const float* __restrict__ dc0f_extra, int H, int H4,
                                                 const float* __restrict__ l3b0, const float* __restrict__ l3w2, const float* __restrict__ rl0b,
                                                 const float* __restrict__ rl2w, float* __restrict__ g_l3b0, float* __restrict__ g_l3w2,
                                                 float* __restrict__ g_l3b2, float* __restrict__ g_rl0b, float* __restrict__ g_rl2w,
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(256) void k_c0_bwd(const float* __restrict__ dc0, c
 }
 // encoders (k_prep; egnn_dynamics.py:95-104): Linear(d, 2d) SiLU Linear(2d, emb) per node; operands of the weight gradients in reference order
 struct XhPtrs { const float* p[OARD_MAX_OBJECTS]; };
-__global__ void k_prep_bwd(TopoDev tp, TailPtrs tl, XhPtrs xh, const float* __restrict__ wb,
+OARD_KERNEL __global__ void k_prep_bwd(TopoDev tp, TailPtrs tl, XhPtrs xh, const float* __restrict__ wb,
                            const float* __restrict__ dhin, int emb, float* __restrict__ op_dy, float* __restrict__ op_hid,
                            float* __restrict__ op_dz, float* __restrict__ op_x) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;

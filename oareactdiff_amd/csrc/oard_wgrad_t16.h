@@ -276,7 +276,7 @@ OARD_DEV int wgt_logical(int padded, int len, int pad, int n) {
     const int sec = padded / pad, w = padded - sec * pad, l = sec * len + w;
     return (w < len && l < n) ? l : -1;
 }
-__global__ __launch_bounds__(256) void k_wgt_reduce(const float* __restrict__ partial, int n_chunks, int MT, int NT, int transposed, int o_len, int o_pad,
+OARD_KERNEL __global__ __launch_bounds__(256) void k_wgt_reduce(const float* __restrict__ partial, int n_chunks, int MT, int NT, int transposed, int o_len, int o_pad,
                                                     int MO, int i_len, int i_pad, int MI, float* __restrict__ dW, int ldW, float* __restrict__ db,
                                                     int ones_col, int acc) {
     __shared__ f4 red[4][64];

@@ -32,15 +32,31 @@ BUDGETS = {
 }
 
 
+def _compile_unit(args):
+    src, out = args
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only", "-Wno-unused-result",
+                        "-DOARD_DIMS_LIST=X(196,96)", "-Rpass-analysis=kernel-resource-usage", src, "-o", out], cwd=CSRC, capture_output=True,
+                       text=True, timeout=900)
+    return src, r.returncode, r.stderr
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_production_kernels_stay_inside_their_register_budgets(tmp_path):
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only", "-Wno-unused-result",
-                        "-DOARD_DIMS_LIST=X(196,96)", "-Rpass-analysis=kernel-resource-usage", "oard_hip.hip", "-o",
-                        os.path.join(tmp_path, "res.o")], cwd=CSRC, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    blocks = r.stderr.split("Function Name: ")[1:]
+    """Every translation unit of the library (oareactdiff_amd/build.py SOURCES), production widths, device code only, side by side."""
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(os.path.dirname(CSRC), ".."))
+    from oareactdiff_amd.build import SOURCES
+    units = [(src, os.path.join(tmp_path, os.path.splitext(src)[0] + ".o")) for src in SOURCES]
+    with ThreadPoolExecutor(max_workers=len(units)) as pool:
+        results = list(pool.map(_compile_unit, units))
+    blocks = []
+    for src, rc, err in results:
+        assert rc == 0, (src, err[-2000:])
+        blocks += err.split("Function Name: ")[1:]
     names = subprocess.run(["c++filt"], input="\n".join(b.split("\n")[0].split()[0] for b in blocks), capture_output=True,
                            text=True).stdout.splitlines()
+    assert len(set(names)) == len(names), "a kernel is emitted by two translation units: " + str(sorted({n for n in names if names.count(n) > 1})[:5])
     seen = {k: 0 for k in BUDGETS}
     bad = []
     for dem, b in zip(names, blocks):
@@ -53,18 +69,23 @@ def test_production_kernels_stay_inside_their_register_budgets(tmp_path):
                     bad.append(f"{dem[:140]}: {scratch} bytes of scratch per lane (budget {limit}), {vgpr} VGPRs")
     assert not bad, "\n".join(bad)
     assert all(v > 0 for v in seen.values()), [k for k, v in seen.items() if v == 0]
-    # ---- wait states behind MFMA results, in the ISA of the same object (round 6, advisor finding) ---------------------------------------
+    # ---- wait states behind MFMA results, in the ISA of the same objects (round 6, advisor finding) --------------------------------------
     # Some kernels issue their MFMAs as `asm volatile` (dense_seq_xyz of csrc/oard_node_v1.h, k_wgrad_t16): hipcc's hazard recogniser does
     # not look inside asm statements, and one of those kernels (k_equi_node_v1) is allowed 36 bytes of scratch - a spill store of an
     # accumulator right behind its last MFMA would read a result that is not there yet.  tools/mfma_hazard_check.py walks the disassembly
     # of EVERY kernel: no instruction but an accumulating MFMA touches an MFMA's destination inside its window.
-    co = os.path.join(tmp_path, "res.co")
-    subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + os.path.join(tmp_path, "res.o"),
-                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
-    import sys
     sys.path.insert(0, os.path.join(os.path.dirname(CSRC), "..", "tools"))
     import mfma_hazard_check as hz
-    viol, n_mfma, n_fn = hz.check(co)
+    n_mfma = n_fn = 0
+    viol = []
+    for src, out in units:
+        co = out[:-2] + ".co"
+        subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + out,
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
+        v, m, f = hz.check(co)
+        viol += v
+        n_mfma += m
+        n_fn += f
     assert n_mfma > 10000 and n_fn > 100, (n_mfma, n_fn)        # the scan saw the library
     assert not viol, "\n".join(viol[:20])
 

@@ -1,5 +1,5 @@
 """Cycle accounting of k_gcl_edge_v1's phase protocol in a probe build (run on the GPU box):
-    hipcc ... -DOARD_EXPERIMENTS -DOARD_PHASE_PROBE oard_hip.hip -o liboard_probe.so
+    OARD_LIB=.../liboard_probe.so OARD_CXXFLAGS="-DOARD_EXPERIMENTS -DOARD_PHASE_PROBE" python -m oareactdiff_amd.build
     OARD_LIB=.../liboard_probe.so python tools/phase_probe.py [parts] [sequential] [gcl_variant]
 Prints, per wave and phase: cycles in the s_waitcnt before the phase barrier, in the barrier, per LDS-DMA issue."""
 import ctypes, os, sys
