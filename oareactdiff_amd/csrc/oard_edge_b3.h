@@ -326,7 +326,8 @@ template <class D, bool TRAIN = false>
 __global__ __launch_bounds__(512, 2) void k_equi_edge_b3(TopoDev tp, const float* __restrict__ stream, const float* __restrict__ dp0b,
                                                          const float* __restrict__ dp2b, const float* __restrict__ ew,
                                                          const float* __restrict__ rbuf, float* __restrict__ qbuf,
-                                                         float* __restrict__ d1s, float* __restrict__ zd1, float* __restrict__ cdbuf) {
+                                                         float* __restrict__ d1s, float* __restrict__ zd1, float* __restrict__ cdbuf,
+                                                         ActList al) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using S = EquiB3Stream<D>;
     constexpr int WB = D::WB, D1T = D::D1T, RB = D::RB, HT = D::HT, NO = S::NO, WAVES = 8;
@@ -348,10 +349,15 @@ __global__ __launch_bounds__(512, 2) void k_equi_edge_b3(TopoDev tp, const float
     auto hook = [&]() { pf.tick(); };
     auto SL = [&](int p) -> const float* { return smem + (size_t)(p & 1) * S::SLAB * 256 + lane * 4; };
 
+    // al (round 6, as k_equi_edge_v1): the inner rows inside the cutoff; column c of the launch is list entry c, the message is exactly zero
+    // on the other rows and the node stage walks the same list.  No list (training mode): every inner row.
+    const long long n_cols = al.n != nullptr ? (long long)*al.n : tp.A;
+    if ((long long)blockIdx.x * WAVES * 16 >= n_cols) return;            // (workgroup-uniform: before the first barrier)
     const long long wt = (long long)blockIdx.x * WAVES + wave;           // this wave's 16-edge tile
     const long long c = wt * 16 + (lane & 15);
-    const size_t a = (size_t)(c < tp.A ? c : tp.A);                       // padding columns use the spare entry A
-    const float* erow = ew + (c < tp.A ? a : (size_t)tp.E) * D::WP + 4 * g;
+    const bool live = c < n_cols;
+    const size_t a = (size_t)(live ? (al.rows != nullptr ? (long long)al.rows[c] : c) : tp.A);      // padding columns use the spare entry A
+    const float* erow = ew + (live ? a : (size_t)tp.E) * D::WP + 4 * g;
     const float* rrow = rbuf + a * D::RP + 4 * g;
     float* d1w = d1s + (size_t)wt * D1T * 256 + lane * 4;                 // [tile t][lane]: this lane's f4 of d1 tile t
     auto ld_pair = [&](const float* row, int kb, int nblk, f4& x, f4& y) {

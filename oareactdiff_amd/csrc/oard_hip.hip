@@ -470,11 +470,11 @@ int launch_gcl_v1(int prec, int variant, int conc, const TopoDev& tp, const floa
 template <class D>
 int launch_equi_v1(int prec, int variant, int conc, const TopoDev& tp, const float* wb, const LayerOff& lo, const float* stream, const float* dp0b, const float* ew,
                    const float* rbuf, float* qbuf, float* zd1, float* cd, hipStream_t st, float* d1s = nullptr, ActList al = ActList{}) {
-    // (the split-precision and the latency kernels run every inner row: their q is zero on the rows outside the cutoff, which the
-    // node stage does not read when it walks the list)
+    // (the latency kernels run every inner row: their q is zero on the rows outside the cutoff, which the node stage does not read when
+    // it walks the list; the throughput kernels of both precisions take the list)
     if (zd1 && (prec & OARD_PREC_TRAIN_BF16X3) && d1s) {      // training-mode forward in split precision (optional)
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_b3<D, true>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiB3Stream<D>::LDS_BYTES), st, tp, wb + lo.equi_b3,
-                   dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s, zd1, cd);
+                   dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s, zd1, cd, ActList{});
         return OARD_OK;
     }
     if (zd1) {                   // training-mode forward
@@ -499,7 +499,7 @@ int launch_equi_v1(int prec, int variant, int conc, const TopoDev& tp, const flo
     }
     if (variant == 2 && (prec & OARD_PREC_EQUI_BF16X3) && d1s) {      // split precision (oard_edge_b3.h): the throughput shape only
         LAUNCH_LDS(F_EQUI_EDGE, (k_equi_edge_b3<D>), cdiv(tp.A, 16 * 8), 8 * 64, (EquiB3Stream<D>::LDS_BYTES), st, tp, wb + lo.equi_b3,
-                   dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s, nullptr, nullptr);
+                   dp0b, wb + lo.dp2b, ew, rbuf, qbuf, d1s, nullptr, nullptr, al);
         return OARD_OK;
     }
     switch (variant) {

@@ -42,7 +42,7 @@ OARD_DIMS_LIST
 
 // ---- split-precision edge kernels (oard_edge_b3.h) -------------------------------------------------------------------------------------
 #if !defined(OARD_INST_DEFINE) || defined(OARD_INST_UNIT_B3)
-#define OARD_A_EQUI_B3 (TopoDev, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*)
+#define OARD_A_EQUI_B3 (TopoDev, const float*, const float*, const float*, const float*, const float*, float*, float*, float*, float*, ActList)
 #define OARD_I_GCL_B3(D, S1, S3) OARD_INST((k_gcl_edge_b3<OARD_UNPAREN D, S1, S3, false>), OARD_A_GCL) OARD_INST((k_gcl_edge_b3<OARD_UNPAREN D, S1, S3, true>), OARD_A_GCL)
 #define X(h, r) OARD_BOOL4(OARD_I_GCL_B3, (Dims<h, r>)) OARD_INST((k_equi_edge_b3<Dims<h, r>, false>), OARD_A_EQUI_B3) OARD_INST((k_equi_edge_b3<Dims<h, r>, true>), OARD_A_EQUI_B3)
 OARD_DIMS_LIST

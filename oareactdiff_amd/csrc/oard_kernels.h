@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void k_neighbor(TopoDev tp, const float* __res
     const int n = id.col, smp = tp.node_sample[n], s0 = tp.sample_ptr[smp], ns = tp.sample_ptr[smp + 1] - s0;
     f4 acc[D::HT];
 #pragma unroll
-    for (int t = 0; t < D::HT; ++t) acc[t] = ld_blk(zemb, n, D::HP, t, id.lane);
+    for (int t = 0; t < D::HT; ++t) acc[t] = f4zero();                 // (the sum on its own, z_emb added once: see k_neighbor_v1)
     const int mx = wave_max(ns);
     for (int k = 0; k < mx; ++k) {
         const int m = s0 + k;
@@ -661,6 +661,8 @@ __global__ __launch_bounds__(256) void k_neighbor(TopoDev tp, const float* __res
                     acc[t] += ld_f4(frow + 16 * t + 4 * id.g) * ld_blk(nb, m, D::HP, t, id.lane);
         }
     }
+#pragma unroll
+    for (int t = 0; t < D::HT; ++t) acc[t] += ld_blk(zemb, n, D::HP, t, id.lane);
     if (id.valid)
 #pragma unroll
         for (int t = 0; t < D::HT; ++t) st_blk(s, n, D::HP, t, id.lane, acc[t]);

@@ -785,7 +785,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_neighbor_v1(TopoDev tp, const fl
     const int self = n - s0;
     const float* c0f = wb + po.c0row + 2 * D::H;
     for (int t = nb.wave; t < HT; t += WAVES) {
-        f4 acc = ld_blk(zemb, n, D::HP, t, nb.lane);
+        // the neighbour sum on its own, z_emb added ONCE at the end, as `s = z_emb + scatter(...)` does (leftnet.py:81-89, 789): a chain that
+        // starts at z_emb (|.| up to 13) rounds each of the ~60 small terms at that magnitude (round 6, tools/config1_locate.py: s0 sat at
+        // 5e-7 ... 1.1e-6 of its largest entry, plain torch float32 at 2.5e-7)
+        f4 acc = f4zero();
         const bool fok = 16 * t + 4 * nb.g < D::H;                 // the f section is H wide, not HP
         const int fo = 16 * t + 4 * nb.g;
         // four neighbours in flight per step; slot k of the sample is node s0 + k, the own slot is skipped
@@ -808,6 +811,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_neighbor_v1(TopoDev tp, const fl
             for (int i = 0; i < 4; ++i)
                 if (k + i < ns && r[i] >= 0) acc += f[i] * x[i];
         }
+        acc += ld_blk(zemb, n, D::HP, t, nb.lane);
         lds_st(sv, t, nb.lane, acc);
         if (nb.valid) st_blk(s, n, D::HP, t, nb.lane, acc);
     }
