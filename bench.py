@@ -114,7 +114,7 @@ def source_stamp() -> str:
     return h.hexdigest()[:16]
 
 
-PROFILE_TAG = os.environ.get("OARD_PROFILE_TAG", "round5")
+PROFILE_TAG = os.environ.get("OARD_PROFILE_TAG", "round6")
 
 
 def pmc_traffic(kernel: str, prefix: str = None, tag: str = None):

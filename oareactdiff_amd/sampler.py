@@ -90,16 +90,17 @@ class DiffusionSampler:
         a, sg = self.schedule.alpha_sigma(step, n_steps)
         return sg / (a * a * self.prior_std * self.prior_std + sg * sg)
 
-    def _add_prior(self, eps_hat, z, coef) -> None:
-        """eps_hat[:, :pos_dim] += coef * z[:, :pos_dim] per object; `coef` a host float (eager loop) or a [1] device tensor (graph)."""
+    def _prior_table(self, timesteps: int, dev) -> Tensor:
+        """[T + 1] float32 on the device: entry k = the coefficient at time k / T.  Built once per run; both loops read their coefficient
+        from it as a [1] device tensor, so the eager loop and the hipGraph replay run the same kernel on the same operands (bit-identical)."""
+        return torch.tensor([self.prior_coefficient(k, timesteps) for k in range(timesteps + 1)], dtype=torch.float32, device=dev)
+
+    def _add_prior(self, eps_hat, z, coef: Tensor) -> None:
+        """eps_hat[:, :pos_dim] += coef * z[:, :pos_dim] per object; `coef` a [1] device tensor."""
         pd = self.pos_dim
         for e, x in zip(eps_hat, z):
-            if e.numel() == 0:
-                continue
-            if isinstance(coef, Tensor):
+            if e.numel():
                 e[:, :pd].addcmul_(x[:, :pd], coef)
-            else:
-                e[:, :pd].add_(x[:, :pd], alpha=coef)
 
     # --------------------------------------------------------------------------------------------
     def _step_kernel(self, topo, mode, z, eh, noise, h0, a, b, c, out, stream):
@@ -133,7 +134,7 @@ class DiffusionSampler:
         coef_tab = torch.tensor([[c.alpha_ts, c.c_eps, c.sigma] for c in coefs], dtype=torch.float32, device=dev)      # [T,3]
         # the eager loop's t values, bit for bit: (arange(T + 1) / T)[s + 1]
         t_tab = (torch.arange(timesteps + 1, device=dev, dtype=torch.float32) / timesteps)[torch.tensor([s + 1 for s in steps], device=dev)]
-        prior_tab = (torch.tensor([self.prior_coefficient(s + 1, timesteps) for s in steps], dtype=torch.float32, device=dev)
+        prior_tab = (self._prior_table(timesteps, dev)[torch.tensor([s + 1 for s in steps], device=dev)]
                      if self.prior_std is not None else None)
         # The noise of the steps is drawn in BLOCKS (not all T draws up front: that would be T x the eager loop's memory -
         # a [T, n, nf] table per object): at most `noise_block_bytes` of draws exist at a time, refilled between replays in
@@ -233,6 +234,7 @@ class DiffusionSampler:
                 zb = [torch.empty_like(z) for z in za]
                 self._step_kernel(topo, 2, None, None, draw(0), h0d if self.pos_only else None, 0.0, 0.0, 1.0, za, stream)
                 t_table = torch.arange(timesteps + 1, device=dev, dtype=torch.float32) / timesteps
+                ptab = self._prior_table(timesteps, dev) if self.prior_std is not None else None
                 out_samples = [None] * return_frames
                 call = 1
                 use_graph = ((n_samples <= 8 and return_frames == 1 and not torch.cuda.is_current_stream_capturing())
@@ -245,8 +247,8 @@ class DiffusionSampler:
                 for s in (reversed(range(timesteps)) if not use_graph else ()):
                     co = self.schedule.step(s, timesteps)
                     eps_hat, _ = dyn(za, edge_index, t_table[s + 1: s + 2], conditions, n_frag_switch, combined_mask)
-                    if self.prior_std is not None:
-                        self._add_prior(eps_hat, za, self.prior_coefficient(s + 1, timesteps))
+                    if ptab is not None:
+                        self._add_prior(eps_hat, za, ptab[s + 1: s + 2])
                     self._step_kernel(topo, 0, za, eps_hat, draw(call), h0d if self.pos_only else None,
                                       co.alpha_ts, co.c_eps, co.sigma, zb, stream)
                     if step_callback is not None:
@@ -257,8 +259,8 @@ class DiffusionSampler:
                         out_samples[(s * return_frames) // timesteps] = self._unnormalize_z([z.clone() for z in za])
                 fc = self.schedule.final()
                 eps_hat, _ = dyn(za, edge_index, t_table[0:1], conditions, n_frag_switch, combined_mask)
-                if self.prior_std is not None:
-                    self._add_prior(eps_hat, za, self.prior_coefficient(0, timesteps))
+                if ptab is not None:
+                    self._add_prior(eps_hat, za, ptab[0:1])
                 self._step_kernel(topo, 1, za, eps_hat, draw(call), None, fc.inv_alpha_0, fc.sigma_0, fc.sigma_x, zb, stream)
                 x = zb
                 self.last_x = x

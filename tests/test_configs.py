@@ -157,7 +157,11 @@ def test_config1_single_reaction_t50_sampler():
     print(f"config 1: trajectory error {traj:.2e} over {T + 1} calls, {inner} of {inner} inner edges active in every call; per network "
           f"call on identical inputs max {max(per_call):.2e} median {sorted(per_call)[len(per_call) // 2]:.2e} "
           f"(against the oracle on the unrounded float64 state: max {max(unrounded):.2e})")
+    # measured in round 6 (MI355X): worst call 3.5e-6 under the suite's launch shapes, 4.7e-6 under the library's defaults (OARD_TEST_SHAPES=auto);
+    # medians 1.9e-6 / 2.1e-6; plain torch float32 on the same inputs: worst 3.2e-6, median 1.4e-6.  Before the two accumulation fixes of
+    # round 6 (csrc/oard_node_v1.h: k_node_pre_v1, k_neighbor_v1): 6.0e-6 / 5.4e-6, medians 3.0e-6 / 3.4e-6.
     assert max(per_call) <= TOL
+    assert sorted(per_call)[len(per_call) // 2] <= 4e-6      # the typical call has a factor of margin
     assert max(unrounded) <= TOL
     assert traj <= 5e-5
 

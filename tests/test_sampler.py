@@ -141,6 +141,16 @@ def test_graphed_sampler_is_bitwise_identical_to_the_eager_loop(name):
     out, _ = smp.sample(c.B, c.frag, conditions=c.cond, h0=c.h0, noise_fn=c.noise, graph=True)
     for a, b in zip(res[False][0], smp.last_x):
         assert torch.equal(a, b)
+    # ... and with the Gaussian-prior term of the benchmark runs (round 6): both loops take the coefficient from the same device table
+    prior = DiffusionSampler(dyn, "polynomial_2", c.T, c.meta["precision"], pos_only=c.pos_only, gaussian_prior_std=1.0)
+    got = {}
+    for graph in (False, True):
+        prior.sample(c.B, c.frag, conditions=c.cond, h0=c.h0, noise_fn=c.noise, graph=graph)
+        got[graph] = [x.clone() for x in prior.last_x]
+    for a, b, plain in zip(got[False], got[True], res[False][0]):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+        if a.numel():
+            assert not torch.equal(a, plain)                    # the term does something
 
 
 class ICase(SCase):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # everything the end of a round re-measures on the final sources: GPU suites (fp32 / split precision), the profile passes, the training
 # timeline, the default bench line and the training lines.   usage: tools/final_round.sh <tag>     (outputs in gpurun_out/)
-tag=${1:-round5}
+tag=${1:-round6}
 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/${tag}_gpu_tests.txt; tail -1 gpurun_out/${tag}_gpu_tests.txt
 OARD_GCL_B3=1 OARD_EQUI_B3=1 OARD_TRAIN_B3=1 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/${tag}_gpu_tests_split_precision.txt
 tail -1 gpurun_out/${tag}_gpu_tests_split_precision.txt

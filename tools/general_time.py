@@ -1,0 +1,42 @@
+"""Time of one call of the general-edge-list path (csrc/oard_general.h) beside the production kernels on the same complete graph, and
+their agreement.  usage (GPU box): python tools/general_time.py [B ...]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from oareactdiff_amd.dynamics import EGNNDynamics  # noqa: E402
+from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict  # noqa: E402
+from oareactdiff_amd.synthetic import make_inputs, make_topology  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = dict(PRODUCTION_LEFTNET_CONFIG)
+sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg, seed=42)
+for B in [int(x) for x in sys.argv[1:]] or [1, 8, 64]:
+    nf = 23
+    cm, nfs, ei, masks = make_topology(B, nf)
+    xh = [x.to(dev) for x in make_inputs(B, nf, masks, 5, "cpu")]
+    args = (xh, ei.to(dev), torch.full((B, 1), 0.5, device=dev), torch.zeros(B, 1, device=dev), nfs.to(dev), cm.to(dev))
+    outs = {}
+    for path in ("auto", "general"):
+        dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0, condition_nf=1, device=dev)
+        dyn.load_state_dict(sd, strict=True)
+        dyn.edge_list_path = path
+        dyn.nan_check = "async"
+        with torch.no_grad():
+            dyn(*args)
+            torch.cuda.synchronize()
+            n = 3 if path == "general" else 10
+            t0 = time.perf_counter()
+            for _ in range(n):
+                o, _ = dyn(*args)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+        outs[path] = (torch.cat([x.reshape(-1) for x in o]).double().cpu(), dt)
+        del dyn
+    a, b = outs["auto"][0], outs["general"][0]
+    print(f"B = {B} (E = {ei.shape[1]}): production kernels {outs['auto'][1] * 1e3:.2f} ms, general path {outs['general'][1] * 1e3:.1f} ms per call; "
+          f"max |difference| / max |.| = {float((a - b).abs().max() / a.abs().max()):.2e}")
