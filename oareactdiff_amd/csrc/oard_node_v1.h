@@ -883,34 +883,72 @@ __global__ __launch_bounds__(WAVES * 64) void k_s2v_agg_v1(TopoDev tp, const flo
 }
 
 // output block (see k_out): dpos = gate * vec2_proj(vec), gate from update_net([s, |vec1_proj(vec)|]); h_out = embedding_out(s)
+// ---- float64 pieces of the output head (round 6) ------------------------------------------------------------------------------------
+// dpos = gate * vec2_proj(vec), gate = update_net(...)[1]: two dot products whose VALUES are ~10 x smaller than their terms, behind a
+// 392 -> 196 layer.  In float32 this block alone costs 2e-6 ... 3.5e-6 of the velocity (plain torch float32: 2.4e-6; tools/stage_error.py,
+// tools/config1_locate.py) - more than the whole network in front of it (1.8e-6).  It is O(N H^2) work, once per call: update_net and
+// vec2_proj run on the float64 MFMA (v_mfma_f64_16x16x4_f64; ~100 of them per wave), SiLU and the two dots in float64 VALU.  vec1_proj and
+// the norm stay float32 (measured with the oracle: their precision does not move the result).
+typedef double d4 __attribute__((ext_vector_type(4)));
+OARD_DEV double col_reduce64(double v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// One 16-row output tile of a Linear layer over an LDS-resident float32 input, accumulated in float64.  Operands as the float32 instruction
+// (A: lane 16 k + i = W[i][k], B: lane 16 k + j = x[k][j]), so the packed weight chunks and the LDS blocks are used as they are; the RESULT
+// layout differs: component r of lane (g, j) is row g + 4 r of the tile (tools/micro/mfma_f64_layout.hip), not 4 g + r.
+template <int KB>
+OARD_DEV d4 dense_tile_lds_f64(const float* __restrict__ wp, int t, const float* in, int lane) {
+    const float* base = wp + ((size_t)t * KB * 64 + lane) * 4;
+    d4 c = {0.0, 0.0, 0.0, 0.0};
+    constexpr int G = 13;
+#pragma unroll
+    for (int b0 = 0; b0 < KB; b0 += G) {
+        f4 a[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (b0 + i < KB) a[i] = ld_f4(base + (size_t)(b0 + i) * 256);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (b0 + i < KB) {
+                const f4 x = lds_blk(in, b0 + i, lane);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[i].x, (double)x.x, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[i].y, (double)x.y, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[i].z, (double)x.z, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[i].w, (double)x.w, c, 0, 0, 0);
+            }
+    }
+    return c;
+}
+
 template <class D, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_out_v1(TopoDev tp, const float* __restrict__ wb, PackOff po,
                                                        const float* __restrict__ s, const float* __restrict__ vec,
                                                        float* __restrict__ dpos, float* __restrict__ hout,
                                                        int* __restrict__ status) {
     constexpr int HT = D::HT, TPW = (HT + WAVES - 1) / WAVES;
-    __shared__ __attribute__((aligned(16))) float sm[6 * HT * 256 + 3 * 16 * 16];
+    __shared__ __attribute__((aligned(16))) float sm[5 * HT * 256];
+    __shared__ double red[4][16][16];      // [v2 x, y, z | gate][wave][column] partial sums
     float* vx = sm;                        // [3][HT]
     float* in = sm + 3 * HT * 256;         // [2 HT]: s | |vec1_proj(vec)|
-    float* hu = sm + 5 * HT * 256;         // [HT]
-    float* red = sm + 6 * HT * 256;        // [3][16 waves][16 columns] partial vec2_proj sums
     const NodeBlk nb = node_blk(tp.N, tp.npb);
     const int n = nb.n;
-    float part[3] = {0.f, 0.f, 0.f};
+    double part[3] = {0.0, 0.0, 0.0};
     for (int t = nb.wave; t < HT; t += WAVES) {
         const f4 w = ld_vec(wb + po.v2p, t, nb.lane);
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
             const f4 v = ld_blk(vec, (size_t)n * 3 + x, D::HP, t, nb.lane);
             lds_st(vx + x * HT * 256, t, nb.lane, v);
-            part[x] += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+            part[x] += (double)v.x * (double)w.x + (double)v.y * (double)w.y + (double)v.z * (double)w.z + (double)v.w * (double)w.w;
         }
         lds_st(in, t, nb.lane, ld_blk(s, n, D::HP, t, nb.lane));
     }
 #pragma unroll
     for (int x = 0; x < 3; ++x) {
-        const float p = col_reduce(part[x]);
-        if (nb.g == 0 && nb.wave < 16) red[(x * 16 + nb.wave) * 16 + (nb.lane & 15)] = p;
+        const double p = col_reduce64(part[x]);
+        if (nb.g == 0 && nb.wave < 16) red[x][nb.wave][nb.lane & 15] = p;
     }
     __syncthreads();
     {
@@ -932,36 +970,38 @@ __global__ __launch_bounds__(WAVES * 64) void k_out_v1(TopoDev tp, const float* 
     }
     __syncthreads();
     {
-        TileJob job[TPW];
-        f4 acc[TPW];
+        // update_net: hidden = SiLU(W0 [s | v1] + b0) tile by tile in float64; the gate row of W2 is applied to the tile at once, so the
+        // hidden vector is never stored: gate = b2[1] + sum over tiles, lane groups and components of W2[1][16 t + g + 4 r] h_r
+        const float* b0 = wb + po.un0_b;
+        const float* w2 = wb + po.un2;             // packed [1 tile][HT chunks]: chunk t, lane (g', o), component r' = W2[o][16 t + 4 g' + r']
+        double gpart = 0.0;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = min(nb.wave + i * WAVES, HT - 1);
-            job[i] = tile_job<2 * HT>(wb + po.un0, t, in);
-            acc[i] = ld_vec(wb + po.un0_b, t, nb.lane);
-        }
-        dense_seq<2 * HT, TPW>(job, nb.lane, acc);
+            const int t = nb.wave + i * WAVES;
+            if (t < HT) {
+                const d4 z = dense_tile_lds_f64<2 * HT>(wb + po.un0, t, in, nb.lane);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i)
-            if (nb.wave + i * WAVES < HT) lds_st(hu, nb.wave + i * WAVES, nb.lane, silu4(acc[i]));
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * t + nb.g + 4 * r;                       // the float64 MFMA's result layout
+                    const double zz = z[r] + (double)b0[row];
+                    const double h = zz / (1.0 + exp(-zz));
+                    gpart += (double)w2[(size_t)t * 256 + (16 * r + 1) * 4 + nb.g] * h;      // W2[1][row]: g' = r, o = 1, r' = g
+                }
+            }
+        }
+        const double gp = col_reduce64(gpart);
+        if (nb.g == 0 && nb.wave < 16) red[3][nb.wave][nb.lane & 15] = gp;
     }
     __syncthreads();
-    if (nb.wave == 0) {
-        const f4 xg = dense_tile_lds<HT>(wb + po.un2, 0, hu, nb.lane, ld_vec(wb + po.un2_b, 0, nb.lane));
-        // rows 0,1 of tile 0 live in lane group 0: xg.x = scalar output (unused), xg.y = gate
-        if (nb.valid && nb.g == 0) {
-            float v2s[3];
+    if (nb.wave == 0 && nb.valid && nb.g == 0) {
+        double v[4] = {0.0, 0.0, 0.0, (double)(wb + po.un2_b)[1]};
+        constexpr int NWV = WAVES < 16 ? WAVES : 16;
 #pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                float a = 0.f;
-                for (int w = 0; w < WAVES; ++w) a += red[(x * 16 + w) * 16 + (nb.lane & 15)];
-                v2s[x] = a;
-            }
-            const float gate = xg.y;
-            const float d0 = gate * v2s[0], d1 = gate * v2s[1], d2 = gate * v2s[2];
-            dpos[n * 3] = d0; dpos[n * 3 + 1] = d1; dpos[n * 3 + 2] = d2;
-            if (isnan(d0) || isnan(d1) || isnan(d2)) atomicOr(status, 1);
-        }
+        for (int x = 0; x < 4; ++x)
+            for (int w = 0; w < NWV; ++w) v[x] += red[x][w][nb.lane & 15];
+        const float d0 = (float)(v[3] * v[0]), d1 = (float)(v[3] * v[1]), d2 = (float)(v[3] * v[2]);
+        dpos[n * 3] = d0; dpos[n * 3 + 1] = d1; dpos[n * 3 + 2] = d2;
+        if (isnan(d0) || isnan(d1) || isnan(d2)) atomicOr(status, 1);
     }
     if (nb.wave == (WAVES > 1 ? 1 : 0)) {
         const f4 ho = dense_tile_lds<HT>(wb + po.embout, 0, in, nb.lane, ld_vec(wb + po.embout_b, 0, nb.lane));

@@ -95,8 +95,9 @@ def test_config1_single_reaction_t50_sampler():
       every call now sees a molecule-sized cloud with all 1 140 same-object edges active;
     * identical inputs.  The float64 oracle used to see the float64 state and the device its float32 rounding.  On that old worst
       call the ROUNDING OF THE INPUTS ALONE moves the float64 oracle by 3.9e-5 (ulp(80 A) against 10 A - d in the cutoff envelope),
-      while float32 arithmetic on identical inputs is 1.3e-6 off (measured with the oracle on the CPU).  The oracle is now
-      evaluated on the float32-rounded state, which is what "identical inputs" means; the other figure is printed beside it."""
+      while float32 arithmetic on identical inputs is 1.3e-6 off (measured with the oracle on the CPU).  The float64 replay now
+      evaluates the network on the float32 rounding of its state - where the device, whose state IS float32, evaluates it - so every
+      recorded call compares the two on identical inputs."""
     from oareactdiff_amd import DiffusionSampler
     dev = torch.device("cuda:0")
     dyn, sd, cfg = _prod_dynamics(dev)
@@ -123,13 +124,14 @@ def test_config1_single_reaction_t50_sampler():
     sd64 = {k: v.double() for k, v in sd.items()}
     calls = []
 
-    def net64(zt, t):
-        return oracle.dynamics_forward(sd64, cfg, zt, ei, t, cond.double(), nfs, cm, 1, nodeframe="exact")
-
     def dyn64(zt, t):
+        # the replay evaluates the network where the device evaluates it: on the float32 rounding of its (float64) state
+        z32 = [z.float() for z in zt]
+        t32 = t.float()
         st = {}
-        o = oracle.dynamics_forward(sd64, cfg, zt, ei, t, cond.double(), nfs, cm, 1, nodeframe="exact", stages=st)
-        calls.append(([z.clone() for z in zt], t.clone(), o, int(st["edge_mask"].sum())))
+        o = oracle.dynamics_forward(sd64, cfg, [z.double() for z in z32], ei, t32.double(), cond.double(), nfs, cm, 1, nodeframe="exact",
+                                    stages=st)
+        calls.append((z32, t32, o, int(st["edge_mask"].sum()), [z.clone() for z in zt]))
         c = smp.prior_coefficient(int(round(float(t.reshape(-1)[0]) * T)), T)          # the device loop's coefficient
         return [torch.cat([x[:, :3] + c * z[:, :3], x[:, 3:]], dim=1) for x, z in zip(o, zt)]
     torch.set_default_dtype(torch.float64)
@@ -145,24 +147,22 @@ def test_config1_single_reaction_t50_sampler():
     assert len(calls) == T + 1
     inner = int((nfs[ei[0]] == nfs[ei[1]]).sum())
     assert min(c[3] for c in calls) == inner, "the trajectory left the cutoff: the calls behind that point test nothing"
-    per_call, unrounded = [], []
-    for zt, t, o, _ in calls:                            # teacher-forced: the HIP network on the float64 trajectory's state
-        z32 = [z.float() for z in zt]
+    per_call, rounding = [], []
+    for z32, t32, o, _, zt in calls:                     # teacher-forced: the HIP network on the float64 trajectory's (rounded) state
         with torch.no_grad():
-            out, _ = dyn([z.to(dev) for z in z32], ei.to(dev), t.float().to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+            out, _ = dyn([z.to(dev) for z in z32], ei.to(dev), t32.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
         v = torch.cat([x[:, :3].cpu().double().reshape(-1) for x in out])
-        o_same = net64([z.double() for z in z32], t.float().double())                  # the oracle on the SAME float32 numbers
-        per_call.append(rel(v, torch.cat([x[:, :3].reshape(-1) for x in o_same])))
-        unrounded.append(rel(v, torch.cat([x[:, :3].reshape(-1) for x in o])))
+        per_call.append(rel(v, torch.cat([x[:, :3].reshape(-1) for x in o])))
+        rounding.append(max(rel(a.double(), b) for a, b in zip(z32, zt)))
     print(f"config 1: trajectory error {traj:.2e} over {T + 1} calls, {inner} of {inner} inner edges active in every call; per network "
           f"call on identical inputs max {max(per_call):.2e} median {sorted(per_call)[len(per_call) // 2]:.2e} "
-          f"(against the oracle on the unrounded float64 state: max {max(unrounded):.2e})")
-    # measured in round 6 (MI355X): worst call 3.5e-6 under the suite's launch shapes, 4.7e-6 under the library's defaults (OARD_TEST_SHAPES=auto);
-    # medians 1.9e-6 / 2.1e-6; plain torch float32 on the same inputs: worst 3.2e-6, median 1.4e-6.  Before the two accumulation fixes of
-    # round 6 (csrc/oard_node_v1.h: k_node_pre_v1, k_neighbor_v1): 6.0e-6 / 5.4e-6, medians 3.0e-6 / 3.4e-6.
-    assert max(per_call) <= TOL
-    assert sorted(per_call)[len(per_call) // 2] <= 4e-6      # the typical call has a factor of margin
-    assert max(unrounded) <= TOL
+          f"(float32 rounding of the state: {max(rounding):.1e} of its largest entry)")
+    # measured in round 6 (MI355X): worst call 2.53e-6 under the suite's launch shapes, 2.55e-6 under the library's defaults
+    # (OARD_TEST_SHAPES=auto); medians 1.41e-6 / 1.50e-6; plain torch float32 on the same inputs: worst 3.2e-6, median 1.4e-6.  On the way
+    # there: round-5 kernels 6.0e-6 / 5.4e-6 (medians 3.0e-6 / 3.4e-6); with the two accumulations of csrc/oard_node_v1.h summed on their
+    # own (k_node_pre_v1, k_neighbor_v1) 3.5e-6 / 4.7e-6; with the output head's update_net / vec2_proj in float64 (k_out_v1) the above.
+    assert max(per_call) <= 5e-6                             # the hard bar is TOL = 1e-5: gated with a factor of two of margin
+    assert sorted(per_call)[len(per_call) // 2] <= 3e-6
     assert traj <= 5e-5
 
 
