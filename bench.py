@@ -190,7 +190,7 @@ def train_leg(dyn, B, nf, dev, dist, world, steps, warmup, timing=True):
     # host_sync=False: the clip / skip decision and AdamW's scalars are taken on the device (oard_adamw_step_dev), so the timed steps
     # contain no device -> host read; the returned info is fetched after the timed region.  OARD_BENCH_HOST_SYNC=1: the host decides.
     tr = DDPMTrainer(dyn, timesteps=1000, norm_values=(1.0, 4.0, 10.0), scales=(1.0, 2.0, 1.0), pos_only=True,
-                     host_sync=bool(os.environ.get("OARD_BENCH_HOST_SYNC")))
+                     host_sync=bool(os.environ.get("OARD_BENCH_HOST_SYNC")), microbatches=int(os.environ.get("OARD_BENCH_MICROBATCHES", "1")))
     # every step a batch the trainer has never seen (new tensors: its layout caches miss, a topology is built and dropped per step), as in
     # a real run over a dataset; OARD_BENCH_CACHED_BATCHES=1: two alternating batches whose layouts stay cached (rounds 2-3 measured that)
     n_b = 2 if os.environ.get("OARD_BENCH_CACHED_BATCHES") else warmup + steps

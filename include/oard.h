@@ -425,6 +425,13 @@ int oard_adamw_step_dev(float* param_dev, const float* grad_dev, float* exp_avg_
                         double* clip_state_dev, int capacity, const float* grad_norm_dev, const float* flag_dev, float* out4_dev,
                         oard_stream_t stream);
 
+/* The library's own streams of the current device (three non-blocking streams, chosen once per device so that each runs on a hardware
+ * queue of its own beside the caller's stream - the runtime serves a process's streams from 4 queues): 0 = the training sweep's
+ * gradient stream (and the second sub-batch of a multi-part forward), 1 = the third sub-batch, 2 = topology uploads (and the fourth).
+ * For callers that want a second in-order queue WITHOUT adding a fifth stream to the process: DDPMTrainer's two-micro-batch step runs
+ * its second micro-batch on stream 1, which is idle in training.  No counterpart in the reference. */
+int oard_library_stream(int which, oard_stream_t* out);
+
 /* ---- general edge lists (round 6) --------------------------------------------------------------------------------------------
  * Replaces: EGNNDynamics.forward on an edge_index that is NOT the complete graph per sample.  The reference accepts any edge list
  * (dynamics/egnn_dynamics.py:63-72), builds incomplete ones with get_edges_index(..., edge_cutoff=) (utils/_graph_tools.py:31-33, plumbed

@@ -28,7 +28,7 @@ EXPORTS = ["oard_version", "oard_supported", "oard_param_count", "oard_packed_by
            "oard_train_layer_backward", "oard_train_init_backward", "oard_train_stage_backward",
            "oard_loss_prepare", "oard_loss_terms", "oard_adamw_step", "oard_adamw_step_dev", "oard_nan_replace",
            "oard_graph_create", "oard_graph_destroy", "oard_graph_num_nodes", "oard_graph_num_edges", "oard_graph_object_rows",
-           "oard_graph_is_complete", "oard_graph_workspace_bytes", "oard_graph_forward"]
+           "oard_graph_is_complete", "oard_graph_workspace_bytes", "oard_graph_forward", "oard_library_stream"]
 STAGE_RECOMPUTE, STAGE_UPDATE, STAGE_MESSAGE, STAGE_GCL_NODE, STAGE_NODE_PRE, STAGE_GCL_EDGE, STAGE_EQUI_EDGE = range(7)
 SCRATCH_XH, SCRATCH_XQ, SCRATCH_CR, SCRATCH_DCD, SCRATCH_DCR = range(1, 6)
 
@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
     cd = C.c_double
     L.oard_adamw_step.argtypes = [vp, vp, vp, vp, vp, i64, cd, cd, cd, cd, cd, i64, ci, cd, vp]; L.oard_adamw_step.restype = ci
     L.oard_adamw_step_dev.argtypes = [vp, vp, vp, vp, vp, i64, cd, cd, cd, cd, cd, ci, ci, vp, ci, vp, vp, vp, vp]; L.oard_adamw_step_dev.restype = ci
+    L.oard_library_stream.argtypes = [ci, pvp]; L.oard_library_stream.restype = ci
     # general edge lists (csrc/oard_general.hip)
     L.oard_graph_create.argtypes = [cfgp, vp, vp, i64, vp, i64, pvp]; L.oard_graph_create.restype = ci
     L.oard_graph_destroy.argtypes = [vp]; L.oard_graph_destroy.restype = None

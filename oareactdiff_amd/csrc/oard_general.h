@@ -153,7 +153,8 @@ inline Workspace carve(const oard_config* c, int64_t N, int64_t E, int64_t G, ch
 G_HD float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 // ---- the one dense layer: Y[row][o] = post(act(sum_seg sum_k X_seg[idx_seg[row]][k] W[o][koff_seg + k] + bias[o])) -------------------
-// One thread per (group of 4 rows, output); float64 accumulation.  Up to three input segments = torch.cat([...], dim=1) of gathered rows.
+// One thread per (4 rows, 4 outputs): every loaded weight serves four rows, every loaded input four outputs; float64 accumulation.
+// Up to three input segments = torch.cat([...], dim=1) of gathered rows.
 struct Seg { const float* x; int ld; int K; const int32_t* idx; };
 struct Gemm {
     long long rows; int nout; Seg seg[3]; int nseg;
@@ -162,12 +163,16 @@ struct Gemm {
     int mode;                                       // 0: Y = v   1: Y += v   2: Y = resid + v
     const float* resid; int ldr;
     const float* rowscale;                          // optional: v *= rowscale[row] (after the activation)
-    long long threads() const { return ((rows + 3) / 4) * (long long)nout; }
+    int ogroups() const { return (nout + 3) / 4; }
+    long long threads() const { return ((rows + 3) / 4) * (long long)ogroups(); }
     G_HD void operator()(long long tid) const {
-        const long long rg = tid / nout;
-        const int o = (int)(tid - rg * nout);
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        const float* w = W + (size_t)o * ldw;
+        const int og = (nout + 3) / 4;
+        const long long rg = tid / og;
+        const int o0 = (int)(tid - rg * og) * 4;
+        double acc[4][4];
+        for (int r = 0; r < 4; ++r) for (int q = 0; q < 4; ++q) acc[r][q] = 0.0;
+        const float* w[4];
+        for (int q = 0; q < 4; ++q) w[q] = W + (size_t)(o0 + q < nout ? o0 + q : nout - 1) * ldw;
         int koff = 0;
         for (int sgi = 0; sgi < nseg; ++sgi) {
             const Seg sg = seg[sgi];
@@ -179,22 +184,28 @@ struct Gemm {
                 xr[r] = sg.x + (size_t)src * sg.ld;
             }
             for (int k = 0; k < sg.K; ++k) {
-                const double wk = (double)w[koff + k];
-                acc[0] += (double)xr[0][k] * wk; acc[1] += (double)xr[1][k] * wk;
-                acc[2] += (double)xr[2][k] * wk; acc[3] += (double)xr[3][k] * wk;
+                const double x0 = xr[0][k], x1 = xr[1][k], x2 = xr[2][k], x3 = xr[3][k];
+                for (int q = 0; q < 4; ++q) {
+                    const double wk = (double)w[q][koff + k];
+                    acc[0][q] += x0 * wk; acc[1][q] += x1 * wk; acc[2][q] += x2 * wk; acc[3][q] += x3 * wk;
+                }
             }
             koff += sg.K;
         }
         for (int r = 0; r < 4; ++r) {
             const long long row = rg * 4 + r;
             if (row >= rows) break;
-            float v = (float)(acc[r] + (bias ? (double)bias[o] : 0.0));
-            if (act) v = silu_f(v);
-            if (rowscale) v *= rowscale[row];
-            float* y = Y + (size_t)row * ldy + o;
-            if (mode == 1) v = *y + v;
-            else if (mode == 2) v = resid[(size_t)row * ldr + o] + v;
-            *y = v;
+            for (int q = 0; q < 4; ++q) {
+                const int o = o0 + q;
+                if (o >= nout) break;
+                float v = (float)(acc[r][q] + (bias ? (double)bias[o] : 0.0));
+                if (act) v = silu_f(v);
+                if (rowscale) v *= rowscale[row];
+                float* y = Y + (size_t)row * ldy + o;
+                if (mode == 1) v = *y + v;
+                else if (mode == 2) v = resid[(size_t)row * ldr + o] + v;
+                *y = v;
+            }
         }
     }
 };

@@ -1090,6 +1090,12 @@ static hipStream_t* device_streams() {
     return all[d];
 }
 
+extern "C" int oard_library_stream(int which, oard_stream_t* out) {
+    if (!out || which < 0 || which > 2) return OARD_EINVAL;
+    *out = (oard_stream_t)device_streams()[which];
+    return OARD_OK;
+}
+
 // ---- table pool (round 4) ---------------------------------------------------------------------------------------------------------------
 // Training sees a new batch layout every step, so a topology is built and dropped per step.  hipMalloc / blocking hipMemcpy on the null
 // stream / hipFree each wait for the device - a pipeline drain per step (measured: + 18 ms on a 68-ms step).  Instead: device blocks and

@@ -21,6 +21,7 @@ left out of the bucket and never get a gradient, as in the reference.
 from __future__ import annotations
 
 import copy
+import contextlib
 import math
 import os
 from collections.abc import Mapping
@@ -98,13 +99,24 @@ class DDPMTrainer:
                  norm_biases: Sequence[float] = (0.0, 0.0, 0.0), loss_type: str = "l2", pos_only: bool = False,
                  scales: Sequence[float] = (1.0, 1.0, 1.0), fixed_idx: Optional[List[int]] = None,
                  optimizer_config: Optional[Dict] = None, clip_grad: bool = True,
-                 process_group: Optional["dist.ProcessGroup"] = None, fused: Optional[bool] = None, host_sync: bool = True):
-        """`host_sync=False` (fused steps only): the adaptive-clipping decision, the skip decision and AdamW's step-dependent scalars
+                 process_group: Optional["dist.ProcessGroup"] = None, fused: Optional[bool] = None, host_sync: bool = True,
+                 microbatches: int = 1):
+        """`microbatches=2` (fused steps on batches that carry their host copies, `to_device`): the step's reactions are dealt to two
+        halves that run their forward and their reverse sweep CONCURRENTLY on two streams (the caller's and the library's idle
+        sub-batch stream), each with its own tape / workspace / scratch and its own gradient buffer, summed before the all-reduce.
+        Same loss, same gradient up to the order of one addition; the low-occupancy node-side launches of one half then run beside
+        the other half's edge kernels instead of alone on the chip (round 6).
+
+        `host_sync=False` (fused steps only): the adaptive-clipping decision, the skip decision and AdamW's step-dependent scalars
         are evaluated on the device (`oard_adamw_step_dev`), so a training step contains NO device -> host read; `training_step`
         then returns a `LazyInfo` whose values are fetched when they are first looked at.  Arithmetic and state are the same as with
         `host_sync=True` (the clipping history is summed in numpy's order); the clipping / skip messages are not printed."""
         self.dynamics = dynamics
         self.host_sync = bool(host_sync)
+        if int(microbatches) not in (1, 2):
+            raise ValueError("microbatches must be 1 or 2")
+        self.microbatches = int(microbatches)
+        self._mb = None                                # second micro-batch: stream, gradient buffer, the module's per-call buffers
         self._clip_state = None                        # device mirror of (history, opt_step, skipped_steps) while host_sync is off
         self.loss = DiffusionLoss(dynamics, noise_schedule, timesteps, precision, norm_values=norm_values,
                                   norm_biases=norm_biases, pos_only=pos_only, fixed_idx=fixed_idx, loss_type=loss_type,
@@ -324,9 +336,91 @@ class DDPMTrainer:
         return grad_norm, max_grad_norm
 
     # ---- fused step (HIP module): no autograd graph, ~20 launches around the network call ----------------------------------------
+    def _fused_part(self, cfg, packed, reps, cond, t_int: Tensor, noise: List[Tensor], counts: List[int], host_masks, host_sizes,
+                    terms: Tensor, col0: int):
+        """One (micro-)batch on the CURRENT stream: oard_loss_prepare -> oard_forward_train -> oard_loss_terms.  `terms` [2K, B_total]: the
+        step's logged terms; this part owns columns [col0, col0 + B) (oard_loss_terms takes B_total both as the row stride of `terms` and
+        as the 1 / B of the mean nll).  -> (nll [B], d(mean nll)/d(net), TrainState)."""
+        import ctypes as C
+        from . import _capi
+        dyn, ls = self.dynamics, self.loss
+        dev = self.flat_grad.device
+        K = len(reps)
+        L = _capi.lib()
+        # the layout: from the batch's HOST copies of mask / size when the loader kept them (to_device) - no device -> host copy, i.e. no
+        # wait for the work queued on the stream; otherwise from the device tensors.  No edge list either way (the kernels walk the
+        # implicit complete graph; a caller-supplied edge_index only exists on dynamics.forward's path, where it is verified).
+        combined_mask, _, n_frag_switch = ls._layout(host_masks, host_sizes, need_edges=False)
+        B = int(t_int.numel())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        topo = dyn._get_train_topology(cfg, None, n_frag_switch, combined_mask, stream, device=dev)
+        nfs = list(dyn.node_nfs)
+        gamma = self._gamma_dev
+        if gamma is None or gamma.device != dev:
+            gamma = self._gamma_dev = ls.schedule.gamma.to(device=dev, dtype=torch.float32).contiguous()
+        pos = [r["pos"].detach().to(torch.float32).contiguous() for r in reps]
+        one_hot = [r["one_hot"].detach().to(torch.int64).contiguous() for r in reps]
+        charge = [r["charge"].detach().to(torch.int64).contiguous() for r in reps]
+        z = [torch.empty(counts[k], nfs[k], device=dev) for k in range(K)]
+        eps = [torch.empty_like(x) for x in z]
+        arr = lambda ts: (C.c_void_p * K)(*[t.data_ptr() for t in ts])      # noqa: E731
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])              # noqa: E731
+        nv, nb = f3(ls.norm_values), f3(ls.norm_biases)
+        sc = (C.c_float * K)(*[float(x) for x in ls.scales[:K]])
+        fixed_mask = sum(1 << int(k) for k in ls.fixed_idx)
+        _capi.check(L.oard_loss_prepare(C.byref(cfg), topo.handle, arr(pos), arr(one_hot), arr(charge), arr(noise), t_int.data_ptr(),
+                                        gamma.data_ptr(), ls.T, nv, nb, 1 if ls.pos_only else 0, fixed_mask, arr(z), arr(eps), stream),
+                    "oard_loss_prepare")
+        t = (t_int / ls.T).view(B, 1)
+        xs, tt, t_scalar, cnd = dyn._train_inputs(topo, z, t, cond, dev)
+        net, state = dyn._run_forward_train(cfg, topo, packed, xs, tt, t_scalar, cnd, stream, reuse_tape=True)
+        nll = torch.empty(B, device=dev)
+        dnet = [torch.empty_like(o) for o in net]
+        B_total = int(terms.shape[1])
+        _capi.check(L.oard_loss_terms(C.byref(cfg), topo.handle, arr(eps), arr(net), arr(z), arr(one_hot), arr(charge), t_int.data_ptr(),
+                                      gamma.data_ptr(), ls.T, nv, nb, sc, 1 if ls.pos_only else 0, B_total, nll.data_ptr(),
+                                      terms.data_ptr() + 4 * col0, arr(dnet), stream), "oard_loss_terms")
+        state.keep_inputs = (pos, one_hot, charge, z, eps, net, t_int, noise)      # the launches above are asynchronous
+        return nll, dnet, state
+
+    def _second_slot(self, dev):
+        """State of the second micro-batch: the library's idle sub-batch stream (no fifth stream in the process: the runtime serves a
+        process's streams from 4 hardware queues), a gradient buffer with the bucket's layout, and the module's per-call buffers."""
+        if self._mb is None or self._mb["device"] != dev:
+            import ctypes as C
+            from . import _capi
+            h = C.c_void_p()
+            with torch.cuda.device(dev):
+                _capi.check(_capi.lib().oard_library_stream(1, C.byref(h)), "oard_library_stream")
+            grad2 = torch.zeros_like(self.flat_grad)
+            dests2, off = {}, 0
+            for p in self.params:
+                dests2[id(p)] = grad2[off: off + p.numel()].view_as(p)
+                off += p.numel()
+            self._mb = {"device": dev, "stream": torch.cuda.ExternalStream(h.value, device=dev), "grad": grad2, "dests": dests2, "buffers": {}}
+        return self._mb
+
+    @contextlib.contextmanager
+    def _slot(self, i: int):
+        """The module's per-call buffers (workspace, tape, sweep scratch, NaN flag) of micro-batch i: the second one has its own."""
+        if i == 0:
+            yield
+            return
+        dyn, names = self.dynamics, ("_ws", "_tape_buf", "_train_scratch", "nan_seen")
+        saved = {n: getattr(dyn, n, None) for n in names}
+        store = self._mb["buffers"]
+        for n in names:
+            setattr(dyn, n, store.get(n))
+        try:
+            yield
+        finally:
+            for n in names:
+                store[n] = getattr(dyn, n, None)
+                setattr(dyn, n, saved[n])
+
     def _fused_forward_backward(self, batch, t_int: Optional[Tensor] = None, draw=None):
         """loss terms + gradients into the bucket: oard_loss_prepare -> oard_forward_train -> oard_loss_terms -> the backward sweep
-        (training.backward_sweep) fed with the closed-form d(mean nll)/d(net).  Returns (nll [B], terms [2K, B]) on the device.
+        (training.Sweep) fed with the closed-form d(mean nll)/d(net).  Returns (nll [B], terms [2K, B]) on the device.
         Injected draws (`draw`) follow DiffusionLoss's protocol (per object: randn(n, 3) then randn(n, nf - 3)); the default is ONE
         device randn for the whole step's noise (same distribution, one launch instead of nine)."""
         import ctypes as C
@@ -337,20 +431,13 @@ class DDPMTrainer:
         K = len(reps)
         L = _capi.lib()
         masks, sizes = [r["mask"] for r in reps], [r["size"] for r in reps]
-        # the layout: from the batch's HOST copies of mask / size when the loader kept them (to_device) - no device -> host copy, i.e. no
-        # wait for the work queued on the stream; otherwise from the device tensors.  No edge list either way (the kernels walk the
-        # implicit complete graph; a caller-supplied edge_index only exists on dynamics.forward's path, where it is verified).
-        if all("mask_host" in r and "size_host" in r for r in reps):
-            combined_mask, _, n_frag_switch = ls._layout([r["mask_host"] for r in reps], [r["size_host"] for r in reps], need_edges=False)
-        else:
-            combined_mask, _, n_frag_switch = ls._layout(masks, sizes, need_edges=False)
+        have_host = all("mask_host" in r and "size_host" in r for r in reps)
         B = int(sizes[0].numel())
         with torch.cuda.device(dev), torch.no_grad():
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            main = torch.cuda.current_stream(dev)
             cfg = dyn._config()
             _capi.check(L.oard_supported(C.byref(cfg)), "oard_supported (hidden_channels/num_radial not built)")
-            packed = dyn._get_packed(cfg, stream)
-            topo = dyn._get_train_topology(cfg, None, n_frag_switch, combined_mask, stream, device=dev)
+            packed = dyn._get_packed(cfg, main.cuda_stream)
             nfs = list(dyn.node_nfs)
             if t_int is None:
                 t_int = torch.randint(0, ls.T + 1, size=(B, 1), device=dev).float()
@@ -364,34 +451,61 @@ class DDPMTrainer:
                     off += c * f
             else:                                     # injected draws follow DiffusionLoss's protocol: (n, 3) then (n, nf - 3) per object
                 noise = [torch.cat([draw((c, 3)).float(), draw((c, f - 3)).float()], dim=1).contiguous() for c, f in zip(counts, nfs)]
-            gamma = self._gamma_dev
-            if gamma is None or gamma.device != dev:
-                gamma = self._gamma_dev = ls.schedule.gamma.to(device=dev, dtype=torch.float32).contiguous()
-            pos = [r["pos"].detach().to(torch.float32).contiguous() for r in reps]
-            one_hot = [r["one_hot"].detach().to(torch.int64).contiguous() for r in reps]
-            charge = [r["charge"].detach().to(torch.int64).contiguous() for r in reps]
-            z = [torch.empty(int(m.numel()), nfs[k], device=dev) for k, m in enumerate(masks)]
-            eps = [torch.empty_like(x) for x in z]
-            arr = lambda ts: (C.c_void_p * K)(*[t.data_ptr() for t in ts])      # noqa: E731
-            f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])              # noqa: E731
-            nv, nb = f3(ls.norm_values), f3(ls.norm_biases)
-            sc = (C.c_float * K)(*[float(x) for x in ls.scales[:K]])
-            fixed_mask = sum(1 << int(k) for k in ls.fixed_idx)
-            _capi.check(L.oard_loss_prepare(C.byref(cfg), topo.handle, arr(pos), arr(one_hot), arr(charge), arr(noise), t_int.data_ptr(),
-                                            gamma.data_ptr(), ls.T, nv, nb, 1 if ls.pos_only else 0, fixed_mask, arr(z), arr(eps), stream),
-                        "oard_loss_prepare")
-            t = (t_int / ls.T).view(B, 1)
-            xs, tt, t_scalar, cnd = dyn._train_inputs(topo, z, t, cond, dev)
-            net, state = dyn._run_forward_train(cfg, topo, packed, xs, tt, t_scalar, cnd, stream, reuse_tape=True)
-            nll = torch.empty(B, device=dev)
-            terms = torch.empty(2 * K, B, device=dev)
-            dnet = [torch.empty_like(o) for o in net]
-            _capi.check(L.oard_loss_terms(C.byref(cfg), topo.handle, arr(eps), arr(net), arr(z), arr(one_hot), arr(charge), t_int.data_ptr(),
-                                          gamma.data_ptr(), ls.T, nv, nb, sc, 1 if ls.pos_only else 0, B, nll.data_ptr(), terms.data_ptr(),
-                                          arr(dnet), stream), "oard_loss_terms")
             dests = {id(p): p.grad for p in self.params}
-            training.backward_sweep(dyn, state, dnet, stream, dests)
+            terms = torch.empty(2 * K, B, device=dev)
+            if self.microbatches == 2 and have_host and B >= 2:
+                return self._fused_two(cfg, packed, reps, cond, t_int, noise, B, dests, main, terms)
+            hm = [r["mask_host"] for r in reps] if have_host else masks
+            hs = [r["size_host"] for r in reps] if have_host else sizes
+            nll, dnet, state = self._fused_part(cfg, packed, reps, cond, t_int, noise, counts, hm, hs, terms, 0)
+            training.backward_sweep(dyn, state, dnet, main.cuda_stream, dests)
         return nll, terms
+
+    def _fused_two(self, cfg, packed, reps, cond, t_int, noise, B: int, dests, main, terms):
+        """The step as two micro-batches (reactions [0, h) and [h, B)) on two streams; see `microbatches` in __init__."""
+        from . import training
+        dyn = self.dynamics
+        dev = self.flat_grad.device
+        mb = self._second_slot(dev)
+        side = mb["stream"]
+        K = len(reps)
+        h = B // 2
+        n0 = [int(r["size_host"][:h].sum()) for r in reps]                 # rows of the first half per object (host arithmetic)
+        halves = []
+        for lo, hi, first in ((0, h, True), (h, B, False)):
+            rp, hm, hs, cn = [], [], [], []
+            for k, r in enumerate(reps):
+                a, b = (0, n0[k]) if first else (n0[k], int(r["mask_host"].numel()))
+                rp.append({"pos": r["pos"][a:b], "one_hot": r["one_hot"][a:b], "charge": r["charge"][a:b]})
+                hm.append(r["mask_host"][a:b] - lo)
+                hs.append(r["size_host"][lo:hi])
+                cn.append(b - a)
+            nz = [x[(0 if first else n0[k]): (n0[k] if first else x.shape[0])] for k, x in enumerate(noise)]
+            cd = cond[lo:hi] if isinstance(cond, Tensor) else cond
+            halves.append((rp, cd, t_int[lo:hi], nz, cn, hm, hs, terms, lo))
+        dyn._get_packed_bwd(cfg, main.cuda_stream)             # both packs on the caller's stream BEFORE the fork (the second half reads them)
+        mb["grad"].zero_()
+        if mb["buffers"].get("nan_seen") is not None:
+            mb["buffers"]["nan_seen"].zero_()
+        side.wait_stream(main)
+        with torch.cuda.stream(side), self._slot(1):
+            nll1, dnet1, st1 = self._fused_part(cfg, packed, *halves[1])
+        nll0, dnet0, st0 = self._fused_part(cfg, packed, *halves[0])
+        with torch.cuda.stream(side), self._slot(1):
+            sw1 = training.Sweep(dyn, st1, dnet1, side.cuda_stream, mb["dests"])
+        sw0 = training.Sweep(dyn, st0, dnet0, main.cuda_stream, dests)
+        # the two sweeps step by step: the library's gradient stream then sees their weight-gradient work alternately
+        steps = [("tail",)] + [("layer", l) for l in reversed(range(sw0.NL))] + [("init",)]
+        for st in steps:
+            with torch.cuda.stream(side), self._slot(1):
+                getattr(sw1, st[0])(*st[1:])
+            getattr(sw0, st[0])(*st[1:])
+        main.wait_stream(side)
+        self.flat_grad.add_(mb["grad"])
+        seen1 = mb["buffers"].get("nan_seen")
+        if seen1 is not None and dyn.nan_seen is not None:
+            dyn.nan_seen.bitwise_or_(seen1)
+        return torch.cat([nll0, nll1]), terms
 
     def _fused_step(self, batch, **kw) -> Dict[str, float]:
         import ctypes as C  # noqa: F401

@@ -201,6 +201,79 @@ def gradient_table(dyn, dests: Dict[int, Tensor]):
     return (C.c_void_p * len(ptrs))(*ptrs)
 
 
+class Sweep:
+    """The reverse sweep of one training-mode forward as L + 2 separately issued steps (`tail`, `layer(l)` for l = L-1 .. 0, `init`), all
+    asynchronous on `stream`.  `backward_sweep` issues them back to back; DDPMTrainer's two-micro-batch step interleaves the steps of two
+    sweeps that run on two streams, so that the library's gradient stream sees their weight-gradient work alternately (one sweep issued
+    as a whole would park the other's weight gradients - and with them its cotangent chain, which waits for the scratch buffers they
+    read - behind all of its own).
+    `dests` (id(param) -> tensor): accumulate INTO these tensors (e.g. the `.grad` views of a flat bucket); None: accumulate into a fresh
+    zero-filled flat buffer, `self.out` = {canonical name: view}.  `scratch`: a uint8 buffer of at least oard_train_scratch_bytes, or None
+    (then `dyn._train_scratch`, grown on demand)."""
+
+    def __init__(self, dyn, st: TrainState, grad_outs: List[Optional[Tensor]], stream: int, dests: Optional[Dict[int, Tensor]] = None):
+        L = _capi.lib()
+        self.L, self.st, self.stream = L, st, stream
+        cfg, topo, tape = st.cfg, st.topo, st.tape
+        H, R, NL, Cc = dyn._dims
+        HP, WP = _pad16(H), _pad16(3 * H + R)
+        N, E = topo.N, topo.E
+        dev = st.xh[0].device
+        n_obj = len(dyn.node_nfs)
+        packed, pbwd = dyn._get_packed(cfg, stream), dyn._get_packed_bwd(cfg, stream)
+        need = L.oard_train_scratch_bytes(C.byref(cfg), topo.handle)
+        sc = getattr(dyn, "_train_scratch", None)
+        if sc is None or sc.numel() < need or sc.device != dev:
+            sc = torch.empty(need, dtype=torch.uint8, device=dev)
+            dyn._train_scratch = sc
+        self.out: Dict[str, Tensor] = {}
+        if dests is None:
+            names = dyn._param_names()
+            P = dyn._param_dict()
+            used = [n for n in names if not n.startswith(UNUSED_PREFIXES)]
+            flat = torch.zeros(sum(P[n].numel() for n in used), dtype=torch.float32, device=dev)
+            dests, off = {}, 0
+            for n in used:
+                p = P[n]
+                self.out[n] = flat[off: off + p.numel()].view_as(p)
+                dests[id(p)] = self.out[n]
+                off += p.numel()
+        tensors = dyn._ordered_tensors()
+        self.params = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        self.grads = gradient_table(dyn, dests)
+        gos = []
+        for k in range(n_obj):
+            g = grad_outs[k] if k < len(grad_outs) else None
+            gos.append(None if g is None else g.to(torch.float32).contiguous())
+        self.go = (C.c_void_p * n_obj)(*[g.data_ptr() if g is not None else None for g in gos])
+        self.xhp = (C.c_void_p * n_obj)(*[x.data_ptr() for x in st.xh])
+        ds = torch.empty(N, HP, device=dev)
+        dvec = torch.empty(3 * N, HP, device=dev)
+        # cotangent of the edge state, updated in place layer by layer.  Nothing flows into the FINAL edge state: the last layer's kernels
+        # read the inner rows [0, A) as that zero gradient (and the spare row E for their padding columns) and never read the inter-object
+        # rows (their S3 was skipped in the forward), so only those rows are cleared - 0.27 GB instead of 0.83 GB at B = 64
+        dew = torch.empty(E + 1, WP, device=dev)
+        dew[: topo.A].zero_()
+        dew[E:].zero_()
+        self.ds, self.dvec, self.dew, self.sc, self.NL = ds, dvec, dew, sc, NL
+        self.a = (C.byref(cfg), topo.handle, packed.data_ptr(), pbwd.data_ptr(), tape.buf.data_ptr())
+        self._keep = (cfg, packed, pbwd, tensors, dests, gos)       # the launches are asynchronous
+        st.keepalive = (gos, ds, dvec, dew)
+
+    def tail(self):
+        _capi.check(self.L.oard_train_tail_backward(*self.a, self.go, self.ds.data_ptr(), self.dvec.data_ptr(), self.params, self.grads,
+                                                    self.sc.data_ptr(), self.sc.numel(), self.stream), "oard_train_tail_backward")
+
+    def layer(self, l: int):
+        _capi.check(self.L.oard_train_layer_backward(*self.a, l, self.ds.data_ptr(), self.dvec.data_ptr(), self.dew.data_ptr(), self.params,
+                                                     self.grads, self.sc.data_ptr(), self.sc.numel(), self.stream),
+                    "oard_train_layer_backward")
+
+    def init(self):
+        _capi.check(self.L.oard_train_init_backward(*self.a, self.xhp, self.ds.data_ptr(), self.dew.data_ptr(), self.params, self.grads,
+                                                    self.sc.data_ptr(), self.sc.numel(), self.stream), "oard_train_init_backward")
+
+
 def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], stream: int,
                    dests: Optional[Dict[int, Tensor]] = None) -> Dict[str, Tensor]:
     """d(loss)/d(parameter) for every parameter the forward uses, given d(loss)/d(out[k]).
@@ -208,62 +281,16 @@ def backward_sweep(dyn, st: TrainState, grad_outs: List[Optional[Tensor]], strea
     None: accumulate into a fresh zero-filled flat buffer and return {canonical name: view}."""
     tm = _StageTimer()
     tm.mark("start")
-    L = _capi.lib()
-    cfg, topo, tape = st.cfg, st.topo, st.tape
-    H, R, NL, Cc = dyn._dims
-    HP, WP = _pad16(H), _pad16(3 * H + R)
-    N, E = topo.N, topo.E
-    dev = st.xh[0].device
-    n_obj = len(dyn.node_nfs)
-    packed, pbwd = dyn._get_packed(cfg, stream), dyn._get_packed_bwd(cfg, stream)
-    need = L.oard_train_scratch_bytes(C.byref(cfg), topo.handle)
-    sc = getattr(dyn, "_train_scratch", None)
-    if sc is None or sc.numel() < need or sc.device != dev:
-        sc = torch.empty(need, dtype=torch.uint8, device=dev)
-        dyn._train_scratch = sc
-    out: Dict[str, Tensor] = {}
-    if dests is None:
-        names = dyn._param_names()
-        P = dyn._param_dict()
-        used = [n for n in names if not n.startswith(UNUSED_PREFIXES)]
-        flat = torch.zeros(sum(P[n].numel() for n in used), dtype=torch.float32, device=dev)
-        dests, off = {}, 0
-        for n in used:
-            p = P[n]
-            out[n] = flat[off: off + p.numel()].view_as(p)
-            dests[id(p)] = out[n]
-            off += p.numel()
-    tensors = dyn._ordered_tensors()
-    params = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
-    grads = gradient_table(dyn, dests)
-    gos = []
-    for k in range(n_obj):
-        g = grad_outs[k] if k < len(grad_outs) else None
-        gos.append(None if g is None else g.to(torch.float32).contiguous())
-    go = (C.c_void_p * n_obj)(*[g.data_ptr() if g is not None else None for g in gos])
-    xhp = (C.c_void_p * n_obj)(*[x.data_ptr() for x in st.xh])
-    ds = torch.empty(N, HP, device=dev)
-    dvec = torch.empty(3 * N, HP, device=dev)
-    # cotangent of the edge state, updated in place layer by layer.  Nothing flows into the FINAL edge state: the last layer's kernels
-    # read the inner rows [0, A) as that zero gradient (and the spare row E for their padding columns) and never read the inter-object
-    # rows (their S3 was skipped in the forward), so only those rows are cleared - 0.27 GB instead of 0.83 GB at B = 64
-    dew = torch.empty(E + 1, WP, device=dev)
-    dew[: topo.A].zero_()
-    dew[E:].zero_()
-    a = (C.byref(cfg), topo.handle, packed.data_ptr(), pbwd.data_ptr(), tape.buf.data_ptr())
-    _capi.check(L.oard_train_tail_backward(*a, go, ds.data_ptr(), dvec.data_ptr(), params, grads, sc.data_ptr(), sc.numel(), stream),
-                "oard_train_tail_backward")
+    sw = Sweep(dyn, st, grad_outs, stream, dests)
+    sw.tail()
     tm.mark("tail")
-    for l in reversed(range(NL)):
-        _capi.check(L.oard_train_layer_backward(*a, l, ds.data_ptr(), dvec.data_ptr(), dew.data_ptr(), params, grads, sc.data_ptr(),
-                                                sc.numel(), stream), "oard_train_layer_backward")
+    for l in reversed(range(sw.NL)):
+        sw.layer(l)
         tm.mark("layers")
-    _capi.check(L.oard_train_init_backward(*a, xhp, ds.data_ptr(), dew.data_ptr(), params, grads, sc.data_ptr(), sc.numel(), stream),
-                "oard_train_init_backward")
+    sw.init()
     tm.mark("init")
     tm.report()
-    st.keepalive = (gos, ds, dvec, dew)                     # the launches above are asynchronous
-    return out
+    return sw.out
 
 
 class DynamicsFunction(torch.autograd.Function):

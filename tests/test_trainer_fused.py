@@ -293,3 +293,51 @@ def test_fused_true_is_refused_where_the_fused_kernels_do_not_apply():
     dyn = EGNNDynamics(model_config=dict(c.cfg), fragment_names=["R", "TS", "P"], node_nfs=NODE_NFS, edge_nf=0, condition_nf=CNF, device=dev)
     with pytest.raises(ValueError):
         DDPMTrainer(dyn, timesteps=c.meta["T"], loss_type="vlb", fused=True)
+
+
+@pytest.mark.parametrize("name,pos_only", [("g9_grad_prod_l2", False), ("g9_grad_prod_n23", True)])
+def test_two_microbatches_give_the_step_of_one(name, pos_only):
+    """`DDPMTrainer(microbatches=2)` (round 6): the step's reactions as two halves on two streams - own tape / workspace / scratch and
+    gradient buffer per half, the two sweeps issued step by step - against the one-batch step on the same recorded randomness: the same
+    per-sample nll and gradient up to summation order, the same weights after the optimiser step; run twice, the two-stream step is
+    bit-identical to itself."""
+    from oareactdiff_amd.trainer import DDPMTrainer
+    c = GradCase(name)
+    dev = torch.device("cuda:0")
+    B = len(c.meta["sizes"])
+    assert B >= 2
+    t_int = torch.tensor(c.meta["t_int"], dtype=torch.float32, device=dev).view(-1, 1)
+
+    def draws():
+        it = iter(range(c.meta["n_randn"]))
+        return lambda shape: torch.from_numpy(c.z[f"randn{next(it)}"]).to(dev)
+
+    def batch():
+        return DDPMTrainer.to_device((c.reps(torch.float32, "cpu"), torch.zeros(B, 1)), dev, non_blocking=False)
+    res = {}
+    for key, mb in (("one", 1), ("two", 2), ("two again", 2)):
+        tr = _trainer(c, dev, True, pos_only, microbatches=mb)
+        tr._bucket.zero_()
+        nll, terms = tr._fused_forward_backward(batch(), t_int=t_int, draw=draws())
+        torch.cuda.synchronize()
+        res[key] = (nll.clone(), terms.clone(), tr.flat_grad.clone())
+        assert (mb == 2) == (tr._mb is not None)
+    # (every reaction's forward is its own, but a half-size launch may pick other node-stage shapes: last bits, not bit-identity)
+    assert float(((res["one"][0] - res["two"][0]).abs() / res["one"][0].abs().clamp(min=1e-6)).max()) <= 2e-6
+    assert float((res["one"][1] - res["two"][1]).abs().max()) <= 2e-6 * max(1.0, float(res["one"][1].abs().max()))
+    g1, g2 = res["one"][2], res["two"][2]
+    gd = float((g2 - g1).norm() / g1.norm())
+    gmax = float((g2 - g1).abs().max() / g1.abs().max())
+    print(f"{name}: two micro-batches vs one: gradient |d|_2/|g|_2 {gd:.2e}, max|d|/max|g| {gmax:.2e}")
+    assert gd <= 1e-6 and gmax <= 1e-6
+    for a, b in zip(res["two"], res["two again"]):
+        assert torch.equal(a, b)
+    # whole steps (no host sync, fresh batch objects): the weights after three steps agree
+    w = {}
+    for mb in (1, 2):
+        tr = _trainer(c, dev, True, pos_only, microbatches=mb, host_sync=False)
+        for _ in range(3):
+            tr.training_step(batch(), t_int=t_int, draw=draws())
+        torch.cuda.synchronize()
+        w[mb] = tr.flat_param.clone()
+    assert float((w[1] - w[2]).abs().max()) <= 1e-6 * float(w[1].abs().max())
