@@ -581,16 +581,9 @@ class _Topology:
         nfs = n_frag_switch.detach().to("cpu", torch.int64).contiguous()
         if cm.numel() != nfs.numel() or cm.numel() == 0:
             raise _capi.OardError("combined_mask / n_frag_switch size mismatch")
-        h = C.c_void_p()
-        rc = L.oard_topology_create(C.byref(cfg), C.cast(cm.data_ptr(), C.POINTER(C.c_int64)),
-                                    C.cast(nfs.data_ptr(), C.POINTER(C.c_int64)), cm.numel(), C.byref(h))
-        _capi.check(rc, "oard_topology_create (n_frag_switch must be object-major, group size <= 1024)")
-        self.handle = h
         self._lib = L
-        self.n_nodes = int(L.oard_topology_num_nodes(h))
-        self.n_edges = int(L.oard_topology_num_edges(h))
-        self.n_inner = int(L.oard_topology_num_inner_edges(h))
-        self.n_samples = int(L.oard_topology_num_samples(h))
+        self.handle, self.graph = None, None
+        self.n_nodes = int(cm.numel())
         self.max_sample_id = int(cm.max())
         n_obj = cfg.n_obj
         self.obj_counts = [int((nfs == k).sum()) for k in range(n_obj)]
@@ -599,28 +592,43 @@ class _Topology:
         for c in self.obj_counts:
             starts.append(starts[-1] + c)
         self.obj_masks = [combined_mask.detach()[starts[k]: starts[k + 1]].to(torch.int64) for k in range(n_obj)]
-        # the kernels assume the complete-per-sample graph (any ordering of its edge list: outputs are per node): verify once
         ei = edge_index.detach()
         if ei.dim() != 2 or ei.shape[0] != 2 or ei.dtype != torch.int64 or ei.device != dev:
             raise _capi.OardError("edge_index must be an int64 [2, E] tensor on the same device")
         ei = ei.contiguous()
-        ok = torch.zeros(1, dtype=torch.int32, device=dev)
-        _capi.check(L.oard_topology_check_edge_index(h, ei.data_ptr(), ei.shape[1], ok.data_ptr(), stream),
-                    "oard_topology_check_edge_index")
-        self.graph = None
-        if int(ok.item()) != 1 or force_general:
-            # not the complete graph per sample (edge_cutoff graphs, disconnected components, arbitrary lists: egnn_dynamics.py:63-72
-            # accepts them all): the general-edge-list path (csrc/oard_general.h) takes the call.  One host copy of the edge list per
-            # topology, like the two masks above.
+        # the production kernels assume the complete-per-sample graph (any ordering of its edge list: outputs are per node): verify once.
+        # A layout their tables do not cover (a (sample, object) group of more than 1024 atoms) cannot be that path's either way.
+        h = C.c_void_p()
+        rc = L.oard_topology_create(C.byref(cfg), C.cast(cm.data_ptr(), C.POINTER(C.c_int64)),
+                                    C.cast(nfs.data_ptr(), C.POINTER(C.c_int64)), cm.numel(), C.byref(h))
+        complete = False
+        if rc == _capi.OARD_OK:
+            ok = torch.zeros(1, dtype=torch.int32, device=dev)
+            _capi.check(L.oard_topology_check_edge_index(h, ei.data_ptr(), ei.shape[1], ok.data_ptr(), stream),
+                        "oard_topology_check_edge_index")
+            complete = int(ok.item()) == 1
+            if complete and not force_general:
+                self.handle = h
+                self.n_edges = int(L.oard_topology_num_edges(h))
+                self.n_inner = int(L.oard_topology_num_inner_edges(h))
+                self.n_samples = int(L.oard_topology_num_samples(h))
+                return
             L.oard_topology_destroy(h)
-            self.handle = None
-            ei_host = ei.to("cpu").contiguous()
-            g = C.c_void_p()
-            rc = L.oard_graph_create(C.byref(cfg), cm.data_ptr(), nfs.data_ptr(), cm.numel(), ei_host.data_ptr(), ei_host.shape[1], C.byref(g))
-            _capi.check(rc, "oard_graph_create (node ids out of range, or n_frag_switch not object-major)")
-            self.graph = g
-            self.n_edges = int(L.oard_graph_num_edges(g))
-            self.n_inner = int((nfs[ei_host[0]] == nfs[ei_host[1]]).sum())
+        # not the complete graph per sample (edge_cutoff graphs, disconnected components, arbitrary lists: egnn_dynamics.py:63-72
+        # accepts them all): the general-edge-list path (csrc/oard_general.h) takes the call.  One host copy of the edge list per
+        # topology, like the two masks above.
+        ei_host = ei.to("cpu").contiguous()
+        g = C.c_void_p()
+        rc = L.oard_graph_create(C.byref(cfg), cm.data_ptr(), nfs.data_ptr(), cm.numel(), ei_host.data_ptr(), ei_host.shape[1], C.byref(g))
+        _capi.check(rc, "oard_graph_create (node ids out of range, or n_frag_switch not in ascending object blocks)")
+        self.graph = g
+        self.n_edges = int(L.oard_graph_num_edges(g))
+        self.n_inner = int((nfs[ei_host[0]] == nfs[ei_host[1]]).sum()) if ei_host.shape[1] else 0
+        self.n_samples = int(torch.unique(cm).numel())
+        if complete is False and rc == _capi.OARD_OK and not force_general and L.oard_graph_is_complete(g):
+            import warnings
+            warnings.warn("this batch layout is outside the production kernels' tables (a (sample, object) group of more than 1024 atoms): "
+                          "the complete graph is served by the general-edge-list path, which is built for parity, not throughput")
 
     def __del__(self):
         try:

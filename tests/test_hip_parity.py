@@ -336,7 +336,7 @@ def test_largest_supported_object_and_the_limit():
     """One reaction of 3 x 1024-atom objects (the per-object limit OARD_MAX_GROUP; 9.4 M edges, 26 GB of edge
     state): no oracle runs at that size, so the check is the reference's own property test - a global rotation of
     the input rotates the velocities and leaves the features unchanged - plus finiteness.  One atom more per
-    object is refused with an error, not a wrong answer."""
+    object is served by the general-edge-list path (round 6; rounds 1-5 refused it)."""
     from oareactdiff_amd._capi import OardError
     from oareactdiff_amd.dynamics import EGNNDynamics
     from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
@@ -359,10 +359,27 @@ def test_largest_supported_object_and_the_limit():
         assert bool(torch.isfinite(x).all()) and float(x[:, :3].abs().max()) > 0
         assert rel(y[:, :3], x[:, :3] @ q.double().T) <= 1e-4 and rel(y[:, 3:], x[:, 3:]) <= 1e-4
     del a, b
-    xh, ei, t, cond, nfs, cm = _random_case([1025], 1.0, 5, cfg)
-    with pytest.raises(OardError):
-        with torch.no_grad():
-            dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+    # One atom more per object is outside the production kernels' tables.  Rounds 1-5 refused it; since round 6 such a layout falls through
+    # to the general-edge-list path (csrc/oard_general.h) - here on a sparse edge list (every node to its 8 successors inside its object, both
+    # directions), so that the call is cheap: the same rotation property, on the other path.
+    xh, _, t, cond, nfs, cm = _random_case([1025], 1.0, 5, cfg)
+    src, dst = [], []
+    for k in range(3):
+        base = torch.arange(1025) + 1025 * k
+        for d in range(1, 9):
+            src += [base, (base + d - 1025 * k) % 1025 + 1025 * k]
+            dst += [(base + d - 1025 * k) % 1025 + 1025 * k, base]
+    ei = torch.stack([torch.cat(src), torch.cat(dst)])
+    xr = [torch.cat([x[:, :3] @ q.T, x[:, 3:]], dim=1) for x in xh]
+    args = (ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+    with torch.no_grad():
+        a, _ = dyn([x.to(dev) for x in xh], *args)
+        assert dyn._last_topo.graph is not None and dyn._last_topo.handle is None
+        b, _ = dyn([x.to(dev) for x in xr], *args)
+    for x, y in zip(a, b):
+        x, y = x.cpu().double(), y.cpu().double()
+        assert bool(torch.isfinite(x).all()) and float(x[:, :3].abs().max()) > 0
+        assert rel(y[:, :3], x[:, :3] @ q.double().T) <= 1e-4 and rel(y[:, 3:], x[:, 3:]) <= 1e-4
 
 
 def test_scalar_t_equals_per_sample_t_and_input_is_not_mutated():
