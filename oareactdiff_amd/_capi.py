@@ -8,7 +8,7 @@ import os
 from .build import LIB
 
 OARD_MAX_OBJECTS = 8
-ABI_VERSION = 2030            # OARD_VERSION of csrc/oard_hip.hip (checked by lib(): a stale library is refused, not misread)
+ABI_VERSION = 2040            # OARD_VERSION of csrc/oard_hip.hip (checked by lib(): a stale library is refused, not misread)
 OARD_OK, OARD_EINVAL, OARD_ENOTCOMPLETE, OARD_EHIP, OARD_ENOMEM = 0, -1, -2, -3, -4
 ERRORS = {OARD_EINVAL: "invalid argument / unsupported configuration", OARD_ENOTCOMPLETE: "topology is not complete-per-sample",
           OARD_EHIP: "HIP runtime error", OARD_ENOMEM: "workspace too small"}

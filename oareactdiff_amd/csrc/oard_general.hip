@@ -41,13 +41,24 @@ struct oard_graph {
 
 extern "C" {
 
+static int graph_create_impl(const oard_config* c, const int64_t* cm, const int64_t* nfs, int64_t n_nodes, const int64_t* ei, int64_t n_edges,
+                             oard_graph** out);
 int oard_graph_create(const oard_config* c, const int64_t* cm, const int64_t* nfs, int64_t n_nodes, const int64_t* ei, int64_t n_edges,
                       oard_graph** out) {
+    try {                                                 // (std::vector growth: no C++ exception may cross the C ABI)
+        return graph_create_impl(c, cm, nfs, n_nodes, ei, n_edges, out);
+    } catch (...) {
+        return OARD_ENOMEM;
+    }
+}
+static int graph_create_impl(const oard_config* c, const int64_t* cm, const int64_t* nfs, int64_t n_nodes, const int64_t* ei, int64_t n_edges,
+                             oard_graph** out) {
     if (!c || !out || (n_nodes > 0 && (!cm || !nfs)) || (n_edges > 0 && !ei) || c->n_obj < 1 || c->n_obj > OARD_MAX_OBJECTS) return OARD_EINVAL;
     oard_graph* g = new (std::nothrow) oard_graph();
     if (!g) return OARD_ENOMEM;
     int rc = og::build_graph(c, cm, nfs, n_nodes, ei, n_edges, g->host);
     if (rc != OARD_OK) { delete g; return rc; }
+    struct Guard { oard_graph* g; ~Guard() { if (g) { if (g->block) (void)hipFree(g->block); delete g; } } } guard{g};      // until *out owns it
     og::GraphHost& h = g->host;
     // complete per sample?  (what oard_topology_check_edge_index answers for the production path): every node has exactly the other members of
     // its combined_mask value as sources, once each
@@ -79,15 +90,12 @@ int oard_graph_create(const oard_config* c, const int64_t* cm, const int64_t* nf
     std::vector<int32_t> stage(off[13] ? off[13] : 64, 0);
     for (int i = 0; i < 13; ++i)
         if (!tabs[i]->empty()) memcpy(stage.data() + off[i], tabs[i]->data(), tabs[i]->size() * sizeof(int32_t));
-    if (hipMalloc((void**)&g->block, stage.size() * sizeof(int32_t)) != hipSuccess) { delete g; return OARD_EHIP; }
-    if (hipMemcpy(g->block, stage.data(), stage.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(g->block);
-        delete g;
-        return OARD_EHIP;
-    }
+    if (hipMalloc((void**)&g->block, stage.size() * sizeof(int32_t)) != hipSuccess) { g->block = nullptr; (void)hipGetLastError(); return OARD_EHIP; }
+    if (hipMemcpy(g->block, stage.data(), stage.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) return OARD_EHIP;
     const int32_t* b = g->block;
     g->dev = og::Graph{h.N, h.E, h.G, b + off[0], b + off[1], b + off[2], b + off[3], b + off[4], b + off[5], b + off[6], b + off[7],
                        b + off[8], b + off[9], b + off[10], b + off[11], b + off[12]};
+    guard.g = nullptr;
     *out = g;
     return OARD_OK;
 }
@@ -133,11 +141,14 @@ int oard_graph_forward(const oard_config* c, const oard_graph* g, const float* c
     // the pointer tables the stage kernels dereference: [params | xh | out] at the head of the caller's workspace (per call, so calls on
     // distinct workspaces do not share anything)
     const size_t np = (size_t)pi.count;
-    std::vector<const void*> tab(np + 2 * OARD_MAX_OBJECTS, nullptr);
+    constexpr size_t TAB_MAX = 1024;
+    const void* tab[TAB_MAX] = {};
+    const size_t n_tab = np + 2 * OARD_MAX_OBJECTS;
+    if (n_tab > TAB_MAX || c->n_obj > OARD_MAX_OBJECTS) return OARD_EINVAL;
     for (size_t i = 0; i < np; ++i) tab[i] = params[i];
     for (int k = 0; k < c->n_obj; ++k) { tab[np + k] = xh[k]; tab[np + OARD_MAX_OBJECTS + k] = out[k]; }
     // pageable source: the runtime stages it before hipMemcpyAsync returns, `tab` may go out of scope afterwards
-    if (hipMemcpyAsync(ws, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, st) != hipSuccess) return OARD_EHIP;
+    if (hipMemcpyAsync(ws, tab, n_tab * sizeof(void*), hipMemcpyHostToDevice, st) != hipSuccess) return OARD_EHIP;
     const float* const* P_dev = (const float* const*)ws;
     const float* const* xh_dev = P_dev + np;
     float* const* out_dev = (float* const*)(P_dev + np + OARD_MAX_OBJECTS);

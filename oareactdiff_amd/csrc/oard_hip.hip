@@ -25,7 +25,7 @@
 #include "oard_node_bwd.h"
 #include "oard_inst.h"        // the heavy kernel families are instantiated in their own translation units: `extern template` here
 
-#define OARD_VERSION 2030
+#define OARD_VERSION 2040      // round 6: + oard_graph_* (general edge lists), oard_library_stream
 // The first-generation kernels (weights straight from L2, one wave per 16 nodes: gcl_variant / equi_variant / node_variant 0) are the
 // A/B baseline of round 1 and a cross-check in tests/test_hip_parity.py::test_every_kernel_variant_is_parity_green; they are compiled
 // into experiment builds (-DOARD_EXPERIMENTS) only - a product library refuses those variants (oard_debug_option returns OARD_EINVAL).
