@@ -93,6 +93,14 @@ def make_inputs(case: dict):
         edge_index = edge_index[:, keep]
         perm = torch.from_numpy(np.argsort(hash_uniform(case["name"] + ".order", edge_index.size(1), 98)))
         edge_index = edge_index[:, perm]                       # ... in an arbitrary order
+    elif mode == "arbitrary":                                  # whatever a caller may hand over: self loops, duplicates, edges across samples
+        N = combined_mask.numel()
+        E = case["n_edges"]
+        a = (hash_uniform(case["name"] + ".src", E, 97) * (N - 1)).astype(np.int64)          # the last node keeps no edge at all
+        b = (hash_uniform(case["name"] + ".dst", E, 96) * (N - 1)).astype(np.int64)
+        a[5], b[5] = a[4], b[4]                                # a duplicate
+        b[7] = a[7]                                            # a self loop
+        edge_index = torch.from_numpy(np.stack([a, b]))
     elif mode == "components":                                 # two components per sample: nodes with even / odd row index never meet
         a, b = edge_index
         edge_index = edge_index[:, (a % 2) == (b % 2)]
@@ -238,6 +246,8 @@ CASES = [
          fragments_nodes=[[9, 6]] * 3, t_1d=False, pos_scale=2.0, onehot=True, edges="edge_cutoff", edge_cutoff=4.0),
     dict(name="g11_random_subset", model_config=dict(TEST_CFG, num_layers=2), node_nfs=[4, 5, 6], condition_nf=3,
          fragments_nodes=[[2, 3], [2, 3], [1, 2]], t_1d=True, edges="random_subset", keep=0.72),
+    dict(name="g11_arbitrary", model_config=dict(TEST_CFG, num_layers=2), node_nfs=[9, 9, 9], condition_nf=1,
+         fragments_nodes=[[3, 2, 4], [2, 0, 3], [1, 3, 2]], t_1d=False, pos_scale=1.5, onehot=True, edges="arbitrary", n_edges=80),
     dict(name="g11_components_noreflect", model_config=dict(TEST_CFG, num_layers=2, reflect_equiv=False), node_nfs=[9, 9, 9],
          condition_nf=1, fragments_nodes=[[6, 4]] * 3, t_1d=False, onehot=True, edges="components"),
 ]

@@ -11,7 +11,7 @@ from _cases import ALL_CASES, Case, rel
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
-GENERAL_CASES = ["g11_edge_cutoff_h32", "g11p_edge_cutoff_prod", "g11_random_subset", "g11_components_noreflect"]
+GENERAL_CASES = ["g11_edge_cutoff_h32", "g11p_edge_cutoff_prod", "g11_random_subset", "g11_components_noreflect", "g11_arbitrary"]
 
 
 def _dyn(c, dev, path="auto"):
@@ -138,3 +138,23 @@ def test_what_is_still_refused():
         dyn(*_args(c, dev, bad))
     with pytest.raises(OardError):
         dyn(*_args(c, dev))                                # autograd enabled: the training path
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_arbitrary_edge_lists_are_taken_as_given(seed):
+    """Self loops, duplicated edges, edges across samples and objects, isolated nodes, an empty object: whatever the list holds is the
+    graph, as in the reference (egnn_dynamics.py:63-72; the oracle, pinned on the reference for general graphs, evaluates the same list)."""
+    from test_general_host import _random_graph_case
+    dev = torch.device("cuda:0")
+    c = _random_graph_case(seed)
+    dyn = _dyn(c, dev)
+    with torch.no_grad():
+        out, _ = dyn(*_args(c, dev))
+    assert dyn._last_topo.graph is not None
+    ref = oracle.dynamics_forward(c.state_dict(torch.float64), c.cfg, [x.double() for x in c.xh], c.edge_index, c.t.double(),
+                                  c.conditions.double(), c.n_frag_switch, c.combined_mask, c.cnf, nodeframe="literal")
+    v, h = c.split([o.cpu() for o in out])
+    rv, rh = c.split(ref)
+    print(f"random graph {seed}: vel {rel(v, rv):.2e} h {rel(h, rh):.2e}")
+    assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
+

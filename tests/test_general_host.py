@@ -14,7 +14,7 @@ import torch
 from _cases import ALL_CASES, Case, rel
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GENERAL_CASES = ["g11_edge_cutoff_h32", "g11p_edge_cutoff_prod", "g11_random_subset", "g11_components_noreflect"]
+GENERAL_CASES = ["g11_edge_cutoff_h32", "g11p_edge_cutoff_prod", "g11_random_subset", "g11_components_noreflect", "g11_arbitrary"]
 
 
 @pytest.fixture(scope="module")
@@ -67,3 +67,38 @@ def test_general_path_is_invariant_under_edge_order(harness):
     a, b = run_host(harness, c), run_host(harness, c, c.edge_index[:, perm])
     for x, y in zip(a, b):
         assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max())
+
+
+def _random_graph_case(seed):
+    """A small ragged batch with an ARBITRARY directed edge list: self loops, duplicated edges, edges across samples and across objects,
+    nodes without incoming / outgoing edges, an empty object - everything `EGNNDynamics.forward` takes as given (egnn_dynamics.py:63-72)."""
+    from oareactdiff_amd.graph_tools import get_mask_for_frag, get_n_frag_switch
+    g = torch.Generator().manual_seed(seed)
+    c = Case("g3_cutoff_ragged")                       # configuration / weights of a fixture; inputs and graph are drawn here
+    sizes = [[3, 2, 4], [2, 0, 3], [1, 3, 2]]
+    natm = [torch.tensor(x) for x in sizes]
+    masks = [get_mask_for_frag(n) for n in natm]
+    cm, nfs = torch.cat(masks), get_n_frag_switch(natm)
+    N = cm.numel()
+    c.xh = [torch.cat([1.5 * torch.randn(m.numel(), 3, generator=g), torch.rand(m.numel(), 6, generator=g)], 1) for m in masks]
+    E = 70
+    ei = torch.randint(0, N - 2, (2, E), generator=g)              # the last two nodes keep no edge at all
+    ei[:, 5] = ei[:, 4]                                             # a duplicate
+    ei[1, 7] = ei[0, 7]                                             # a self loop
+    c.edge_index, c.combined_mask, c.n_frag_switch = ei, cm, nfs
+    c.t, c.conditions = torch.rand(3, 1, generator=g), torch.rand(3, 1, generator=g)
+    return c
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_arbitrary_edge_lists_are_taken_as_given(harness, seed):
+    import leftnet_oracle as oracle
+    c = _random_graph_case(seed)
+    out = run_host(harness, c)
+    ref = oracle.dynamics_forward(c.state_dict(torch.float64), c.cfg, [x.double() for x in c.xh], c.edge_index, c.t.double(),
+                                  c.conditions.double(), c.n_frag_switch, c.combined_mask, c.cnf, nodeframe="literal")
+    v, h = c.split(out)
+    rv, rh = c.split(ref)
+    print(f"random graph {seed}: vel {rel(v, rv):.2e} h {rel(h, rh):.2e}")
+    assert rel(v, rv) <= 1e-5 and rel(h, rh) <= 1e-5
+
