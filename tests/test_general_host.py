@@ -1,8 +1,9 @@
 """The general-edge-list path's formulas on the CPU (csrc/oard_general.h).  The stage functors and the orchestration of that path are
 written once for two executors; here tests/general_host/harness.cpp runs them in host loops (compiled with g++ by this test) against the
 REFERENCE's float64 outputs (tests/golden/*.npz, oracle/make_goldens.py): the eight complete-graph fixtures - where the literal node
-frame this path evaluates agrees with the exact-arithmetic one - and the four general graphs of round 6 (edge_cutoff graphs from the
-reference's own builder, an arbitrary directed subset in arbitrary order, disconnected components with reflect_equiv=False).
+frame this path evaluates agrees with the exact-arithmetic one - and the five general graphs of round 6 (edge_cutoff graphs from the
+reference's own builder, a directed subset in arbitrary order, disconnected components with reflect_equiv=False, an arbitrary list with
+self loops / duplicates / cross-sample edges).
 On the GPU the same functors run as HIP kernels (tests/test_general_edges.py, -m gpu).  Nothing in the product path loads this harness."""
 import ctypes as C
 import os
