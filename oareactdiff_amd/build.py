@@ -19,6 +19,7 @@ SOURCES = {
     "oard_inst_b3.hip": _EDGE + ["oard_edge_b3.h"],
     "oard_inst_equi.hip": _EDGE + ["oard_node_v1.h", "oard_edge_bwd.h"],
     "oard_inst_wgrad.hip": _EDGE + ["oard_edge_bwd.h", "oard_wgrad_t16.h"],
+    "oard_inst_node.hip": _EDGE + ["oard_node_v1.h", "oard_edge_bwd.h", "oard_node_bwd.h", "oard_rows.h"],
 }
 _OWNED = {"oard_general.h"}                     # headers no other unit includes
 _PUBLIC = os.path.join("..", "..", "include", "oard.h")

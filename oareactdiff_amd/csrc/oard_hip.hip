@@ -23,6 +23,7 @@
 #include "oard_edge_small.h"
 #include "oard_edge_bwd.h"
 #include "oard_node_bwd.h"
+#include "oard_rows.h"
 #include "oard_inst.h"        // the heavy kernel families are instantiated in their own translation units: `extern template` here
 
 #define OARD_VERSION 2040      // round 6: + oard_graph_* (general edge lists), oard_library_stream

@@ -19,6 +19,7 @@
 #endif
 #define OARD_BOOL4(M, D) M(D, true, true) M(D, false, true) M(D, true, false) M(D, false, false)      /* D = (Dims<h, r>), parenthesised */
 
+#define OARD_NW(h) (((h) + 15) / 16 <= 16 ? ((h) + 15) / 16 : 8)       /* forward_impl: NW = D::HT <= 16 ? D::HT : 8 */
 #define OARD_A_GCL (TopoDev, const float*, const float*, const float*, const float*, const float*, long long, long long, const float*, float*, float*, GclTape)
 
 // ---- k_gcl_edge_p: persistent GCL throughput shape, inference and training-mode (oard_edge_p.h) --------------------------------------
@@ -53,7 +54,6 @@ OARD_DIMS_LIST
 #if !defined(OARD_INST_DEFINE) || defined(OARD_INST_UNIT_EQUI)
 #define OARD_A_EQUI (TopoDev, const float*, const float*, const float*, const float*, float*, float*, float*, ActList)
 #define OARD_A_EQUI_NODE (TopoDev, const float*, LayerOff, const float*, const float*, const float*, const float*, const float*, float*, const float*, float*, float*, float*, ActList)
-#define OARD_NW(h) (((h) + 15) / 16 <= 16 ? ((h) + 15) / 16 : 8)       /* forward_impl: NW = D::HT <= 16 ? D::HT : 8 */
 #define X(h, r) \
     OARD_INST((k_equi_edge_v1<Dims<h, r>, 8, false>), OARD_A_EQUI) OARD_INST((k_equi_edge_v1<Dims<h, r>, 8, true>), OARD_A_EQUI) \
     OARD_INST((k_equi_edge_v1<Dims<h, r>, 4, false>), OARD_A_EQUI) \
@@ -64,6 +64,28 @@ OARD_DIMS_LIST
     OARD_INST((k_equi_edge_bwd<Dims<h, r>, 8>), (TopoDev, const float*, const float*, const float*, float*, float*))
 OARD_DIMS_LIST
 #undef X
+#endif
+
+// ---- node-side kernels of both passes (oard_node_v1.h, oard_node_bwd.h, oard_rows.h).  The row-generic dense kernels are templates of
+// tile counts, not of the widths: the shapes of the production widths are listed (other widths instantiate theirs in oard_hip.hip). ---------
+#if !defined(OARD_INST_DEFINE) || defined(OARD_INST_UNIT_NODE)
+#define OARD_A_GCL_NODE (TopoDev, const float*, LayerOff, const float*, const float*, float*, float*, float*)
+#define OARD_A_OUT (TopoDev, const float*, PackOff, const float*, const float*, float*, float*, int*)
+#define OARD_A_SCAL_BWD (TopoDev, const float*, const float*, int, const float*, const float*, float*, float*)
+#define OARD_A_MSG_BWD (TopoDev, const float*, Strided3, Strided3, const float*, Strided3, const float*, int, Strided3, float*, float*, float*, float*, int, int, int)
+#define X(h, r) \
+    OARD_INST((k_gcl_node_v1<Dims<h, r>, OARD_NW(h), false>), OARD_A_GCL_NODE) OARD_INST((k_gcl_node_v1<Dims<h, r>, OARD_NW(h), true>), OARD_A_GCL_NODE) \
+    OARD_INST((k_out_v1<Dims<h, r>, OARD_NW(h)>), OARD_A_OUT) \
+    OARD_INST((k_scalarize_bwd<Dims<h, r>, 2, false>), OARD_A_SCAL_BWD) OARD_INST((k_scalarize_bwd<Dims<h, r>, 2, true>), OARD_A_SCAL_BWD) \
+    OARD_INST((k_equi_msg_bwd<Dims<h, r> >), OARD_A_MSG_BWD)
+OARD_DIMS_LIST
+#undef X
+OARD_INST((k_lin3u_bwd_fused<4>), (const float*, const float*, const float*, long long, float*, float*))
+#define OARD_I_ROWS(KB, EPI) OARD_INST((k_rows_dense<KB, EPI, 8>), (RowsDense)) OARD_INST((k_rows_dense_long<KB, EPI, 8, 4>), (RowsDense))
+OARD_I_ROWS(13, 0) OARD_I_ROWS(13, 2) OARD_I_ROWS(13, 3) OARD_I_ROWS(7, 3) OARD_I_ROWS(6, 0) OARD_I_ROWS(6, 1) OARD_I_ROWS(4, 1) OARD_I_ROWS(4, 3)
+OARD_INST((k_rows_dense<26, 1, 8>), (RowsDense)) OARD_INST((k_rows_dense<26, 3, 8>), (RowsDense))
+OARD_INST((k_rows_dense2<13, 1, 8, 13>), (RowsDense2)) OARD_INST((k_rows_dense2<13, 2, 8, 13>), (RowsDense2))
+OARD_INST((k_rows_dense2<26, 1, 8, 13>), (RowsDense2)) OARD_INST((k_rows_dense2<39, 2, 8, 13>), (RowsDense2))
 #endif
 
 // ---- weight-gradient GEMMs (oard_wgrad_t16.h, oard_edge_bwd.h): not templates of the widths ----------------------------------------------
