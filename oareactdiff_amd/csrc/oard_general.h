@@ -127,7 +127,7 @@ struct Workspace {
     double *pos, *pf, *lmean;                      // [N][3] each
     int32_t* labels;                               // [N]
     float *hin, *mask, *dist, *env, *cd, *cc, *cv, *rbf, *nf, *pp, *f, *eH, *m, *nb, *s, *s1, *ne1, *ew, *xh, *agg, *nH, *nH2, *xq, *e3a,
-        *e3b, *e3c, *vec, *vec2, *vp, *scalar, *vdot, *xv, *n3H, *v1n, *v2, *xg, *dpos, *hout, *gmean;
+        *e3b, *e3c, *vec, *vec2, *vp, *scalar, *vdot, *xv, *n3H, *v1n, *v2, *xg, *dpos, *hout, *gmean, *att;
     size_t bytes;
 };
 inline Workspace carve(const oard_config* c, int64_t N, int64_t E, int64_t G, char* base) {
@@ -144,7 +144,7 @@ inline Workspace carve(const oard_config* c, int64_t N, int64_t E, int64_t G, ch
     F(f, e * H); F(eH, e * H); F(m, e * H); F(nb, n * H); F(s, n * H); F(s1, n * H); F(ne1, n * 3 * H); F(ew, e * W); F(xh, n * H);
     F(agg, n * H); F(nH, n * H); F(nH2, n * H); F(xq, n * 3 * H); F(e3a, e * 3 * H); F(e3b, e * 3 * H); F(e3c, e * 3 * H);
     F(vec, n * 3 * H); F(vec2, n * 3 * H); F(vp, n * 3 * 2 * H); F(scalar, n * H); F(vdot, n * H); F(xv, n * 3 * H); F(n3H, n * 3 * H);
-    F(v1n, n * H); F(v2, n * 3); F(xg, n * 2); F(dpos, n * 3); F(hout, n * d.Cin); F(gmean, g * 3);
+    F(v1n, n * H); F(v2, n * 3); F(xg, n * 2); F(dpos, n * 3); F(hout, n * d.Cin); F(gmean, g * 3); F(att, e);
 #undef F
     w.bytes = cur;
     return w;
@@ -420,15 +420,9 @@ struct CopyRbf {
 };
 
 // ---- GCLMessage (:157-183) ------------------------------------------------------------------------------------------------------------
-struct Gate {                                       // m *= SiLU(att_mlp(m))
-    int H; const float* watt; const float* batt; float* m;
-    G_HD void operator()(long long e) const {
-        float* r = m + (size_t)e * H;
-        double a = batt[0];
-        for (int c = 0; c < H; ++c) a += (double)watt[c] * (double)r[c];
-        const float gt = silu_f((float)a);
-        for (int c = 0; c < H; ++c) r[c] *= gt;
-    }
+struct Gate {                                       // m *= SiLU(att_mlp(m)); att = the H -> 1 dense layer (SiLU applied), one thread per element
+    int H; const float* att; float* m;
+    G_HD void operator()(long long tid) const { m[tid] *= att[tid / H]; }
 };
 struct AggMean {                                    // unsorted_segment_sum(m, ei0) / max(count, 1) (util_funcs.py:27-45)
     Graph g; int H; const float* m; float* agg;
@@ -571,7 +565,8 @@ struct Post {
 };
 
 // ---- orchestration ----------------------------------------------------------------------------------------------------------------------
-// Exec: run(n, functor) executes functor(0 .. n-1) (a kernel launch / a host loop), zero(ptr, bytes).  `P`, `xh`, `out` are tables the
+// Exec: run(n, functor) executes functor(0 .. n-1) (a kernel launch / a host loop), zero(ptr, bytes), gemm(Gemm) = one dense layer
+// (run(k.threads(), k), or the executor's own kernel with the same result up to the order of the float64 sum).  `P`, `xh`, `out` are tables the
 // FUNCTORS dereference: device-visible tables for the HIP executor.  P_host is the same parameter table readable by this function.
 inline Seg seg(const float* x, int ld, int K, const int32_t* idx = nullptr) { return Seg{x, ld, K, idx}; }
 template <class Exec>
@@ -583,7 +578,7 @@ int dense(Exec& ex, long long rows, int nout, const Seg* segs, int nseg, const f
     k.rows = rows; k.nout = nout; k.nseg = nseg;
     for (int i = 0; i < nseg; ++i) k.seg[i] = segs[i];
     k.W = W; k.ldw = ldw; k.bias = bias; k.Y = Y; k.ldy = ldy; k.act = act; k.mode = mode; k.resid = resid; k.ldr = ldr; k.rowscale = rowscale;
-    return ex.run(k.threads(), k);
+    return ex.gemm(k);                                   // the executor's dense layer: Gemm itself on plain threads, or a kernel of its own
 }
 #define G_TRY(x) do { const int rc_ = (x); if (rc_ != OARD_OK) return rc_; } while (0)
 
@@ -637,7 +632,8 @@ int forward(Exec& ex, const oard_config* c, const Graph& g, const float* const* 
         { Seg s3[3] = {seg(w.xh, H, H, g.ei0), seg(w.xh, H, H, g.ei1), seg(w.ew, W, W)};
           G_TRY(dense(ex, E, H, s3, 3, Pw(gp + 0), 2 * H + W, Pw(gp + 1), w.eH, H, 1)); }
         { Seg s1[1] = {seg(w.eH, H, H)}; G_TRY(dense(ex, E, H, s1, 1, Pw(gp + 2), H, Pw(gp + 3), w.m, H, 1)); }
-        G_TRY(ex.run(E, Gate{H, Pw(gp + 10), Pw(gp + 11), w.m}));
+        { Seg s1[1] = {seg(w.m, H, H)}; G_TRY(dense(ex, E, 1, s1, 1, Pw(gp + 10), H, Pw(gp + 11), w.att, 1, 1)); }
+        G_TRY(ex.run(E * H, Gate{H, w.att, w.m}));
         G_TRY(ex.run(N * H, AggMean{g, H, w.m, w.agg}));
         { Seg s2[2] = {seg(w.xh, H, H), seg(w.agg, H, H)}; G_TRY(dense(ex, N, H, s2, 2, Pw(gp + 4), 2 * H, Pw(gp + 5), w.nH, H, 1)); }
         { Seg s1[1] = {seg(w.nH, H, H)}; G_TRY(dense(ex, N, H, s1, 1, Pw(gp + 6), H, Pw(gp + 7), w.s, H, 0, 2, w.xh, H)); }

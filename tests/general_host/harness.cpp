@@ -11,6 +11,7 @@ namespace og = oard_general;
 struct HostExec {
     template <class F> int run(long long n, const F& f) { for (long long i = 0; i < n; ++i) f(i); return OARD_OK; }
     int zero(void* p, size_t bytes) { memset(p, 0, bytes); return OARD_OK; }
+    int gemm(const og::Gemm& k) { return run(k.threads(), k); }
 };
 
 extern "C" int oard_general_forward_host(const oard_config* c, const int64_t* cm, const int64_t* nfs, int64_t N, const int64_t* ei, int64_t E,

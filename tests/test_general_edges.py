@@ -63,6 +63,28 @@ def test_general_path_agrees_with_the_production_kernels_on_complete_graphs(name
     assert rel(vb, va) <= TOL and rel(hb, ha) <= TOL
 
 
+@pytest.mark.parametrize("name", ["g11p_edge_cutoff_prod", "g11_arbitrary", "g3p_prod_cutoff"])
+def test_dense_layers_on_the_matrix_pipe_and_on_plain_threads_agree(name, monkeypatch):
+    """The dense layers of the general path run on the float64 matrix pipe (k_general_gemm_f64: 16-row x 16-output MFMA tiles, ragged row and
+    output tails, gathered segments); OARD_GENERAL_GEMM=threads runs the same layers as og::Gemm on plain threads - the formulation the CPU
+    suite checks on the host executor.  Both carry the sum in float64: they may differ in its ORDER only."""
+    dev = torch.device("cuda:0")
+    c = Case(name)
+    outs = {}
+    for how in ("matrix", "threads"):
+        monkeypatch.setenv("OARD_GENERAL_GEMM", how)                       # read by the library on every call
+        dyn = _dyn(c, dev, "general")
+        with torch.no_grad():
+            out, _ = dyn(*_args(c, dev))
+        assert dyn._last_topo.graph is not None
+        outs[how] = c.split([o.cpu() for o in out])
+    (va, ha), (vb, hb) = outs["matrix"], outs["threads"]
+    rv, rh = c.split(c.ref64)
+    print(f"{name}: matrix pipe vs threads vel {rel(va, vb):.1e} h {rel(ha, hb):.1e}; vs f64 reference: matrix vel {rel(va, rv):.2e}, threads vel {rel(vb, rv):.2e}")
+    assert rel(va, vb) <= 2e-7 and rel(ha, hb) <= 2e-7
+    assert rel(va, rv) <= TOL and rel(vb, rv) <= TOL
+
+
 def test_edge_cutoff_batch_against_the_oracle():
     """get_edges_index(combined_mask, pos, edge_cutoff) (utils/_graph_tools.py:31-33) on a ragged batch at production dims, against the
     float64 oracle (literal node frame) evaluated here."""

@@ -21,15 +21,16 @@ for B in [int(x) for x in sys.argv[1:]] or [1, 8, 64]:
     xh = [x.to(dev) for x in make_inputs(B, nf, masks, 5, "cpu")]
     args = (xh, ei.to(dev), torch.full((B, 1), 0.5, device=dev), torch.zeros(B, 1, device=dev), nfs.to(dev), cm.to(dev))
     outs = {}
-    for path in ("auto", "general"):
+    for path in ("auto", "general", "general_threads"):
+        os.environ["OARD_GENERAL_GEMM"] = "threads" if path == "general_threads" else "matrix"     # read by the library per call
         dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0, condition_nf=1, device=dev)
         dyn.load_state_dict(sd, strict=True)
-        dyn.edge_list_path = path
+        dyn.edge_list_path = "auto" if path == "auto" else "general"
         dyn.nan_check = "async"
         with torch.no_grad():
             dyn(*args)
             torch.cuda.synchronize()
-            n = 3 if path == "general" else 10
+            n = 3 if path != "auto" else 10
             t0 = time.perf_counter()
             for _ in range(n):
                 o, _ = dyn(*args)
@@ -37,6 +38,7 @@ for B in [int(x) for x in sys.argv[1:]] or [1, 8, 64]:
             dt = (time.perf_counter() - t0) / n
         outs[path] = (torch.cat([x.reshape(-1) for x in o]).double().cpu(), dt)
         del dyn
-    a, b = outs["auto"][0], outs["general"][0]
-    print(f"B = {B} (E = {ei.shape[1]}): production kernels {outs['auto'][1] * 1e3:.2f} ms, general path {outs['general'][1] * 1e3:.1f} ms per call; "
-          f"max |difference| / max |.| = {float((a - b).abs().max() / a.abs().max()):.2e}")
+    a, b, c = outs["auto"][0], outs["general"][0], outs["general_threads"][0]
+    print(f"B = {B} (E = {ei.shape[1]}): production kernels {outs['auto'][1] * 1e3:.2f} ms, general path {outs['general'][1] * 1e3:.1f} ms per call "
+          f"(dense layers on plain threads, OARD_GENERAL_GEMM=threads: {outs['general_threads'][1] * 1e3:.1f} ms); "
+          f"max |difference| / max |.| = {float((a - b).abs().max() / a.abs().max()):.2e} (threads vs matrix pipe: {float((c - b).abs().max() / a.abs().max()):.2e})")
