@@ -503,6 +503,43 @@ def config5(dev, steps=6, warmup=2):
     return out
 
 
+def general_edge_lists(dev, B, nf, calls=3):
+    """The general-edge-list path (csrc/oard_general.h; DESIGN.md section 13: any `edge_index` that is not the complete graph per sample)
+    on the headline batch: (a) the complete graph sent down that path on purpose, beside the production kernels on the same inputs - time per
+    call and agreement of the two independent implementations; (b) an `edge_cutoff` graph of the same atoms
+    (utils/_graph_tools.py:31-33), which takes that path by itself."""
+    from oareactdiff_amd.graph_tools import get_edges_index
+    wl = Workload(B, nf, dev, 777, pos_scale=2.0, n_sets=1)
+    xh = wl.inputs[0]
+
+    def run(dyn, ei):
+        with torch.no_grad():
+            out, _ = dyn(xh, ei, wl.ts[0], wl.cond, wl.nfs, wl.cm)           # (first call: tables, workspace)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                out, _ = dyn(xh, ei, wl.ts[0], wl.cond, wl.nfs, wl.cm)
+            torch.cuda.synchronize(dev)
+        return torch.cat([o.reshape(-1) for o in out]).double(), (time.perf_counter() - t0) / calls * 1e3
+
+    prod = new_dynamics(dev)
+    a, ms_prod = run(prod, wl.ei)
+    gen = new_dynamics(dev)
+    gen.edge_list_path = "general"
+    b, ms_gen = run(gen, wl.ei)
+    assert gen._last_topo.graph is not None and prod._last_topo.graph is None
+    pos = torch.cat([x[:, :3] for x in xh])
+    cut = get_edges_index(wl.cm, pos=pos, edge_cutoff=4.0, remove_self_edge=True)
+    auto = new_dynamics(dev)
+    c, ms_cut = run(auto, cut)
+    assert auto._last_topo.graph is not None, "an incomplete edge list must take the general path"
+    assert bool(torch.isfinite(c).all())
+    return {"workload": f"B={B} x 3 x {nf} atoms, positions ~ 2 N(0,1); {calls} calls each", "dtype": "f32 storage, f64 accumulation (float64 MFMA)",
+            "complete_graph": {"edges": int(wl.ei.shape[1]), "ms_per_call_general": ms_gen, "ms_per_call_production": ms_prod,
+                               "max_abs_difference_over_max_abs": float((a - b).abs().max() / a.abs().max())},
+            "edge_cutoff_4A": {"edges": int(cut.shape[1]), "ms_per_call_general": ms_cut}}
+
+
 def dry_run(args, rank, world, dist, backend):
     """The multi-process skeleton of the timed region without a GPU (OARD_BENCH_DRY=1, tests/test_bench_multirank.py):
     per-rank stand-in steps, barrier on both sides, MAX of the wall clock over the ranks, ONE JSON line on rank 0."""
@@ -709,7 +746,7 @@ def main():
         roof = roofline_of(kernel_families(dyn, eager_step, dev), E, A, args.precision, prefix, dyn.active_inner_edges())
 
     # the real sampling loop (row N1): the BASELINE metric's reactions/s, MEASURED (T = 1000 unless --quick)
-    sampler_leg = train = second = cfg5 = None
+    sampler_leg = train = second = cfg5 = general = None
     extra = rank == 0 and world == 1 and not os.environ.get("OARD_BENCH_ALLOW_NAN")     # N > 1: the other ranks wait in a barrier meanwhile
     if extra and "sampler" not in skip:
         sampler_leg = sampler_run(dyn, wl, 12 if args.quick else 1000, dev)
@@ -728,6 +765,9 @@ def main():
             torch.cuda.empty_cache()
         if "config5" not in skip:
             cfg5 = config5(dev)
+            torch.cuda.empty_cache()
+        if "general" not in skip:
+            general = general_edge_lists(dev, B, nf)
             torch.cuda.empty_cache()
 
     if rank == 0:
@@ -751,6 +791,7 @@ def main():
             "train_step": train,
             "second_line": second,
             "config5": cfg5,
+            "general_edge_lists": general,
         }
         if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(nf)
