@@ -437,8 +437,10 @@ int oard_library_stream(int which, oard_stream_t* out);
  * (dynamics/egnn_dynamics.py:63-72), builds incomplete ones with get_edges_index(..., edge_cutoff=) (utils/_graph_tools.py:31-33, plumbed
  * through trainer/pl_trainer.py:68,94 and dynamics/_base.py:59), and its model tests run disconnected and cut graphs
  * (tests/model/test_equiv.py:177-230, tests/model/test_subgraphs.py:285-339).  Production never leaves the complete graph
- * (trainer/train_ts1x.py:106), so this path is built for parity, not throughput (csrc/oard_general.h): explicit edge list, CSR gathers in
+ * (trainer/train_ts1x.py:106), so this path is built for parity first (csrc/oard_general.h): explicit edge list, CSR gathers in
  * edge order, the reference's literal node frame (leftnet.py:812-834) on float64 geometry, float64 accumulation, raw (unpacked) parameters.
+ * Its dense layers run on the float64 matrix pipe (k_general_gemm_f64, csrc/oard_general.hip); the environment variable
+ * OARD_GENERAL_GEMM=threads, read on every call, runs them on plain threads instead (the cross-check form; same results, ~18 x the time).
  * Inference only.
  *
  * oard_graph_create: host arrays in (combined_mask / n_frag_switch as for oard_topology_create; edge_index [2, E] row-major, reference
