@@ -21,7 +21,9 @@ GENERAL_CASES = ["g11_edge_cutoff_h32", "g11p_edge_cutoff_prod", "g11_random_sub
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("general_host") / "libgeneral_host.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "general_host", "harness.cpp")], check=True)
+    # OARD_HOST_SANITIZE=1 (with LD_PRELOAD=$(gcc -print-file-name=libasan.so) for the interpreter): the same functors under ASan + UBSan
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if os.environ.get("OARD_HOST_SANITIZE") else ["-O2"]
+    subprocess.run(["g++", *san, "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "general_host", "harness.cpp")], check=True)
     return C.CDLL(so)
 
 
