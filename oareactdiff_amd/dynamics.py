@@ -165,6 +165,7 @@ class EGNNDynamics(nn.Module):
         #: "auto": the complete graph per sample runs the production kernels, any other edge list the general path (csrc/oard_general.h);
         #: "general": every inference call runs the general path (tests: two independent implementations of the same network)
         self.edge_list_path = "auto"
+        self._warned_unbuilt = False
 
     # ------------------------------------------------------------------------------------------
     def _config(self) -> _capi.OardConfig:
@@ -290,8 +291,8 @@ class EGNNDynamics(nn.Module):
         return torch.cat([c0s.expand(2 * H), c0f, torch.zeros(R, dtype=c0f.dtype, device=c0f.device)])
 
     def _get_topology(self, cfg, edge_index: Tensor, n_frag_switch: Tensor, combined_mask: Tensor,
-                      stream: int) -> "_Topology":
-        force_general = self.edge_list_path == "general"
+                      stream: int, force_general: bool = False) -> "_Topology":
+        force_general = force_general or self.edge_list_path == "general"
         key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
                n_frag_switch.data_ptr(), n_frag_switch._version, combined_mask.data_ptr(), combined_mask._version,
                combined_mask.numel(), force_general)
@@ -329,13 +330,25 @@ class EGNNDynamics(nn.Module):
             raise _capi.OardError("EGNNDynamics.forward needs tensors on a ROCm device (no CPU fallback)")
         L = _capi.lib()
         cfg = self._config()
-        _capi.check(L.oard_supported(C.byref(cfg)), "oard_supported (hidden_channels/num_radial not built)")
+        # the production kernels are compiled per (hidden_channels, num_radial) pair (OARD_DIMS, oareactdiff_amd.build).  Any other pair
+        # still runs - inference only - on the general-edge-list kernels, whose widths are run-time values (csrc/oard_general.h)
+        built = L.oard_supported(C.byref(cfg)) == _capi.OARD_OK
+        if not built:
+            if train:
+                _capi.check(L.oard_supported(C.byref(cfg)), "oard_supported (hidden_channels/num_radial not built: the backward pass exists for "
+                                                            "built widths only - rebuild: OARD_DIMS=\"196x96,HxR\" python -m oareactdiff_amd.build)")
+            if not self._warned_unbuilt:
+                import warnings
+                self._warned_unbuilt = True
+                warnings.warn(f"hidden_channels={int(cfg.hidden)}, num_radial={int(cfg.num_radial)} is not a width pair the production kernels were built "
+                              "for: this module's inference calls run the general-edge-list kernels (float64 accumulation, several times slower). "
+                              f"For the production kernels rebuild: OARD_DIMS=\"196x96,{int(cfg.hidden)}x{int(cfg.num_radial)}\" python -m oareactdiff_amd.build")
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            packed = self._get_packed(cfg, stream)
+            packed = self._get_packed(cfg, stream) if built else None
             if train:
                 return self._forward_train(cfg, packed, xh, edge_index, t, conditions, n_frag_switch, combined_mask, stream)
-            topo = self._get_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+            topo = self._get_topology(cfg, edge_index, n_frag_switch, combined_mask, stream, force_general=not built)
             n_obj = len(self.node_nfs)
             xs = []
             for k in range(n_obj):

@@ -224,6 +224,9 @@ class DiffusionSampler:
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 cfg = dyn._config()
                 topo = dyn._get_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+                if topo.handle is None:
+                    raise _capi.OardError("the sampling loops run on the production kernels: hidden_channels / num_radial must be a built width "
+                                          "pair (OARD_DIMS=... python -m oareactdiff_amd.build) and a (sample, object) group at most 1024 atoms")
 
                 def draw(i):
                     if noise_fn is not None:
@@ -351,6 +354,9 @@ class DiffusionSampler:
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 cfg = dyn._config()
                 topo = dyn._get_topology(cfg, edge_index, n_frag_switch, combined_mask, stream)
+                if topo.handle is None:
+                    raise _capi.OardError("the sampling loops run on the production kernels: hidden_channels / num_radial must be a built width "
+                                          "pair (OARD_DIMS=... python -m oareactdiff_amd.build) and a (sample, object) group at most 1024 atoms")
                 counter = [0]
 
                 def draw():

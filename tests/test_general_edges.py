@@ -87,6 +87,49 @@ def test_dense_layers_on_the_matrix_pipe_and_on_plain_threads_agree(name, monkey
     assert rel(va, rv) <= TOL and rel(vb, rv) <= TOL
 
 
+@pytest.mark.parametrize("hidden, radial", [(36, 6), (40, 12), (64, 20)])
+def test_widths_nobody_built_run_the_general_kernels(hidden, radial):
+    """The production kernels exist per (hidden_channels, num_radial) pair of the build (OARD_DIMS_LIST); the general path's widths are
+    run-time values.  A module of any other width - the reference's tests and notebooks use many - answers inference calls through the general
+    kernels (a warning, once, names the rebuild), on complete and cut graphs alike; training at such a width still raises.  Against the float64
+    oracle evaluated here.  (36, 6): H / 2 = 18, num_radial = 6 and an edge width of 114 are not multiples of four - most dense layers of that
+    network stay on plain threads, a few run on the matrix pipe; (40, 12) and (64, 20): nearly all on the matrix pipe.)"""
+    from oareactdiff_amd import _capi
+    from oareactdiff_amd.dynamics import EGNNDynamics
+    from oareactdiff_amd.graph_tools import get_edges_index, get_mask_for_frag, get_n_frag_switch
+    from oareactdiff_amd.spec import PRODUCTION_LEFTNET_CONFIG, state_spec, synthetic_state_dict
+    dev = torch.device("cuda:0")
+    cfg = dict(PRODUCTION_LEFTNET_CONFIG, num_layers=2, hidden_channels=hidden, num_radial=radial)
+    sd = synthetic_state_dict(state_spec(cfg, [9, 9, 9], 1), cfg, seed=3)
+    dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0, condition_nf=1, device=dev)
+    dyn.load_state_dict(sd, strict=True)
+    natm = [torch.tensor([5, 9, 3]) for _ in range(3)]
+    masks = [get_mask_for_frag(n) for n in natm]
+    cm, nfs = torch.cat(masks), get_n_frag_switch(natm)
+    g = torch.Generator().manual_seed(hidden + radial)
+    xh = [torch.cat([2.0 * torch.randn(m.numel(), 3, generator=g), torch.rand(m.numel(), 6, generator=g)], 1) for m in masks]
+    full = get_edges_index(cm, remove_self_edge=True)
+    cut = get_edges_index(cm, pos=torch.cat([x[:, :3] for x in xh]), edge_cutoff=4.0, remove_self_edge=True)
+    assert 0 < cut.shape[1] < full.shape[1]
+    t, cond = torch.rand(3, 1, generator=g), torch.rand(3, 1, generator=g)
+    for name, ei in (("complete", full), ("edge_cutoff", cut)):
+        with torch.no_grad():
+            if name == "complete":
+                with pytest.warns(UserWarning, match="not a width pair the production kernels were built for"):
+                    out, _ = dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+            else:
+                out, _ = dyn([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+        assert dyn._last_topo.graph is not None and dyn._last_topo.handle is None
+        ref = oracle.dynamics_forward({k: v.double() for k, v in sd.items()}, cfg, [x.double() for x in xh], ei, t.double(), cond.double(), nfs, cm, 1,
+                                      nodeframe="literal")
+        v = torch.cat([o[:, :3].cpu().double().reshape(-1) for o in out]); h = torch.cat([o[:, 3:].cpu().double().reshape(-1) for o in out])
+        rv = torch.cat([o[:, :3].reshape(-1) for o in ref]); rh = torch.cat([o[:, 3:].reshape(-1) for o in ref])
+        print(f"H {hidden} R {radial}, {name}: {ei.shape[1]} edges, vel {rel(v, rv):.2e} h {rel(h, rh):.2e}")
+        assert rel(v, rv) <= TOL and rel(h, rh) <= TOL
+    with pytest.raises(_capi.OardError, match="not built"):                 # under autograd: the backward pass exists for built widths only
+        dyn([x.to(dev) for x in xh], full.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+
+
 def test_edge_cutoff_batch_against_the_oracle():
     """get_edges_index(combined_mask, pos, edge_cutoff) (utils/_graph_tools.py:31-33) on a ragged batch at production dims, against the
     float64 oracle (literal node frame) evaluated here."""
