@@ -35,15 +35,29 @@ ev = max(rel(o[:, :3].cpu(), r[:, :3]) for o, r in zip(out, ref))
 eh = max(rel(o[:, 3:].cpu(), r[:, 3:]) for o, r in zip(out, ref))
 print(f"DIMS64x16 vel {ev:.3e} h {eh:.3e}")
 assert ev <= 1e-5 and eh <= 1e-5
-# and the widths this scratch build leaves out are refused loudly
-cfg2 = dict(PRODUCTION_LEFTNET_CONFIG)
+# the widths this scratch build leaves out: inference runs the general-edge-list kernels (run-time widths; a warning names the rebuild),
+# training - which exists for built widths only - is refused loudly
+import warnings
+cfg2 = dict(PRODUCTION_LEFTNET_CONFIG, num_layers=2)
+sd2 = synthetic_state_dict(state_spec(cfg2, [9, 9, 9], 1), cfg2)
 d2 = EGNNDynamics(model_config=dict(cfg2), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0, condition_nf=1, device=dev)
-try:
+d2.load_state_dict(sd2, strict=True)
+with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter("always")
     with torch.no_grad():
-        d2([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
-    raise SystemExit("196x96 should not be in this build")
+        out2, _ = d2([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))
+assert any("not a width pair the production kernels were built for" in str(w.message) for w in caught), [str(w.message) for w in caught]
+assert d2._last_topo.graph is not None and d2._last_topo.handle is None
+ref2 = oracle.dynamics_forward({k: v.double() for k, v in sd2.items()}, cfg2, [x.double() for x in xh], ei, t.double(), cond.double(),
+                               nfs, cm, 1, nodeframe="literal")
+ev2 = max(rel(o[:, :3].cpu(), r[:, :3]) for o, r in zip(out2, ref2))
+assert ev2 <= 1e-5, ev2
+print(f"GENERAL196x96 vel {ev2:.3e}")
+try:
+    d2([x.to(dev) for x in xh], ei.to(dev), t.to(dev), cond.to(dev), nfs.to(dev), cm.to(dev))          # under autograd
+    raise SystemExit("196x96 is not in this build: its training-mode forward must raise")
 except _capi.OardError:
-    print("REFUSED196x96")
+    print("REFUSEDTRAIN196x96")
 '''
 
 
@@ -96,4 +110,4 @@ def test_rebuild_with_another_width_matches_the_oracle(tmp_path):
     out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + CHILD], cwd=ROOT, env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
-    assert "DIMS64x16" in out.stdout and "REFUSED196x96" in out.stdout
+    assert "DIMS64x16" in out.stdout and "GENERAL196x96" in out.stdout and "REFUSEDTRAIN196x96" in out.stdout
