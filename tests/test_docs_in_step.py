@@ -35,3 +35,22 @@ def test_profile_stamp_belongs_to_the_sources_in_the_tree():
     for key in ("roofline", "cpu_baseline"):
         assert key in line
     assert line["config"]["workload"] and line["unit"] == "reaction-steps/s"
+
+
+def test_committed_bench_line_carries_every_leg():
+    """The default `bench.py` run measures more than the headline: the T = 1000 loop, the training step, the split-precision line, config 5 and
+    (round 6) the general-edge-list path beside the production kernels.  The committed line of the round has them all, and the two independent
+    implementations of the network agree on the headline batch."""
+    import bench
+    path = os.path.join(ROOT, "profiles", f"{bench.PROFILE_TAG}_bench_line.json")
+    if not os.path.exists(path):
+        pytest.skip("no committed bench line yet")
+    d = json.load(open(path))
+    for leg in ("roofline", "sampler_loop", "train_step", "second_line", "config5", "general_edge_lists", "cpu_baseline"):
+        assert d.get(leg), leg
+    s = d["sampler_loop"]
+    assert s["T"] == 1000 and s["active_inner_edges_in_the_last_call"] == s["inner_edges"]          # the loop ran on the full radius graph
+    g = d["general_edge_lists"]
+    cg, ct = g["complete_graph"], g["edge_cutoff_4A"]
+    assert cg["max_abs_difference_over_max_abs"] <= 1e-5 and 0 < ct["edges"] < cg["edges"]
+    assert cg["ms_per_call_general"] > cg["ms_per_call_production"] > 0 and ct["ms_per_call_general"] > 0
