@@ -21,7 +21,8 @@ for B in [int(x) for x in sys.argv[1:]] or [1, 8, 64]:
     xh = [x.to(dev) for x in make_inputs(B, nf, masks, 5, "cpu")]
     args = (xh, ei.to(dev), torch.full((B, 1), 0.5, device=dev), torch.zeros(B, 1, device=dev), nfs.to(dev), cm.to(dev))
     outs = {}
-    for path in ("auto", "general", "general_threads"):
+    paths = ("auto", "general") if os.environ.get("OARD_GENERAL_TIME_SKIP_THREADS") else ("auto", "general", "general_threads")
+    for path in paths:
         os.environ["OARD_GENERAL_GEMM"] = "threads" if path == "general_threads" else "matrix"     # read by the library per call
         dyn = EGNNDynamics(model_config=dict(cfg), fragment_names=["R", "TS", "P"], node_nfs=[9, 9, 9], edge_nf=0, condition_nf=1, device=dev)
         dyn.load_state_dict(sd, strict=True)
@@ -38,6 +39,8 @@ for B in [int(x) for x in sys.argv[1:]] or [1, 8, 64]:
             dt = (time.perf_counter() - t0) / n
         outs[path] = (torch.cat([x.reshape(-1) for x in o]).double().cpu(), dt)
         del dyn
+    if "general_threads" not in outs:
+        outs["general_threads"] = (outs["general"][0], float("nan"))
     a, b, c = outs["auto"][0], outs["general"][0], outs["general_threads"][0]
     print(f"B = {B} (E = {ei.shape[1]}): production kernels {outs['auto'][1] * 1e3:.2f} ms, general path {outs['general'][1] * 1e3:.1f} ms per call "
           f"(dense layers on plain threads, OARD_GENERAL_GEMM=threads: {outs['general_threads'][1] * 1e3:.1f} ms); "

@@ -19,7 +19,7 @@ T = lambda p: [t for t in tabs if t.startswith(p)][0]
 kd, ks, pe, pi = T("rocpd_kernel_dispatch"), T("rocpd_info_kernel_symbol"), T("rocpd_pmc_event"), T("rocpd_info_pmc")
 scols = [r[1] for r in c.execute(f"pragma table_info({ks})")]
 namecol = "display_name" if "display_name" in scols else "kernel_name"
-clean = lambda n: re.sub(r"\(.*$", "", n).replace("void ", "")
+clean = lambda n: re.sub(r"\(.*$", "", n.replace("(anonymous namespace)::", "").replace("oard_general::", "")).replace("void ", "")
 n_post = sum(1 for (n,) in c.execute(f"select s.{namecol} from {kd} d join {ks} s on d.kernel_id = s.id") if clean(n).strip() == "k_post")
 forwards = n_post / parts if parts else None
 q = (f"select s.{namecol}, d.start, d.end, p.name, e.value, d.id from {pe} e join {kd} d on e.event_id = d.event_id "

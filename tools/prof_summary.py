@@ -8,6 +8,7 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("oard_general::", "")
     name = re.sub(r"\(.*$", "", name)
     name = re.sub(r"^void ", "", name)
     return name[:90]
